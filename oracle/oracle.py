@@ -1,0 +1,243 @@
+"""ctypes binding of the CPU oracle (oracle/snake_oracle.cpp).
+
+TEST INFRASTRUCTURE ONLY -- imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py, never by the product package.  PARITY UNPINNED: see
+snake_oracle.h.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class OrcParams(C.Structure):
+    _fields_ = [
+        ("n_modules", C.c_int32), ("inertia_from_file", C.c_int32),
+        ("default_mass", C.c_double), ("collision_margin", C.c_double),
+        ("hull_sides", C.c_int32),
+        ("dt", C.c_double), ("gravity_z", C.c_double),
+        ("lin_damping", C.c_double), ("ang_damping", C.c_double),
+        ("joint_damping", C.c_double), ("max_coord_vel", C.c_double),
+        ("kp", C.c_double), ("kd", C.c_double), ("max_motor_impulse", C.c_double),
+        ("joint_lo", C.c_double), ("joint_hi", C.c_double),
+        ("limit_erp", C.c_double), ("limit_max_impulse", C.c_double),
+        ("mu_link", C.c_double), ("aniso", C.c_double * 3),
+        ("contact_erp", C.c_double), ("linear_slop", C.c_double),
+        ("breaking_threshold", C.c_double), ("cone_friction", C.c_int32),
+        ("n_iterations", C.c_int32), ("residual_threshold", C.c_double),
+        ("scaling_factor", C.c_double), ("gait", C.c_int32),
+        ("servo_tol", C.c_double), ("max_counter", C.c_int32),
+        ("height_threshold", C.c_double), ("energy_dt", C.c_double),
+        ("alpha", C.c_double), ("beta", C.c_double), ("gamma", C.c_double),
+        ("term_angle", C.c_double), ("term_index", C.c_int32),
+        ("collision_force", C.c_double), ("collision_penalty", C.c_double),
+        ("done_penalty", C.c_double),
+    ]
+
+
+def build(force=False):
+    """Compile liboracle.so / liboracle32.so in place (g++, seconds)."""
+    need = force or not all(
+        os.path.exists(os.path.join(_HERE, f)) for f in ("liboracle.so", "liboracle32.so"))
+    if not need:
+        src = max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("snake_oracle.cpp", "snake_oracle.h"))
+        need = any(os.path.getmtime(os.path.join(_HERE, f)) < src for f in ("liboracle.so", "liboracle32.so"))
+    if need:
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+
+
+_libs = {}
+
+
+def _load(f32=False):
+    key = bool(f32)
+    if key in _libs:
+        return _libs[key]
+    path = os.path.join(_HERE, "liboracle32.so" if f32 else "liboracle.so")
+    if not os.path.exists(path):
+        build()
+    lib = C.CDLL(path)
+    D = C.POINTER(C.c_double)
+    I = C.POINTER(C.c_int32)
+    vp = C.c_void_p
+    sig = {
+        "orc_default_params": (None, [C.POINTER(OrcParams)]),
+        "orc_create": (vp, [C.POINTER(OrcParams)]),
+        "orc_destroy": (None, [vp]),
+        "orc_set_plane_friction": (None, [vp, C.c_double]),
+        "orc_num_links": (C.c_int32, [vp]), "orc_num_dofs": (C.c_int32, [vp]),
+        "orc_obs_dim": (C.c_int32, [vp]), "orc_state_dim": (C.c_int32, [vp]),
+        "orc_get_state": (None, [vp, D]), "orc_set_state": (None, [vp, D]),
+        "orc_get_aux": (None, [vp, D, D, D]), "orc_set_aux": (None, [vp, D, C.c_double, C.c_double]),
+        "orc_hard_reset": (None, [vp]), "orc_reset": (None, [vp, D]),
+        "orc_get_obs": (None, [vp, D]), "orc_mean_height": (C.c_double, [vp]),
+        "orc_substep": (None, [vp, D]),
+        "orc_last_iterations": (C.c_int32, [vp]), "orc_last_num_contacts": (C.c_int32, [vp]),
+        "orc_env_step": (None, [vp, D, C.c_int32, D, D, I, I]),
+        "orc_link_com_world": (None, [vp, D]), "orc_joint_axes_world": (None, [vp, D, D]),
+        "orc_link_inertials": (None, [vp, D]), "orc_link_parents": (None, [vp, I]),
+        "orc_forward_dynamics": (None, [vp, D, C.c_int32, C.c_int32, D]),
+        "orc_minv_mul": (None, [vp, D, D]),
+        "orc_momentum": (None, [vp, D, D, D]),
+        "orc_contacts": (C.c_int32, [vp, D, C.c_int32]),
+        "orc_last_normal_impulses": (C.c_int32, [vp, D, C.c_int32]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _libs[key] = lib
+    return lib
+
+
+def default_params(**over):
+    p = OrcParams()
+    _load().orc_default_params(C.byref(p))
+    for k, v in over.items():
+        if k == "aniso":
+            for i in range(3):
+                p.aniso[i] = v[i]
+        else:
+            setattr(p, k, v)
+    return p
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class OracleEnv:
+    """One environment of the CPU oracle."""
+
+    def __init__(self, params=None, f32=False, **over):
+        self.lib = _load(f32)
+        self.params = params if params is not None else default_params(**over)
+        self.h = self.lib.orc_create(C.byref(self.params))
+        self.n = self.params.n_modules
+        self.L = self.lib.orc_num_links(self.h)
+        self.nd = self.lib.orc_num_dofs(self.h)
+        self.obs_dim = self.lib.orc_obs_dim(self.h)
+        self.state_dim = self.lib.orc_state_dim(self.h)
+        self.act_dim = self.n // 2 if self.params.gait in (0, 1) else self.n
+
+    def __del__(self):
+        try:
+            self.lib.orc_destroy(self.h)
+        except Exception:
+            pass
+
+    def set_plane_friction(self, mu):
+        self.lib.orc_set_plane_friction(self.h, float(mu))
+
+    def get_state(self):
+        s = np.zeros(self.state_dim)
+        self.lib.orc_get_state(self.h, _dp(s))
+        return s
+
+    def set_state(self, s):
+        s = np.ascontiguousarray(s, dtype=np.float64)
+        assert s.shape == (self.state_dim,)
+        self.lib.orc_set_state(self.h, _dp(s))
+
+    def get_aux(self):
+        tau = np.zeros(self.n)
+        fz = C.c_double()
+        px = C.c_double()
+        self.lib.orc_get_aux(self.h, _dp(tau), C.byref(fz), C.byref(px))
+        return tau, fz.value, px.value
+
+    def set_aux(self, tau, fz, prev_x):
+        tau = np.ascontiguousarray(tau, dtype=np.float64)
+        self.lib.orc_set_aux(self.h, _dp(tau), float(fz), float(prev_x))
+
+    def hard_reset(self):
+        self.lib.orc_hard_reset(self.h)
+
+    def reset(self):
+        o = np.zeros(self.obs_dim)
+        self.lib.orc_reset(self.h, _dp(o))
+        return o
+
+    def get_obs(self):
+        o = np.zeros(self.obs_dim)
+        self.lib.orc_get_obs(self.h, _dp(o))
+        return o
+
+    def mean_height(self):
+        return self.lib.orc_mean_height(self.h)
+
+    def substep(self, targets):
+        t = np.ascontiguousarray(targets, dtype=np.float64)
+        assert t.shape == (self.n,)
+        self.lib.orc_substep(self.h, _dp(t))
+
+    @property
+    def last_iterations(self):
+        return self.lib.orc_last_iterations(self.h)
+
+    @property
+    def last_num_contacts(self):
+        return self.lib.orc_last_num_contacts(self.h)
+
+    def env_step(self, action, vec_mode=False):
+        a = np.ascontiguousarray(action, dtype=np.float64).reshape(-1).copy()
+        assert a.shape == (self.act_dim,)
+        o = np.zeros(self.obs_dim)
+        r = C.c_double()
+        d = C.c_int32()
+        k = C.c_int32()
+        self.lib.orc_env_step(self.h, _dp(a), 1 if vec_mode else 0, _dp(o), C.byref(r), C.byref(d), C.byref(k))
+        return o, r.value, bool(d.value), k.value, a
+
+    def link_com_world(self):
+        out = np.zeros((self.L, 3))
+        self.lib.orc_link_com_world(self.h, _dp(out))
+        return out
+
+    def joint_axes_world(self):
+        ax = np.zeros((self.n, 3))
+        org = np.zeros((self.n, 3))
+        self.lib.orc_joint_axes_world(self.h, _dp(ax), _dp(org))
+        return ax, org
+
+    def link_inertials(self):
+        out = np.zeros((self.L, 7))
+        self.lib.orc_link_inertials(self.h, _dp(out))
+        return out
+
+    def link_parents(self):
+        out = np.zeros(self.L, dtype=np.int32)
+        self.lib.orc_link_parents(self.h, out.ctypes.data_as(C.POINTER(C.c_int32)))
+        return out
+
+    def forward_dynamics(self, tau=None, gravity=True, damping=True):
+        tau = np.zeros(self.n) if tau is None else np.ascontiguousarray(tau, dtype=np.float64)
+        acc = np.zeros(self.nd)
+        self.lib.orc_forward_dynamics(self.h, _dp(tau), int(gravity), int(damping), _dp(acc))
+        return acc
+
+    def minv_mul(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.zeros(self.nd)
+        self.lib.orc_minv_mul(self.h, _dp(x), _dp(y))
+        return y
+
+    def momentum(self):
+        lin = np.zeros(3)
+        ang = np.zeros(3)
+        k = C.c_double()
+        self.lib.orc_momentum(self.h, _dp(lin), _dp(ang), C.byref(k))
+        return lin, ang, k.value
+
+    def contacts(self, maxc=256):
+        out = np.zeros((maxc, 5))
+        nc = self.lib.orc_contacts(self.h, _dp(out), maxc)
+        return out[:nc]
+
+    def last_normal_impulses(self, maxc=256):
+        out = np.zeros(maxc)
+        nc = self.lib.orc_last_normal_impulses(self.h, _dp(out), maxc)
+        return out[:nc]

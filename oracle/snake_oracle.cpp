@@ -1,0 +1,1213 @@
+/*
+ * snake_oracle.cpp -- CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * A plain restatement, in double precision (or -DORC_REAL=float), of what the
+ * reference's SnakeGymEnv.step()/reset() path computes, i.e. of the PyBullet calls
+ * sequenced by /root/reference/snake.py and /root/reference/SnakeGymEnv.py.
+ *
+ * PARITY UNPINNED.  The physics arithmetic lives in the third-party `pybullet`
+ * wheel (bullet3; version not pinned by the reference, era 2.5.9-2.6.x), which is
+ * not in this image.  The restatement below follows Bullet's published algorithm
+ * (btMultiBody articulated-body algorithm, btMultiBodyConstraintSolver projected
+ * Gauss-Seidel, btConvexPlaneCollisionAlgorithm, URDF import rules); each rule
+ * taken from knowledge of those sources is tagged [U] (unverified here) and is a
+ * field of orc_params.  Known deviations from Bullet are listed in DESIGN.md §3.
+ *
+ * Structure: the model is the UNMERGED URDF tree (root + 3n+1 links, 2n+1 of them
+ * behind fixed joints), exactly as Bullet keeps it when URDF_MERGE_FIXED_LINKS is
+ * not passed (snake.py:93), and the dynamics use Featherstone's link-coordinate
+ * spatial algebra.  The product (bullet-envs_amd/csrc) deliberately uses a
+ * different formulation (merged composite bodies, world-aligned classical
+ * accelerations), so GPU-vs-oracle parity is also a cross-formulation check.
+ *
+ * Conventions: spatial motion m = [omega; v_O], spatial force f = [n_O; f],
+ * both in link coordinates with O the link-frame origin.  Link frames are the URDF
+ * link frames (Bullet uses the inertial frames; every inertial rpy in snake.urdf is
+ * zero, so the two differ by a translation only and all physical outputs agree).
+ */
+#include "snake_oracle.h"
+
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <vector>
+
+#ifndef ORC_REAL
+#define ORC_REAL double
+#endif
+typedef ORC_REAL Real;
+
+namespace {
+
+const double kPi = 3.14159265358979323846;
+
+/* ---------- tiny linear algebra ---------- */
+inline void cross3(const Real* a, const Real* b, Real* o) {
+    Real x = a[1] * b[2] - a[2] * b[1];
+    Real y = a[2] * b[0] - a[0] * b[2];
+    Real z = a[0] * b[1] - a[1] * b[0];
+    o[0] = x; o[1] = y; o[2] = z;
+}
+inline Real dot3(const Real* a, const Real* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+inline void mat3_mul(const Real* A, const Real* B, Real* C) {
+    Real t[9];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++)
+            t[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+    memcpy(C, t, sizeof(t));
+}
+inline void mat3_vec(const Real* A, const Real* v, Real* o) {
+    Real t[3];
+    for (int i = 0; i < 3; i++) t[i] = A[3 * i] * v[0] + A[3 * i + 1] * v[1] + A[3 * i + 2] * v[2];
+    o[0] = t[0]; o[1] = t[1]; o[2] = t[2];
+}
+inline void mat3T_vec(const Real* A, const Real* v, Real* o) {
+    Real t[3];
+    for (int i = 0; i < 3; i++) t[i] = A[i] * v[0] + A[3 + i] * v[1] + A[6 + i] * v[2];
+    o[0] = t[0]; o[1] = t[1]; o[2] = t[2];
+}
+inline void mat3_T(const Real* A, Real* B) {
+    Real t[9];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) t[3 * i + j] = A[3 * j + i];
+    memcpy(B, t, sizeof(t));
+}
+/* URDF rpy -> rotation Rz(yaw) Ry(pitch) Rx(roll) */
+void rpy_to_mat(double roll, double pitch, double yaw, Real* R) {
+    double cr = cos(roll), sr = sin(roll), cp = cos(pitch), sp = sin(pitch), cy = cos(yaw), sy = sin(yaw);
+    R[0] = cy * cp; R[1] = cy * sp * sr - sy * cr; R[2] = cy * sp * cr + sy * sr;
+    R[3] = sy * cp; R[4] = sy * sp * sr + cy * cr; R[5] = sy * sp * cr - cy * sr;
+    R[6] = -sp;     R[7] = cp * sr;                R[8] = cp * cr;
+}
+/* rotation by angle about unit axis */
+void axis_angle_mat(const Real* ax, Real q, Real* R) {
+    Real c = std::cos(q), s = std::sin(q), t = 1 - c;
+    Real x = ax[0], y = ax[1], z = ax[2];
+    R[0] = t * x * x + c;     R[1] = t * x * y - s * z; R[2] = t * x * z + s * y;
+    R[3] = t * x * y + s * z; R[4] = t * y * y + c;     R[5] = t * y * z - s * x;
+    R[6] = t * x * z - s * y; R[7] = t * y * z + s * x; R[8] = t * z * z + c;
+}
+void quat_to_mat(const Real* q, Real* R) { /* xyzw */
+    Real x = q[0], y = q[1], z = q[2], w = q[3];
+    Real d = x * x + y * y + z * z + w * w;
+    Real s = Real(2) / d;
+    Real xs = x * s, ys = y * s, zs = z * s;
+    Real wx = w * xs, wy = w * ys, wz = w * zs;
+    Real xx = x * xs, xy = x * ys, xz = x * zs, yy = y * ys, yz = y * zs, zz = z * zs;
+    R[0] = 1 - (yy + zz); R[1] = xy - wz;       R[2] = xz + wy;
+    R[3] = xy + wz;       R[4] = 1 - (xx + zz); R[5] = yz - wx;
+    R[6] = xz - wy;       R[7] = yz + wx;       R[8] = 1 - (xx + yy);
+}
+
+inline void mat6_vec(const Real* A, const Real* v, Real* o) {
+    Real t[6];
+    for (int i = 0; i < 6; i++) {
+        Real s = 0;
+        for (int j = 0; j < 6; j++) s += A[6 * i + j] * v[j];
+        t[i] = s;
+    }
+    memcpy(o, t, sizeof(t));
+}
+/* C = X^T A X, all 6x6 */
+void xtax(const Real* X, const Real* A, Real* C) {
+    Real T[36];
+    for (int i = 0; i < 6; i++)
+        for (int j = 0; j < 6; j++) {
+            Real s = 0;
+            for (int k = 0; k < 6; k++) s += A[6 * i + k] * X[6 * k + j];
+            T[6 * i + j] = s;
+        }
+    for (int i = 0; i < 6; i++)
+        for (int j = 0; j < 6; j++) {
+            Real s = 0;
+            for (int k = 0; k < 6; k++) s += X[6 * k + i] * T[6 * k + j];
+            C[6 * i + j] = s;
+        }
+}
+/* solve 6x6 SPD system in place by Cholesky; A is destroyed */
+void chol6_factor(Real* A) {
+    for (int j = 0; j < 6; j++) {
+        Real s = A[6 * j + j];
+        for (int k = 0; k < j; k++) s -= A[6 * j + k] * A[6 * j + k];
+        Real d = std::sqrt(s);
+        A[6 * j + j] = d;
+        for (int i = j + 1; i < 6; i++) {
+            Real t = A[6 * i + j];
+            for (int k = 0; k < j; k++) t -= A[6 * i + k] * A[6 * j + k];
+            A[6 * i + j] = t / d;
+        }
+    }
+}
+void chol6_solve(const Real* L, const Real* b, Real* x) {
+    Real y[6];
+    for (int i = 0; i < 6; i++) {
+        Real s = b[i];
+        for (int k = 0; k < i; k++) s -= L[6 * i + k] * y[k];
+        y[i] = s / L[6 * i + i];
+    }
+    for (int i = 5; i >= 0; i--) {
+        Real s = y[i];
+        for (int k = i + 1; k < 6; k++) s -= L[6 * k + i] * x[k];
+        x[i] = s / L[6 * i + i];
+    }
+}
+
+/* ---------- model ---------- */
+struct Link {
+    int parent;
+    int revolute;        /* 0 fixed, 1 revolute */
+    Real Rfix[9];        /* child frame in parent coords at q=0 */
+    Real pfix[3];
+    Real axis[3];        /* in child (= joint) frame */
+    Real mass;
+    Real com[3];
+    Real Icom[3];        /* diagonal, link axes, about COM */
+    int dof;             /* joint dof index 0..n-1 or -1 */
+    int has_cyl;
+    Real cyl_c[3];
+};
+
+struct Row {
+    std::vector<Real> J, M;  /* [6+n] */
+    Real dinv, rhs, lo, hi, applied;
+    int kind;                /* 0 limit, 1 motor, 2 normal, 3 friction */
+    int joint;               /* for limit/motor */
+    int contact;             /* for normal/friction */
+    Real dir[3];             /* world direction (friction: anisotropically scaled) */
+};
+
+struct Contact {
+    int link;
+    Real P[3];   /* world point on the link */
+    Real dist;
+};
+
+}  // namespace
+
+struct orc_env {
+    orc_params P;
+    int n, L, nd;
+    std::vector<Link> links;
+    std::vector<int> dof_link;   /* dof -> link index */
+    Real cyl_r, cyl_len;
+    double mu_plane;
+    /* state */
+    Real pos[3], quat[4], omega[3], vel[3];
+    std::vector<Real> q, qd, tau_motor;
+    Real fz, prev_x;
+    /* workspace, per link */
+    std::vector<Real> Rw, ow, E, X, v, c, I6, IA, pA, U, a, S;
+    std::vector<Real> D, u;
+    Real L0[36];   /* Cholesky factor of IA[0] */
+    int fk_valid;
+    /* last substep info */
+    int last_iters;
+    std::vector<Contact> contacts;
+    std::vector<Real> last_normal_impulse;
+};
+
+namespace {
+
+void build_model(orc_env* e) {
+    const orc_params& P = e->P;
+    int n = P.n_modules;
+    e->n = n;
+    e->L = 3 * n + 2;
+    e->nd = 6 + n;
+    e->links.clear();
+    e->dof_link.assign(n, -1);
+    e->cyl_r = 0.026;      /* snake.urdf:809 */
+    e->cyl_len = 0.033;    /* snake.urdf:809 */
+    const double m_link = 0.103;                                  /* snake.urdf:814,870 */
+    const double I_file[3] = {5.4796e-05, 5.4796e-05, 3.4814e-05}; /* snake.urdf:815,871 */
+    const double mg = P.collision_margin;
+
+    /* [U] Bullet import rule: inertia from the collision compound's AABB box
+     * (btCompoundShape::calculateLocalInertia).  Half extents: the hull's cached local
+     * AABB carries one margin, getAabb adds a second, the compound a third.  A link with
+     * no collision shape has an empty compound whose AABB is margin-sized. */
+    double hx = 0.026 + 3 * mg, hz = 0.033 / 2 + 3 * mg;
+    double lx = 2 * hx, lz = 2 * hz;
+    double I_cyl_aabb[3] = {m_link / 12.0 * (lx * lx + lz * lz), m_link / 12.0 * (lx * lx + lz * lz),
+                            m_link / 12.0 * (lx * lx + lx * lx)};
+    double le = 2 * mg;
+    double I_empty = P.default_mass / 12.0 * (le * le + le * le);
+
+    auto ident = [](Real* R) { for (int i = 0; i < 9; i++) R[i] = (i % 4 == 0) ? 1 : 0; };
+    auto massless = [&](Link& k) {
+        /* [U] URDF parser: "No inertial data for link, using mass=1, localinertiadiagonal = 1,1,1" */
+        k.mass = P.default_mass;
+        k.com[0] = k.com[1] = k.com[2] = 0;
+        for (int i = 0; i < 3; i++) k.Icom[i] = P.inertia_from_file ? 1.0 : I_empty;
+    };
+    auto bodylink = [&](Link& k, double comz) {
+        k.mass = m_link;
+        k.com[0] = 0; k.com[1] = 0; k.com[2] = comz;
+        for (int i = 0; i < 3; i++) k.Icom[i] = P.inertia_from_file ? I_file[i] : I_cyl_aabb[i];
+        k.has_cyl = 1;
+        k.cyl_c[0] = 0; k.cyl_c[1] = 0; k.cyl_c[2] = 0.0183;     /* snake.urdf:807,863 */
+    };
+
+    Link root; memset(&root, 0, sizeof(root));
+    root.parent = -1; root.dof = -1; ident(root.Rfix); massless(root);   /* kdl_dummy_root, urdf:7 */
+    e->links.push_back(root);
+
+    Link base; memset(&base, 0, sizeof(base));
+    base.parent = 0; base.dof = -1;
+    rpy_to_mat(0, -1.57079632679, 0, base.Rfix);                  /* snake.urdf:11 */
+    base.pfix[0] = 0; base.pfix[1] = 0; base.pfix[2] = 0.026;
+    massless(base);                                               /* snake.urdf:14 */
+    e->links.push_back(base);
+
+    for (int k = 1; k <= n; k++) {
+        Link in; memset(&in, 0, sizeof(in));
+        in.dof = -1;
+        if (k == 1) {
+            in.parent = 1; ident(in.Rfix);                        /* snake.urdf:16-20, no origin */
+        } else {
+            in.parent = (int)e->links.size() - 1;                 /* previous OUTPUT_BODY */
+            rpy_to_mat(0, 0, -1.57075, in.Rfix);                  /* snake.urdf:877 */
+            in.pfix[2] = 0.0273;
+        }
+        bodylink(in, 0.0366);                                     /* snake.urdf:813 */
+        int in_idx = (int)e->links.size();
+        e->links.push_back(in);
+
+        Link collar; memset(&collar, 0, sizeof(collar));
+        collar.parent = in_idx; collar.dof = -1; ident(collar.Rfix);
+        massless(collar);                                         /* snake.urdf:818-832 */
+        e->links.push_back(collar);
+
+        Link out; memset(&out, 0, sizeof(out));
+        out.parent = in_idx; out.revolute = 1; ident(out.Rfix);
+        out.pfix[2] = 0.0366;                                     /* snake.urdf:836 */
+        out.axis[1] = 1;                                          /* snake.urdf:837 */
+        out.dof = k - 1;
+        bodylink(out, 0.0);                                       /* snake.urdf:869 */
+        e->dof_link[k - 1] = (int)e->links.size();
+        e->links.push_back(out);
+    }
+    int L = e->L;
+    e->Rw.assign(9 * L, 0); e->ow.assign(3 * L, 0); e->E.assign(9 * L, 0); e->X.assign(36 * L, 0);
+    e->v.assign(6 * L, 0); e->c.assign(6 * L, 0); e->I6.assign(36 * L, 0); e->IA.assign(36 * L, 0);
+    e->pA.assign(6 * L, 0); e->U.assign(6 * L, 0); e->a.assign(6 * L, 0); e->S.assign(6 * L, 0);
+    e->D.assign(L, 0); e->u.assign(L, 0);
+    e->q.assign(n, 0); e->qd.assign(n, 0); e->tau_motor.assign(n, 0);
+    /* constant spatial inertias and joint axes in link coords */
+    for (int i = 0; i < L; i++) {
+        const Link& k = e->links[i];
+        Real* I = &e->I6[36 * i];
+        const Real* cc = k.com;
+        Real m = k.mass;
+        Real cx[9] = {0, -cc[2], cc[1], cc[2], 0, -cc[0], -cc[1], cc[0], 0};
+        Real c2 = dot3(cc, cc);
+        for (int r = 0; r < 3; r++)
+            for (int s = 0; s < 3; s++) {
+                Real Ibar = (r == s ? k.Icom[r] : 0) + m * ((r == s ? c2 : 0) - cc[r] * cc[s]);
+                I[6 * r + s] = Ibar;
+                I[6 * r + 3 + s] = m * cx[3 * r + s];
+                I[6 * (3 + r) + s] = m * cx[3 * s + r];
+                I[6 * (3 + r) + 3 + s] = (r == s) ? m : 0;
+            }
+        Real* S = &e->S[6 * i];
+        for (int r = 0; r < 3; r++) { S[r] = k.revolute ? k.axis[r] : 0; S[3 + r] = 0; }
+    }
+}
+
+/* forward kinematics: world pose of every link, parent->child motion transforms */
+void fk(orc_env* e) {
+    int L = e->L;
+    quat_to_mat(e->quat, &e->Rw[0]);
+    for (int i = 0; i < 3; i++) e->ow[i] = e->pos[i];
+    for (int i = 1; i < L; i++) {
+        const Link& k = e->links[i];
+        Real Rpc[9];
+        if (k.revolute) {
+            Real Rq[9];
+            axis_angle_mat(k.axis, e->q[k.dof], Rq);
+            mat3_mul(k.Rfix, Rq, Rpc);
+        } else {
+            memcpy(Rpc, k.Rfix, sizeof(Rpc));
+        }
+        int p = k.parent;
+        mat3_mul(&e->Rw[9 * p], Rpc, &e->Rw[9 * i]);
+        Real t[3];
+        mat3_vec(&e->Rw[9 * p], k.pfix, t);
+        for (int r = 0; r < 3; r++) e->ow[3 * i + r] = e->ow[3 * p + r] + t[r];
+        Real* E = &e->E[9 * i];
+        mat3_T(Rpc, E);
+        /* X = [[E,0],[-E rx, E]] */
+        Real* X = &e->X[36 * i];
+        const Real* r = k.pfix;
+        Real rx[9] = {0, -r[2], r[1], r[2], 0, -r[0], -r[1], r[0], 0};
+        Real Erx[9];
+        mat3_mul(E, rx, Erx);
+        for (int a = 0; a < 3; a++)
+            for (int b = 0; b < 3; b++) {
+                X[6 * a + b] = E[3 * a + b];
+                X[6 * a + 3 + b] = 0;
+                X[6 * (3 + a) + b] = -Erx[3 * a + b];
+                X[6 * (3 + a) + 3 + b] = E[3 * a + b];
+            }
+    }
+    e->fk_valid = 1;
+}
+
+inline void xmotion(const orc_env* e, int i, const Real* mp, Real* mc) {
+    /* mc = X_i mp */
+    mat6_vec(&e->X[36 * i], mp, mc);
+}
+inline void xforceT(const orc_env* e, int i, const Real* fc, Real* fp) {
+    /* fp = X_i^T fc */
+    const Real* X = &e->X[36 * i];
+    Real t[6];
+    for (int a = 0; a < 6; a++) {
+        Real s = 0;
+        for (int b = 0; b < 6; b++) s += X[6 * b + a] * fc[b];
+        t[a] = s;
+    }
+    memcpy(fp, t, sizeof(t));
+}
+
+/* link spatial velocities from generalized velocity (omega_w, vel_w, qd) */
+void velocities(orc_env* e, const Real* omega_w, const Real* vel_w, const Real* qd) {
+    int L = e->L;
+    mat3T_vec(&e->Rw[0], omega_w, &e->v[0]);
+    mat3T_vec(&e->Rw[0], vel_w, &e->v[3]);
+    for (int i = 1; i < L; i++) {
+        const Link& k = e->links[i];
+        Real* v = &e->v[6 * i];
+        xmotion(e, i, &e->v[6 * k.parent], v);
+        Real* c = &e->c[6 * i];
+        for (int r = 0; r < 6; r++) c[r] = 0;
+        if (k.revolute) {
+            Real vJ[6];
+            for (int r = 0; r < 6; r++) vJ[r] = e->S[6 * i + r] * qd[k.dof];
+            for (int r = 0; r < 6; r++) v[r] += vJ[r];
+            /* c = v x vJ (motion cross product) */
+            cross3(&v[0], &vJ[0], &c[0]);
+            Real t1[3], t2[3];
+            cross3(&v[0], &vJ[3], t1);
+            cross3(&v[3], &vJ[0], t2);
+            for (int r = 0; r < 3; r++) c[3 + r] = t1[r] + t2[r];
+        }
+    }
+}
+
+/* articulated inertias (depends on q only) */
+void aba_factor(orc_env* e) {
+    int L = e->L;
+    memcpy(&e->IA[0], &e->I6[0], sizeof(Real) * 36 * L);
+    for (int i = L - 1; i >= 1; i--) {
+        const Link& k = e->links[i];
+        Real* IA = &e->IA[36 * i];
+        Real Ia[36];
+        if (k.revolute) {
+            Real* U = &e->U[6 * i];
+            mat6_vec(IA, &e->S[6 * i], U);
+            Real D = 0;
+            for (int r = 0; r < 6; r++) D += e->S[6 * i + r] * U[r];
+            e->D[i] = D;
+            for (int r = 0; r < 6; r++)
+                for (int s = 0; s < 6; s++) Ia[6 * r + s] = IA[6 * r + s] - U[r] * U[s] / D;
+        } else {
+            memcpy(Ia, IA, sizeof(Ia));
+        }
+        Real T[36];
+        xtax(&e->X[36 * i], Ia, T);
+        Real* IP = &e->IA[36 * k.parent];
+        for (int r = 0; r < 36; r++) IP[r] += T[r];
+    }
+    memcpy(e->L0, &e->IA[0], sizeof(Real) * 36);
+    chol6_factor(e->L0);
+}
+
+/* bias forces of every link at the current spatial velocities e->v:
+ *   pA_i = v x* I v + damping - f_ext          (link coords)
+ * with_vel: velocity-product (gyroscopic/centrifugal) terms and Bullet's link damping.
+ * gravity: add m g at each link COM.  ext: optional world wrenches (force at world point). */
+struct ExtForce { int link; Real P[3]; Real F[3]; };
+
+void bias_forces(orc_env* e, bool with_vel, bool with_damping, bool with_gravity,
+                 const std::vector<ExtForce>* ext) {
+    int L = e->L;
+    const orc_params& P = e->P;
+    for (int i = 0; i < L; i++) {
+        const Link& k = e->links[i];
+        Real* p = &e->pA[6 * i];
+        for (int r = 0; r < 6; r++) p[r] = 0;
+        const Real* v = &e->v[6 * i];
+        if (with_vel) {
+            Real Iv[6];
+            mat6_vec(&e->I6[36 * i], v, Iv);
+            /* v x* Iv = [w x n + v x f ; w x f] */
+            Real t1[3], t2[3], t3[3];
+            cross3(&v[0], &Iv[0], t1);
+            cross3(&v[3], &Iv[3], t2);
+            cross3(&v[0], &Iv[3], t3);
+            for (int r = 0; r < 3; r++) { p[r] += t1[r] + t2[r]; p[3 + r] += t3[r]; }
+        }
+        if (with_damping) {
+            /* [U] btMultiBody link damping: force m v_com (k + k|v_com|), torque I w (k + k|w|),
+             * both opposing motion, evaluated on the link's COM-frame velocity. */
+            Real vc[3], t[3];
+            cross3(&v[0], k.com, t);
+            for (int r = 0; r < 3; r++) vc[r] = v[3 + r] + t[r];
+            Real nv = std::sqrt(dot3(vc, vc)), nw = std::sqrt(dot3(&v[0], &v[0]));
+            Real F[3], T[3];
+            for (int r = 0; r < 3; r++) {
+                F[r] = k.mass * vc[r] * (Real)(P.lin_damping + P.lin_damping * nv);
+                T[r] = k.Icom[r] * v[r] * (Real)(P.ang_damping + P.ang_damping * nw);
+            }
+            Real cxF[3];
+            cross3(k.com, F, cxF);
+            for (int r = 0; r < 3; r++) { p[r] += T[r] + cxF[r]; p[3 + r] += F[r]; }
+        }
+        if (with_gravity) {
+            Real gw[3] = {0, 0, (Real)(P.gravity_z * k.mass)}, gl[3], cxg[3];
+            mat3T_vec(&e->Rw[9 * i], gw, gl);
+            cross3(k.com, gl, cxg);
+            for (int r = 0; r < 3; r++) { p[r] -= cxg[r]; p[3 + r] -= gl[r]; }
+        }
+    }
+    if (ext) {
+        for (size_t j = 0; j < ext->size(); j++) {
+            const ExtForce& f = (*ext)[j];
+            int i = f.link;
+            Real rel[3], nw[3], nl[3], fl[3];
+            for (int r = 0; r < 3; r++) rel[r] = f.P[r] - e->ow[3 * i + r];
+            cross3(rel, f.F, nw);
+            mat3T_vec(&e->Rw[9 * i], nw, nl);
+            mat3T_vec(&e->Rw[9 * i], f.F, fl);
+            Real* p = &e->pA[6 * i];
+            for (int r = 0; r < 3; r++) { p[r] -= nl[r]; p[3 + r] -= fl[r]; }
+        }
+    }
+}
+
+/* ABA passes 2 and 3 for the bias forces in e->pA, velocity-product accelerations in e->c
+ * (use_c) and joint torques tau[n].  Outputs spatial accelerations e->a (link coords) and
+ * qdd[n].  e->pA holds the articulated bias forces afterwards. */
+void aba_solve(orc_env* e, const Real* tau, bool use_c, Real* qdd) {
+    int L = e->L;
+    for (int i = L - 1; i >= 1; i--) {
+        const Link& k = e->links[i];
+        Real* p = &e->pA[6 * i];
+        Real pa[6];
+        memcpy(pa, p, sizeof(pa));
+        if (k.revolute) {
+            const Real* U = &e->U[6 * i];
+            Real sp = 0;
+            for (int r = 0; r < 6; r++) sp += e->S[6 * i + r] * p[r];
+            Real u = tau[k.dof] - sp;
+            e->u[i] = u;
+            Real Dinv = Real(1) / e->D[i];
+            if (use_c) {
+                const Real* c = &e->c[6 * i];
+                Real t[6];
+                mat6_vec(&e->IA[36 * i], c, t);
+                Real uc = 0;
+                for (int r = 0; r < 6; r++) uc += U[r] * c[r];
+                for (int r = 0; r < 6; r++) pa[r] += t[r] - U[r] * uc * Dinv;
+            }
+            for (int r = 0; r < 6; r++) pa[r] += U[r] * u * Dinv;
+        }
+        Real pp[6];
+        xforceT(e, i, pa, pp);
+        Real* P = &e->pA[6 * k.parent];
+        for (int r = 0; r < 6; r++) P[r] += pp[r];
+    }
+    Real nb[6];
+    for (int r = 0; r < 6; r++) nb[r] = -e->pA[r];
+    chol6_solve(e->L0, nb, &e->a[0]);
+    for (int i = 1; i < L; i++) {
+        const Link& k = e->links[i];
+        Real* a = &e->a[6 * i];
+        xmotion(e, i, &e->a[6 * k.parent], a);
+        if (k.revolute) {
+            if (use_c)
+                for (int r = 0; r < 6; r++) a[r] += e->c[6 * i + r];
+            Real ua = 0;
+            for (int r = 0; r < 6; r++) ua += e->U[6 * i + r] * a[r];
+            Real qa = (e->u[i] - ua) / e->D[i];
+            qdd[k.dof] = qa;
+            for (int r = 0; r < 6; r++) a[r] += e->S[6 * i + r] * qa;
+        }
+    }
+}
+
+/* generalized acceleration in (omega_w, vel_w, q) coordinates from e->a[0] */
+void base_acc_world(const orc_env* e, bool with_vel, Real* acc6) {
+    const Real* a0 = &e->a[0];
+    Real lin[3] = {a0[3], a0[4], a0[5]};
+    if (with_vel) {
+        /* classical acceleration of the origin = spatial + omega x v (Bullet adds the same
+         * term when it maps spatAcc[0] back to the world frame) */
+        Real t[3];
+        cross3(&e->v[0], &e->v[3], t);
+        for (int r = 0; r < 3; r++) lin[r] += t[r];
+    }
+    mat3_vec(&e->Rw[0], &a0[0], &acc6[0]);
+    mat3_vec(&e->Rw[0], lin, &acc6[3]);
+}
+
+/* wrench transmitted through Bullet joint 0 (root -> `base` link), link-1 coordinates:
+ * spatInertia * spatAcc + zeroAccSpatFrc of that link [U] */
+void joint0_wrench(const orc_env* e, Real* w6) {
+    Real t[6];
+    mat6_vec(&e->IA[36 * 1], &e->a[6 * 1], t);
+    for (int r = 0; r < 6; r++) w6[r] = t[r] + e->pA[6 * 1 + r];
+}
+
+/* y = M^-1 J^T for a unit force along d at world point Pw on link `link` (or a unit
+ * generalized force when link < 0: x given in generalized coordinates) */
+void minv_apply(orc_env* e, int link, const Real* Pw, const Real* d, const Real* xgen, Real* y) {
+    int L = e->L, n = e->n;
+    for (int i = 0; i < 6 * L; i++) e->pA[i] = 0;
+    std::vector<Real> tau(n, 0);
+    if (link >= 0) {
+        Real rel[3], nw[3], nl[3], fl[3];
+        for (int r = 0; r < 3; r++) rel[r] = Pw[r] - e->ow[3 * link + r];
+        cross3(rel, d, nw);
+        mat3T_vec(&e->Rw[9 * link], nw, nl);
+        mat3T_vec(&e->Rw[9 * link], d, fl);
+        Real* p = &e->pA[6 * link];
+        for (int r = 0; r < 3; r++) { p[r] = -nl[r]; p[3 + r] = -fl[r]; }
+    } else {
+        Real nl[3], fl[3];
+        mat3T_vec(&e->Rw[0], &xgen[0], nl);
+        mat3T_vec(&e->Rw[0], &xgen[3], fl);
+        for (int r = 0; r < 3; r++) { e->pA[r] = -nl[r]; e->pA[3 + r] = -fl[r]; }
+        for (int j = 0; j < n; j++) tau[j] = xgen[6 + j];
+    }
+    aba_solve(e, tau.data(), false, y + 6);
+    base_acc_world(e, false, y);
+}
+
+/* Jacobian row of the velocity of world point Pw (fixed on `link`) along d */
+void jac_row(const orc_env* e, int link, const Real* Pw, const Real* d, Real* J) {
+    int nd = e->nd;
+    for (int i = 0; i < nd; i++) J[i] = 0;
+    Real rel[3], t[3];
+    for (int r = 0; r < 3; r++) rel[r] = Pw[r] - e->ow[r];
+    cross3(rel, d, t);
+    for (int r = 0; r < 3; r++) { J[r] = t[r]; J[3 + r] = d[r]; }
+    for (int i = link; i > 0; i = e->links[i].parent) {
+        const Link& k = e->links[i];
+        if (!k.revolute) continue;
+        Real aw[3];
+        mat3_vec(&e->Rw[9 * i], k.axis, aw);
+        for (int r = 0; r < 3; r++) rel[r] = Pw[r] - e->ow[3 * i + r];
+        cross3(rel, d, t);
+        J[6 + k.dof] = dot3(aw, t);
+    }
+}
+
+/* ground contacts of the current pose [U]: plane z=0, normal +z; each URDF cylinder is a
+ * 32-gon prism hull inflated by the collision margin; one candidate point per end cap
+ * (the lowest rim vertex), kept when closer than the contact breaking threshold.  This is
+ * the populated state of Bullet's persistent manifold (which adds one deepest point per
+ * frame and caches up to four); see DESIGN.md §3 for the deviation. */
+void find_contacts(orc_env* e) {
+    const orc_params& P = e->P;
+    e->contacts.clear();
+    for (int i = 0; i < e->L; i++) {
+        const Link& k = e->links[i];
+        if (!k.has_cyl) continue;
+        const Real* Rw = &e->Rw[9 * i];
+        Real dl[3] = {-Rw[6], -Rw[7], -Rw[8]};   /* world -z in link coords */
+        for (int end = -1; end <= 1; end += 2) {
+            Real loc[3];
+            if (P.hull_sides > 0) {
+                int best = 0;
+                Real bestv = -std::numeric_limits<Real>::infinity();
+                for (int s = 0; s < P.hull_sides; s++) {
+                    double th = 2.0 * kPi * s / P.hull_sides;
+                    Real vx = (Real)(e->cyl_r * sin(th)), vy = (Real)(e->cyl_r * cos(th));
+                    Real val = dl[0] * vx + dl[1] * vy;
+                    if (val > bestv) { bestv = val; best = s; }
+                }
+                double th = 2.0 * kPi * best / P.hull_sides;
+                loc[0] = (Real)(e->cyl_r * sin(th));
+                loc[1] = (Real)(e->cyl_r * cos(th));
+            } else {
+                Real rr = std::sqrt(dl[0] * dl[0] + dl[1] * dl[1]);
+                if (rr > Real(1e-12)) { loc[0] = e->cyl_r * dl[0] / rr; loc[1] = e->cyl_r * dl[1] / rr; }
+                else { loc[0] = 0; loc[1] = 0; }
+            }
+            loc[2] = end * e->cyl_len / 2;
+            for (int r = 0; r < 3; r++) loc[r] += k.cyl_c[r] + (Real)P.collision_margin * dl[r];
+            Real w[3];
+            mat3_vec(Rw, loc, w);
+            Contact c;
+            c.link = i;
+            for (int r = 0; r < 3; r++) c.P[r] = e->ow[3 * i + r] + w[r];
+            c.dist = c.P[2];
+            if (c.dist < (Real)P.breaking_threshold) e->contacts.push_back(c);
+        }
+    }
+}
+
+void apply_dv(orc_env* e, const Real* dvec, Real mult) {
+    /* btMultiBody::applyDeltaVeeMultiDof: add and clamp to +-m_maxCoordinateVelocity [U] */
+    Real mx = (Real)e->P.max_coord_vel;
+    auto clampv = [&](Real& x) { if (x > mx) x = mx; if (x < -mx) x = -mx; };
+    for (int r = 0; r < 3; r++) { e->omega[r] += dvec[r] * mult; clampv(e->omega[r]); }
+    for (int r = 0; r < 3; r++) { e->vel[r] += dvec[3 + r] * mult; clampv(e->vel[r]); }
+    for (int j = 0; j < e->n; j++) { e->qd[j] += dvec[6 + j] * mult; clampv(e->qd[j]); }
+}
+
+void integrate_positions(orc_env* e) {
+    Real dt = (Real)e->P.dt;
+    for (int j = 0; j < e->n; j++) e->q[j] += dt * e->qd[j];
+    for (int r = 0; r < 3; r++) e->pos[r] += dt * e->vel[r];
+    /* [U] btMultiBody::stepPositionsMultiDof quaternion update (exponential map) */
+    Real fAngle = std::sqrt(dot3(e->omega, e->omega));
+    const Real kThresh = (Real)(0.5 * (kPi / 2));
+    if (fAngle * dt > kThresh) fAngle = kThresh / dt;
+    Real ax[3];
+    if (fAngle < Real(0.001)) {
+        Real s = Real(0.5) * dt - (dt * dt * dt) * Real(0.020833333333) * fAngle * fAngle;
+        for (int r = 0; r < 3; r++) ax[r] = e->omega[r] * s;
+    } else {
+        Real s = std::sin(Real(0.5) * fAngle * dt) / fAngle;
+        for (int r = 0; r < 3; r++) ax[r] = e->omega[r] * s;
+    }
+    Real dq[4] = {ax[0], ax[1], ax[2], std::cos(fAngle * dt * Real(0.5))};
+    Real* q = e->quat;
+    /* world orientation <- dq * q */
+    Real nq[4];
+    nq[3] = dq[3] * q[3] - dq[0] * q[0] - dq[1] * q[1] - dq[2] * q[2];
+    nq[0] = dq[3] * q[0] + dq[0] * q[3] + dq[1] * q[2] - dq[2] * q[1];
+    nq[1] = dq[3] * q[1] - dq[0] * q[2] + dq[1] * q[3] + dq[2] * q[0];
+    nq[2] = dq[3] * q[2] + dq[0] * q[1] - dq[1] * q[0] + dq[2] * q[3];
+    Real nn = std::sqrt(nq[0] * nq[0] + nq[1] * nq[1] + nq[2] * nq[2] + nq[3] * nq[3]);
+    for (int r = 0; r < 4; r++) q[r] = nq[r] / nn;
+    e->fk_valid = 0;
+}
+
+/* one row of btMultiBodyConstraintSolver::resolveSingleConstraintRowGeneric [U] */
+inline Real resolve_row(Row& c, std::vector<Real>& dv, int nd) {
+    Real dvn = 0;
+    for (int i = 0; i < nd; i++) dvn += c.J[i] * dv[i];
+    Real dI = c.rhs - dvn * c.dinv;
+    Real sum = c.applied + dI;
+    if (sum < c.lo) { dI = c.lo - c.applied; c.applied = c.lo; }
+    else if (sum > c.hi) { dI = c.hi - c.applied; c.applied = c.hi; }
+    else c.applied = sum;
+    for (int i = 0; i < nd; i++) dv[i] += c.M[i] * dI;
+    return c.dinv != 0 ? dI / c.dinv : 0;
+}
+
+void substep(orc_env* e, const Real* targets) {
+    const orc_params& P = e->P;
+    int n = e->n, nd = e->nd;
+    Real dt = (Real)P.dt;
+    if (!e->fk_valid) fk(e);
+
+    /* (1) collision detection on the poses at the start of the step */
+    find_contacts(e);
+
+    /* (2) forward dynamics: gravity, joint damping torque -c*qd (PyBullet adds the URDF
+     * joint damping as a joint torque before every step [U]), link damping, gyroscopic */
+    std::vector<Real> tau(n), qdd(n), acc(nd);
+    for (int j = 0; j < n; j++) tau[j] = -(Real)P.joint_damping * e->qd[j];
+    velocities(e, e->omega, e->vel, e->qd.data());
+    aba_factor(e);
+    bias_forces(e, true, true, true, nullptr);
+    aba_solve(e, tau.data(), true, qdd.data());
+    base_acc_world(e, true, acc.data());
+    for (int j = 0; j < n; j++) acc[6 + j] = qdd[j];
+    Real w1[6];
+    joint0_wrench(e, w1);   /* joint feedback, first (non-constraint) pass */
+
+    /* (3) v += a dt  (applyDeltaVeeMultiDof, clamped) */
+    apply_dv(e, acc.data(), dt);
+
+    /* (4) constraint rows */
+    std::vector<Real> g(nd);
+    for (int r = 0; r < 3; r++) { g[r] = e->omega[r]; g[3 + r] = e->vel[r]; }
+    for (int j = 0; j < n; j++) g[6 + j] = e->qd[j];
+
+    std::vector<Row> noncontact, normals, frictions;
+    auto finish_row = [&](Row& row, Real vel_target_minus_relvel_plus_pos) {
+        Real d = 0;
+        for (int i = 0; i < nd; i++) d += row.J[i] * row.M[i];
+        row.dinv = d > std::numeric_limits<Real>::epsilon() ? Real(1) / d : 0;
+        row.rhs = vel_target_minus_relvel_plus_pos * row.dinv;
+        row.applied = 0;
+    };
+    /* joint limit rows, only when violated (btMultiBodyJointLimitConstraint [U]) */
+    for (int j = 0; j < n; j++) {
+        for (int side = 0; side < 2; side++) {
+            Real pen = side == 0 ? e->q[j] - (Real)P.joint_lo : (Real)P.joint_hi - e->q[j];
+            if (pen > 0) continue;
+            Real dirn = side == 0 ? 1 : -1;
+            Row row;
+            row.kind = 0; row.joint = j; row.contact = -1;
+            row.J.assign(nd, 0); row.M.assign(nd, 0);
+            row.J[6 + j] = dirn;
+            std::vector<Real> x(nd, 0);
+            x[6 + j] = dirn;
+            minv_apply(e, -1, nullptr, nullptr, x.data(), row.M.data());
+            Real rel_vel = dirn * g[6 + j];
+            finish_row(row, -rel_vel + (-pen) * (Real)P.limit_erp / dt);
+            row.lo = 0; row.hi = (Real)P.limit_max_impulse;
+            noncontact.push_back(row);
+        }
+    }
+    /* motor rows (btMultiBodyJointMotor, PyBullet POSITION_CONTROL defaults [U]) */
+    for (int j = 0; j < n; j++) {
+        Row row;
+        row.kind = 1; row.joint = j; row.contact = -1;
+        row.J.assign(nd, 0); row.M.assign(nd, 0);
+        row.J[6 + j] = 1;
+        std::vector<Real> x(nd, 0);
+        x[6 + j] = 1;
+        minv_apply(e, -1, nullptr, nullptr, x.data(), row.M.data());
+        Real cur = g[6 + j];
+        Real want = (Real)P.kp * (targets[j] - e->q[j]) / dt + cur + (Real)P.kd * (0 - cur);
+        finish_row(row, want - cur);
+        Real mi = (Real)P.max_motor_impulse;
+        row.lo = -mi; row.hi = mi;
+        noncontact.push_back(row);
+    }
+    /* contact rows (btMultiBodyConstraintSolver::setupMultiBodyContactConstraint [U]) */
+    int nc = (int)e->contacts.size();
+    Real mu = (Real)(P.mu_link * e->mu_plane);
+    if (mu > 10) mu = 10;   /* MAX_FRICTION */
+    for (int ci = 0; ci < nc; ci++) {
+        const Contact& c = e->contacts[ci];
+        Real nrm[3] = {0, 0, 1};
+        Row row;
+        row.kind = 2; row.joint = -1; row.contact = ci;
+        row.J.assign(nd, 0); row.M.assign(nd, 0);
+        memcpy(row.dir, nrm, sizeof(nrm));
+        jac_row(e, c.link, c.P, nrm, row.J.data());
+        minv_apply(e, c.link, c.P, nrm, nullptr, row.M.data());
+        Real rel_vel = 0;
+        for (int i = 0; i < nd; i++) rel_vel += row.J[i] * g[i];
+        Real pen = c.dist + (Real)P.linear_slop;
+        Real velerr = -rel_vel, poserr = 0;   /* restitution 0 */
+        if (pen > 0) velerr -= pen / dt;
+        else poserr = -pen * (Real)P.contact_erp / dt;
+        finish_row(row, velerr + poserr);
+        row.lo = 0; row.hi = Real(1e10);
+        normals.push_back(row);
+        /* two friction directions from btPlaneSpace1(n=(0,0,1)) = (0,-1,0), (1,0,0),
+         * each scaled by the link's anisotropic friction in link axes:
+         * d' = R diag(aniso) R^T d  (applyAnisotropicFriction [U]) */
+        const Real fd[2][3] = {{0, -1, 0}, {1, 0, 0}};
+        for (int f = 0; f < 2; f++) {
+            Real loc[3], dsc[3];
+            mat3T_vec(&e->Rw[9 * c.link], fd[f], loc);
+            for (int r = 0; r < 3; r++) loc[r] *= (Real)P.aniso[r];
+            mat3_vec(&e->Rw[9 * c.link], loc, dsc);
+            Row fr;
+            fr.kind = 3; fr.joint = -1; fr.contact = ci;
+            fr.J.assign(nd, 0); fr.M.assign(nd, 0);
+            memcpy(fr.dir, dsc, sizeof(dsc));
+            jac_row(e, c.link, c.P, dsc, fr.J.data());
+            minv_apply(e, c.link, c.P, dsc, nullptr, fr.M.data());
+            Real rv = 0;
+            for (int i = 0; i < nd; i++) rv += fr.J[i] * g[i];
+            finish_row(fr, -rv);
+            fr.lo = 0; fr.hi = 0;   /* set from the normal impulse every iteration */
+            frictions.push_back(fr);
+        }
+    }
+
+    /* (5) projected Gauss-Seidel (btMultiBodyConstraintSolver::solveSingleIteration [U]) */
+    std::vector<Real> dv(nd, 0);
+    int iters = 0;
+    for (int it = 0; it < P.n_iterations; it++) {
+        Real lsq = 0;
+        int nn = (int)noncontact.size();
+        for (int j = 0; j < nn; j++) {
+            int idx = (it & 1) ? j : nn - 1 - j;
+            Real r = resolve_row(noncontact[idx], dv, nd);
+            if (r * r > lsq) lsq = r * r;
+        }
+        for (int ci = 0; ci < nc; ci++) {
+            Real r = resolve_row(normals[ci], dv, nd);
+            if (r * r > lsq) lsq = r * r;
+        }
+        for (int ci = 0; ci < nc; ci++) {
+            Real lim = mu * normals[ci].applied;
+            Row& A = frictions[2 * ci];
+            Row& B = frictions[2 * ci + 1];
+            if (P.cone_friction) {
+                /* resolveConeFrictionConstraintRows [U]: both rows from the same velocity,
+                 * accumulated pair projected radially onto the disc of radius mu*lambda_n */
+                Real ua = 0, ub = 0;
+                for (int i = 0; i < nd; i++) { ua += A.J[i] * dv[i]; ub += B.J[i] * dv[i]; }
+                Real dA = A.rhs - ua * A.dinv, dB = B.rhs - ub * B.dinv;
+                Real sA = A.applied + dA, sB = B.applied + dB;
+                Real rr = std::sqrt(sA * sA + sB * sB);
+                if (rr > lim) {
+                    Real sc = rr > 0 ? lim / rr : 0;
+                    sA *= sc; sB *= sc;
+                }
+                dA = sA - A.applied; dB = sB - B.applied;
+                A.applied = sA; B.applied = sB;
+                for (int i = 0; i < nd; i++) dv[i] += A.M[i] * dA + B.M[i] * dB;
+                Real ra = A.dinv != 0 ? dA / A.dinv : 0, rb = B.dinv != 0 ? dB / B.dinv : 0;
+                if (ra * ra > lsq) lsq = ra * ra;
+                if (rb * rb > lsq) lsq = rb * rb;
+            } else {
+                if (lim > 0) {
+                    A.lo = -lim; A.hi = lim; B.lo = -lim; B.hi = lim;
+                    Real r = resolve_row(A, dv, nd);
+                    if (r * r > lsq) lsq = r * r;
+                    r = resolve_row(B, dv, nd);
+                    if (r * r > lsq) lsq = r * r;
+                }
+            }
+        }
+        iters = it + 1;
+        if (lsq <= (Real)P.residual_threshold || it >= P.n_iterations - 1) break;
+    }
+    e->last_iters = iters;
+
+    /* (6) constraint pass for the joint-feedback sensors [U]: ABA again at the velocities
+     * after (3), with the constraint forces as the only link forces (no gravity) and the
+     * joint torques still applied; its joint-0 wrench ADDS to the first pass */
+    std::vector<ExtForce> ext;
+    std::vector<Real> tau2(tau);
+    for (size_t k2 = 0; k2 < noncontact.size(); k2++) {
+        const Row& r = noncontact[k2];
+        tau2[r.joint] += r.J[6 + r.joint] * r.applied / dt;
+    }
+    e->last_normal_impulse.assign(nc, 0);
+    for (int ci = 0; ci < nc; ci++) {
+        const Contact& c = e->contacts[ci];
+        ExtForce f;
+        f.link = c.link;
+        for (int r = 0; r < 3; r++) {
+            f.P[r] = c.P[r];
+            f.F[r] = (normals[ci].dir[r] * normals[ci].applied + frictions[2 * ci].dir[r] * frictions[2 * ci].applied +
+                      frictions[2 * ci + 1].dir[r] * frictions[2 * ci + 1].applied) / dt;
+        }
+        ext.push_back(f);
+        e->last_normal_impulse[ci] = normals[ci].applied;
+    }
+    velocities(e, e->omega, e->vel, e->qd.data());
+    bias_forces(e, true, true, false, &ext);
+    std::vector<Real> qdd2(n);
+    aba_solve(e, tau2.data(), true, qdd2.data());
+    Real w2[6];
+    joint0_wrench(e, w2);
+    e->fz = w1[5] + w2[5];   /* linear z in the `base` link frame = getJointState(0)[2][2] */
+
+    /* (7) apply solver delta-v (processDeltaVeeMultiDof2), motor torques, integrate */
+    apply_dv(e, dv.data(), 1);
+    for (size_t k2 = 0; k2 < noncontact.size(); k2++)
+        if (noncontact[k2].kind == 1) e->tau_motor[noncontact[k2].joint] = noncontact[k2].applied / dt;
+    integrate_positions(e);
+}
+
+Real mean_height(orc_env* e) {
+    if (!e->fk_valid) fk(e);
+    /* getLinkStates(arange(0, numJoints, 3)): Bullet links 0,3,...,3n = `base` + OUTPUT_BODYs;
+     * [0] of a link state is the world position of its COM */
+    Real s = 0;
+    int cnt = 0;
+    for (int b = 0; b <= 3 * e->n; b += 3) {
+        int i = b + 1;
+        Real w[3];
+        mat3_vec(&e->Rw[9 * i], e->links[i].com, w);
+        s += e->ow[3 * i + 2] + w[2];
+        cnt++;
+    }
+    return s / cnt;
+}
+
+void get_obs(const orc_env* e, double* obs) {
+    int n = e->n;
+    for (int j = 0; j < n; j++) {
+        obs[j] = e->q[j];
+        obs[n + j] = e->qd[j];
+        obs[2 * n + j] = e->tau_motor[j];
+    }
+    for (int r = 0; r < 3; r++) obs[3 * n + r] = e->pos[r];
+    for (int r = 0; r < 4; r++) obs[3 * n + 3 + r] = e->quat[r];
+    obs[3 * n + 7] = e->fz;
+}
+
+void soft_reset(orc_env* e) {
+    /* snake.py:96-99: resetBasePositionAndOrientation([0,0,0],[0,0,0,1]) zeroes the base
+     * twist [U]; resetJointState(i, 0) zeroes q and qd; motor/sensor caches persist [U] */
+    for (int r = 0; r < 3; r++) { e->pos[r] = 0; e->omega[r] = 0; e->vel[r] = 0; }
+    e->quat[0] = e->quat[1] = e->quat[2] = 0; e->quat[3] = 1;
+    for (int j = 0; j < e->n; j++) { e->q[j] = 0; e->qd[j] = 0; }
+    e->fk_valid = 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+void orc_default_params(orc_params* p) {
+    memset(p, 0, sizeof(*p));
+    p->n_modules = 16;
+    p->inertia_from_file = 0;
+    p->default_mass = 1.0;
+    p->collision_margin = 0.001;
+    p->hull_sides = 0;   /* implicit cylinder: see find_contacts and DESIGN.md §3 */
+    p->dt = 1.0 / 240.0;
+    p->gravity_z = -9.8;
+    p->lin_damping = 0.04;
+    p->ang_damping = 0.04;
+    p->joint_damping = 0.1;
+    p->max_coord_vel = 100.0;
+    p->kp = 0.1;
+    p->kd = 1.0;
+    p->max_motor_impulse = std::numeric_limits<double>::infinity();
+    p->joint_lo = -1.57;
+    p->joint_hi = 1.57;
+    p->limit_erp = 0.2;
+    p->limit_max_impulse = 100.0;
+    p->mu_link = 2.0;
+    p->aniso[0] = 1.0; p->aniso[1] = 0.1; p->aniso[2] = 0.01;
+    p->contact_erp = 0.08;
+    p->linear_slop = 1e-5;
+    p->breaking_threshold = 0.02;
+    p->cone_friction = 1;
+    p->n_iterations = 50;
+    p->residual_threshold = 1e-7;
+    p->scaling_factor = kPi / 6.0;
+    p->gait = 1;
+    p->servo_tol = 0.05;
+    p->max_counter = 40;
+    p->height_threshold = 0.1;
+    p->energy_dt = 1.0 / 100.0;
+    p->alpha = 1.0; p->beta = 0.01; p->gamma = 0.1;
+    p->term_angle = 0.5;
+    p->term_index = 9;
+    p->collision_force = 10.0;
+    p->collision_penalty = -10.0;
+    p->done_penalty = -5.0;
+}
+
+orc_env* orc_create(const orc_params* p) {
+    orc_env* e = new orc_env();
+    e->P = *p;
+    e->mu_plane = 1.0;   /* pybullet_data/plane.urdf lateral_friction [U] */
+    build_model(e);
+    orc_hard_reset(e);
+    return e;
+}
+void orc_destroy(orc_env* e) { delete e; }
+void orc_set_plane_friction(orc_env* e, double mu) { e->mu_plane = mu; }
+
+int32_t orc_num_links(const orc_env* e) { return e->L; }
+int32_t orc_num_dofs(const orc_env* e) { return e->nd; }
+int32_t orc_obs_dim(const orc_env* e) { return 3 * e->n + 8; }
+int32_t orc_state_dim(const orc_env* e) { return 13 + 2 * e->n; }
+
+void orc_get_state(const orc_env* e, double* s) {
+    for (int r = 0; r < 3; r++) s[r] = e->pos[r];
+    for (int r = 0; r < 4; r++) s[3 + r] = e->quat[r];
+    for (int r = 0; r < 3; r++) s[7 + r] = e->omega[r];
+    for (int r = 0; r < 3; r++) s[10 + r] = e->vel[r];
+    for (int j = 0; j < e->n; j++) { s[13 + j] = e->q[j]; s[13 + e->n + j] = e->qd[j]; }
+}
+void orc_set_state(orc_env* e, const double* s) {
+    for (int r = 0; r < 3; r++) e->pos[r] = (Real)s[r];
+    for (int r = 0; r < 4; r++) e->quat[r] = (Real)s[3 + r];
+    for (int r = 0; r < 3; r++) e->omega[r] = (Real)s[7 + r];
+    for (int r = 0; r < 3; r++) e->vel[r] = (Real)s[10 + r];
+    for (int j = 0; j < e->n; j++) { e->q[j] = (Real)s[13 + j]; e->qd[j] = (Real)s[13 + e->n + j]; }
+    e->fk_valid = 0;
+}
+void orc_get_aux(const orc_env* e, double* tau_n, double* fz, double* prev_x) {
+    for (int j = 0; j < e->n; j++) tau_n[j] = e->tau_motor[j];
+    *fz = e->fz;
+    *prev_x = e->prev_x;
+}
+void orc_set_aux(orc_env* e, const double* tau_n, double fz, double prev_x) {
+    for (int j = 0; j < e->n; j++) e->tau_motor[j] = (Real)tau_n[j];
+    e->fz = (Real)fz;
+    e->prev_x = (Real)prev_x;
+}
+
+void orc_hard_reset(orc_env* e) {
+    soft_reset(e);
+    for (int j = 0; j < e->n; j++) e->tau_motor[j] = 0;
+    e->fz = 0;
+    e->prev_x = 0;
+    e->last_iters = 0;
+    e->contacts.clear();
+    e->last_normal_impulse.clear();
+}
+
+void orc_reset(orc_env* e, double* obs) {
+    soft_reset(e);
+    std::vector<double> o(3 * e->n + 8);
+    get_obs(e, o.data());
+    e->prev_x = (Real)o[3 * e->n];   /* self._observation = getObservation() (SnakeGymEnv.py:30) */
+    if (obs) memcpy(obs, o.data(), sizeof(double) * o.size());
+}
+void orc_get_obs(const orc_env* e, double* obs) { get_obs(e, obs); }
+double orc_mean_height(orc_env* e) { return (double)mean_height(e); }
+
+void orc_substep(orc_env* e, const double* targets_n) {
+    std::vector<Real> t(e->n);
+    for (int j = 0; j < e->n; j++) t[j] = (Real)targets_n[j];
+    substep(e, t.data());
+}
+int32_t orc_last_iterations(const orc_env* e) { return e->last_iters; }
+int32_t orc_last_num_contacts(const orc_env* e) { return (int32_t)e->contacts.size(); }
+
+void orc_env_step(orc_env* e, double* action, int32_t vec_mode, double* obs, double* reward,
+                  int32_t* done, int32_t* substeps) {
+    const orc_params& P = e->P;
+    int n = e->n;
+    int A = (P.gait == 0 || P.gait == 1) ? n / 2 : n;
+    /* checkBound (SnakeGymEnv.py:82-88): clip in place */
+    for (int k = 0; k < A; k++) {
+        if (action[k] < -1) action[k] = -1;
+        if (action[k] > 1) action[k] = 1;
+    }
+    /* createAction (snake.py:247-269) */
+    std::vector<Real> a16(n, 0), targets(n);
+    if (P.gait == 0) { for (int i = 0, c = 0; i < n; i += 2) a16[i] = (Real)action[c++]; }
+    else if (P.gait == 1) { for (int i = 1, c = 0; i < n; i += 2) a16[i] = (Real)action[c++]; }
+    else { for (int i = 0; i < n; i++) a16[i] = (Real)action[i]; }
+    for (int i = 0; i < n; i++) targets[i] = a16[i] * (Real)P.scaling_factor;
+    /* Snake.step servo loop (snake.py:283-304) */
+    int counter = 0;
+    bool end_height = false;
+    auto feedback = [&]() {
+        Real s = 0;
+        for (int i = 0; i < n; i++) { Real d = targets[i] - e->q[i]; s += d * d; }
+        return std::sqrt(s) > (Real)P.servo_tol;
+    };
+    while (feedback()) {
+        substep(e, targets.data());
+        counter++;
+        if (mean_height(e) > (Real)P.height_threshold) { end_height = true; break; }
+        if (counter > P.max_counter) break;
+    }
+    /* SnakeGymEnv.step (SnakeGymEnv.py:36-42) */
+    std::vector<double> o(3 * n + 8);
+    get_obs(e, o.data());
+    double energy = 0;
+    for (int i = 0; i < n; i++) energy += o[n + i] * o[2 * n + i] * P.energy_dt;   /* snake.py:336-341 */
+    double r_x = o[3 * n] - (double)e->prev_x;
+    double r_y = fabs(o[3 * n + 1] - 0.0);
+    double r_col = fabs(o[3 * n + 7]) > P.collision_force ? P.collision_penalty : 0.0;
+    double rew = P.alpha * r_x + r_col - P.beta * r_y - P.gamma * energy;
+    bool dn = fabs(o[P.term_index]) > P.term_angle;
+    if (!dn) dn = mean_height(e) > (Real)P.height_threshold;
+    if (!dn) dn = end_height;
+    if (dn) {
+        rew += P.done_penalty;
+        soft_reset(e);                       /* self.reset() at SnakeGymEnv.py:41 sets           */
+    }                                        /* _observation to the reset obs, and :42 then      */
+    e->prev_x = (Real)o[3 * n];              /* overwrites it with the (terminal) obs            */
+    if (dn && vec_mode) {
+        /* SubprocVecEnv worker (multiprocessing_env.py:13-15): ob = env.reset() */
+        soft_reset(e);
+        get_obs(e, o.data());
+        e->prev_x = (Real)o[3 * n];
+    }
+    memcpy(obs, o.data(), sizeof(double) * o.size());
+    *reward = rew;
+    *done = dn ? 1 : 0;
+    *substeps = counter;
+}
+
+void orc_link_com_world(orc_env* e, double* out) {
+    if (!e->fk_valid) fk(e);
+    for (int i = 0; i < e->L; i++) {
+        Real w[3];
+        mat3_vec(&e->Rw[9 * i], e->links[i].com, w);
+        for (int r = 0; r < 3; r++) out[3 * i + r] = e->ow[3 * i + r] + w[r];
+    }
+}
+void orc_joint_axes_world(orc_env* e, double* axis, double* origin) {
+    if (!e->fk_valid) fk(e);
+    for (int j = 0; j < e->n; j++) {
+        int i = e->dof_link[j];
+        Real aw[3];
+        mat3_vec(&e->Rw[9 * i], e->links[i].axis, aw);
+        for (int r = 0; r < 3; r++) { axis[3 * j + r] = aw[r]; origin[3 * j + r] = e->ow[3 * i + r]; }
+    }
+}
+void orc_link_inertials(const orc_env* e, double* out) {
+    for (int i = 0; i < e->L; i++) {
+        const Link& k = e->links[i];
+        out[7 * i] = k.mass;
+        for (int r = 0; r < 3; r++) { out[7 * i + 1 + r] = k.com[r]; out[7 * i + 4 + r] = k.Icom[r]; }
+    }
+}
+void orc_link_parents(const orc_env* e, int32_t* out) {
+    for (int i = 0; i < e->L; i++) out[i] = e->links[i].parent;
+}
+void orc_forward_dynamics(orc_env* e, const double* tau_n, int32_t with_gravity, int32_t with_damping,
+                          double* acc) {
+    int n = e->n;
+    if (!e->fk_valid) fk(e);
+    std::vector<Real> tau(n), qdd(n);
+    for (int j = 0; j < n; j++) tau[j] = (Real)tau_n[j];
+    velocities(e, e->omega, e->vel, e->qd.data());
+    aba_factor(e);
+    bias_forces(e, true, with_damping != 0, with_gravity != 0, nullptr);
+    aba_solve(e, tau.data(), true, qdd.data());
+    Real a6[6];
+    base_acc_world(e, true, a6);
+    for (int r = 0; r < 6; r++) acc[r] = a6[r];
+    for (int j = 0; j < n; j++) acc[6 + j] = qdd[j];
+}
+void orc_minv_mul(orc_env* e, const double* x, double* y) {
+    if (!e->fk_valid) fk(e);
+    aba_factor(e);
+    std::vector<Real> xr(e->nd), yr(e->nd);
+    for (int i = 0; i < e->nd; i++) xr[i] = (Real)x[i];
+    minv_apply(e, -1, nullptr, nullptr, xr.data(), yr.data());
+    for (int i = 0; i < e->nd; i++) y[i] = yr[i];
+}
+void orc_momentum(orc_env* e, double* lin3, double* ang3, double* kinetic) {
+    if (!e->fk_valid) fk(e);
+    velocities(e, e->omega, e->vel, e->qd.data());
+    double Lm[3] = {0, 0, 0}, Am[3] = {0, 0, 0}, K = 0;
+    for (int i = 0; i < e->L; i++) {
+        const Link& k = e->links[i];
+        const Real* v = &e->v[6 * i];
+        Real vc[3], t[3], wl[3] = {v[0], v[1], v[2]};
+        cross3(wl, k.com, t);
+        for (int r = 0; r < 3; r++) vc[r] = v[3 + r] + t[r];
+        Real vw[3], ww[3], cw[3], Iw[3], hl[3];
+        mat3_vec(&e->Rw[9 * i], vc, vw);
+        mat3_vec(&e->Rw[9 * i], wl, ww);
+        mat3_vec(&e->Rw[9 * i], k.com, cw);
+        for (int r = 0; r < 3; r++) { cw[r] += e->ow[3 * i + r]; hl[r] = k.Icom[r] * wl[r]; }
+        mat3_vec(&e->Rw[9 * i], hl, Iw);
+        Real cxp[3], pw[3] = {k.mass * vw[0], k.mass * vw[1], k.mass * vw[2]};
+        cross3(cw, pw, cxp);
+        for (int r = 0; r < 3; r++) { Lm[r] += pw[r]; Am[r] += Iw[r] + cxp[r]; }
+        K += 0.5 * k.mass * dot3(vw, vw) + 0.5 * dot3(wl, hl);
+    }
+    for (int r = 0; r < 3; r++) { lin3[r] = Lm[r]; ang3[r] = Am[r]; }
+    *kinetic = K;
+}
+int32_t orc_contacts(orc_env* e, double* out, int32_t maxc) {
+    if (!e->fk_valid) fk(e);
+    find_contacts(e);
+    int nc = (int)e->contacts.size();
+    for (int i = 0; i < nc && i < maxc; i++) {
+        for (int r = 0; r < 3; r++) out[5 * i + r] = e->contacts[i].P[r];
+        out[5 * i + 3] = e->contacts[i].dist;
+        out[5 * i + 4] = e->contacts[i].link;
+    }
+    return nc;
+}
+int32_t orc_last_normal_impulses(const orc_env* e, double* out, int32_t maxc) {
+    int nc = (int)e->last_normal_impulse.size();
+    for (int i = 0; i < nc && i < maxc; i++) out[i] = e->last_normal_impulse[i];
+    return nc;
+}
+
+}  // extern "C"

@@ -1,0 +1,141 @@
+/*
+ * snake_oracle.h -- C API of the CPU ORACLE for the SnakeGymEnv step/reset path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.
+ *
+ * PARITY UNPINNED: the arithmetic of the reference path lives in the third-party
+ * `pybullet` wheel (bullet3, version not pinned by the reference; absent from this
+ * image and from /root/reference).  This oracle restates Bullet's published
+ * btMultiBody pipeline from knowledge of the public bullet3 sources; every such
+ * rule is tagged [U] in snake_oracle.cpp and is a field of orc_params.  The
+ * reference holds no golden vectors for this path.
+ *
+ * Reference call sites restated (paths under /root/reference):
+ *   snake.py:86-101   Snake.reset            -> orc_reset / orc_hard_reset
+ *   snake.py:209-217  Snake.getObservation   -> orc_get_obs
+ *   snake.py:219-225  applyActions           -> motor targets in orc_substep
+ *   snake.py:228-235  checkFeedback          -> inside orc_env_step
+ *   snake.py:237-245  checkSnakeHeight       -> orc_mean_height
+ *   snake.py:247-269  createAction           -> inside orc_env_step
+ *   snake.py:274-306  Snake.step             -> inside orc_env_step
+ *   snake.py:286      pybullet.stepSimulation-> orc_substep
+ *   snake.py:336-341  calculateEnergy        -> inside orc_env_step
+ *   SnakeGymEnv.py:33-50,82-103 step / reward / termination -> orc_env_step
+ *   ppo/multiprocessing_env.py:11-16 worker auto-reset       -> orc_env_step(vec_mode=1)
+ */
+#ifndef SNAKE_ORACLE_H
+#define SNAKE_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct orc_params {
+    /* model (snake/snake.urdf constants) */
+    int32_t n_modules;        /* 16 (reference) or 32 (BASELINE config 4)                */
+    int32_t inertia_from_file;/* 0: Bullet default, inertia from collision AABB [U]      */
+    double  default_mass;     /* mass given to links without <inertial> [U] = 1          */
+    double  collision_margin; /* gUrdfDefaultCollisionMargin [U] = 0.001                 */
+    int32_t hull_sides;       /* 0 = implicit cylinder (default here); 32 = PyBullet's
+                               * default 32-gon hull import [U] (rocks with a 2-point manifold) */
+    /* world / integrator */
+    double  dt;               /* PyBullet default fixedTimeStep 1/240 [U] (F2)           */
+    double  gravity_z;        /* snake.py:8  -9.8                                        */
+    double  lin_damping;      /* btMultiBody m_linearDamping  0.04 [U]                   */
+    double  ang_damping;      /* btMultiBody m_angularDamping 0.04 [U]                   */
+    double  joint_damping;    /* snake.urdf:838 damping=.1                               */
+    double  max_coord_vel;    /* btMultiBody m_maxCoordinateVelocity 100 [U]             */
+    /* motors (snake.py:219-221, PyBullet defaults [U]) */
+    double  kp;               /* positionGain default 0.1                                */
+    double  kd;               /* velocityGain default 1.0                                */
+    double  max_motor_impulse;/* forces=[inf] -> inf                                     */
+    double  joint_lo, joint_hi;/* snake.urdf:839 +-1.57                                  */
+    double  limit_erp;        /* btContactSolverInfo m_erp 0.2 [U]                       */
+    double  limit_max_impulse;/* btMultiBodyConstraint m_maxAppliedImpulse 100 [U]       */
+    /* contact */
+    double  mu_link;          /* snake.py:104-106 lateralFriction=2                      */
+    double  aniso[3];         /* snake.py:25 [1, 0.1, 0.01]                              */
+    double  contact_erp;      /* solver m_erp2 [U] (PyBullet sets 0.08? default 0.2)     */
+    double  linear_slop;      /* PyBullet m_linearSlop 1e-5 [U]                          */
+    double  breaking_threshold;/* gContactBreakingThreshold 0.02 [U]                     */
+    int32_t cone_friction;    /* 1: implicit cone on the 2 friction rows [U]; 0: pyramid */
+    /* solver */
+    int32_t n_iterations;     /* numSolverIterations 50 [U]                              */
+    double  residual_threshold;/* m_leastSquaresResidualThreshold 1e-7 [U]; 0 = never exit */
+    /* task (snake.py / SnakeGymEnv.py) */
+    double  scaling_factor;   /* snake.py:63  pi/6                                       */
+    int32_t gait;             /* snake.py:62  1 -> odd slots                             */
+    double  servo_tol;        /* snake.py:232 0.05                                       */
+    int32_t max_counter;      /* snake.py:303 40                                         */
+    double  height_threshold; /* snake.py:238 0.1                                        */
+    double  energy_dt;        /* snake.py:9   1/100                                      */
+    double  alpha, beta, gamma;/* SnakeGymEnv.py:14-16  1, 0.01, 0.1                     */
+    double  term_angle;       /* SnakeGymEnv.py:100 0.5 on obs[9]                        */
+    int32_t term_index;       /* 9                                                       */
+    double  collision_force;  /* SnakeGymEnv.py:94  10                                   */
+    double  collision_penalty;/* -10                                                     */
+    double  done_penalty;     /* SnakeGymEnv.py:40  -5                                   */
+} orc_params;
+
+typedef struct orc_env orc_env;
+
+void     orc_default_params(orc_params* p);
+orc_env* orc_create(const orc_params* p);
+void     orc_destroy(orc_env* e);
+void     orc_set_plane_friction(orc_env* e, double mu);          /* BASELINE config 5 */
+
+int32_t  orc_num_links(const orc_env* e);    /* 3*n+2 (root + Bullet links 0..3n)       */
+int32_t  orc_num_dofs(const orc_env* e);     /* 6 + n                                    */
+int32_t  orc_obs_dim(const orc_env* e);      /* 3n + 8                                   */
+int32_t  orc_state_dim(const orc_env* e);    /* 13 + 2n                                  */
+
+/* state = [pos3, quat xyzw 4, omega_world 3, vel_world 3, q n, qd n] */
+void     orc_get_state(const orc_env* e, double* s);
+void     orc_set_state(orc_env* e, const double* s);
+/* carried observables: motor torques [n], joint-0 reaction Fz, prev obs x */
+void     orc_get_aux(const orc_env* e, double* tau_n, double* fz, double* prev_x);
+void     orc_set_aux(orc_env* e, const double* tau_n, double fz, double prev_x);
+
+void     orc_hard_reset(orc_env* e);                  /* snake.py:88-95  */
+void     orc_reset(orc_env* e, double* obs);          /* SnakeGymEnv.py:28-31 (soft) */
+void     orc_get_obs(const orc_env* e, double* obs);  /* snake.py:209-217 */
+double   orc_mean_height(orc_env* e);                 /* snake.py:237-245 (value) */
+
+/* one physics substep (pybullet.stepSimulation with POSITION_CONTROL targets) */
+void     orc_substep(orc_env* e, const double* targets_n);
+int32_t  orc_last_iterations(const orc_env* e);
+int32_t  orc_last_num_contacts(const orc_env* e);
+
+/* SnakeGymEnv.step.  vec_mode=1 adds the SubprocVecEnv worker's reset-on-done
+ * (returned obs is the post-reset one).  action[A] is clipped in place.        */
+void     orc_env_step(orc_env* e, double* action, int32_t vec_mode,
+                      double* obs, double* reward, int32_t* done, int32_t* substeps);
+
+/* --- introspection for tests --- */
+/* per link: world COM position (3) */
+void     orc_link_com_world(orc_env* e, double* out_L3);
+/* per revolute joint: world axis (3) and origin (3) */
+void     orc_joint_axes_world(orc_env* e, double* axis_n3, double* origin_n3);
+/* per link: mass, com(3, link frame), inertia diag(3) */
+void     orc_link_inertials(const orc_env* e, double* out_L7);
+void     orc_link_parents(const orc_env* e, int32_t* out_L);
+/* forward dynamics only: generalized acceleration [6+n] = [omega_dot_w, vdot_w, qdd]
+ * for joint torques tau[n] (gravity+damping per flags), no constraints          */
+void     orc_forward_dynamics(orc_env* e, const double* tau_n, int32_t with_gravity,
+                              int32_t with_damping, double* acc);
+/* y = M^-1 x for x in generalized force space [6+n] (ABA delta pass)            */
+void     orc_minv_mul(orc_env* e, const double* x, double* y);
+/* total linear momentum (3), angular momentum about world origin (3), kinetic energy */
+void     orc_momentum(orc_env* e, double* lin3, double* ang3, double* kinetic);
+/* contacts of the current pose: returns count; per contact [px,py,pz, dist, link] */
+int32_t  orc_contacts(orc_env* e, double* out, int32_t max_contacts);
+/* impulses of the last substep: normal impulses per contact */
+int32_t  orc_last_normal_impulses(const orc_env* e, double* out, int32_t max_contacts);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

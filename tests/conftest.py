@@ -1,0 +1,46 @@
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle_mod():
+    import oracle as orc
+    orc.build()
+    return orc
+
+
+@pytest.fixture(scope="session")
+def pkg():
+    """The product package (directory name has a hyphen, so import through importlib)."""
+    return importlib.import_module("bullet-envs_amd")
+
+
+def random_state(rng, n, z=0.2, qamp=0.5, vamp=1.0, flat=False):
+    """A reachable random state [pos3, quat4, omega3, vel3, q n, qd n]."""
+    s = np.zeros(13 + 2 * n)
+    s[0:3] = rng.uniform(-0.1, 0.1, 3)
+    s[2] = z
+    if flat:
+        yaw = rng.uniform(-np.pi, np.pi)
+        s[3:7] = [0, 0, np.sin(yaw / 2), np.cos(yaw / 2)]
+    else:
+        qv = rng.normal(size=4)
+        s[3:7] = qv / np.linalg.norm(qv)
+    s[7:10] = rng.uniform(-vamp, vamp, 3)
+    s[10:13] = rng.uniform(-vamp, vamp, 3)
+    s[13:13 + n] = rng.uniform(-qamp, qamp, n)
+    s[13 + n:] = rng.uniform(-vamp, vamp, n)
+    return s
