@@ -1,0 +1,429 @@
+// snk_api.hip -- C ABI (include/snk.h) over the HIP kernels of snk_device.hpp.
+// Build: hipcc --offload-arch=gfx950 -O3 -shared -fPIC snk_api.hip -o libsnk.so
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "../../include/snk.h"
+#include "snk_device.hpp"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(const std::string& msg) {
+    g_err = msg;
+    return 1;
+}
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e__ = (expr);                                                               \
+        if (e__ != hipSuccess)                                                                 \
+            return fail(std::string(#expr) + ": " + hipGetErrorString(e__));                   \
+    } while (0)
+
+}  // namespace
+
+struct snk_handle {
+    snk_params P;
+    snk::HostModel H;
+    snk::DevModel D;
+    int n_envs, device, n, rec;
+    snk::DevModel* d_model = nullptr;
+    float* d_recs = nullptr;
+    float* d_mu = nullptr;
+    // scratch for the host-buffer forms
+    float* d_act = nullptr;
+    float* d_obs = nullptr;
+    float* d_rew = nullptr;
+    uint8_t* d_done = nullptr;
+    int32_t* d_sub = nullptr;
+    uint8_t* d_mask = nullptr;
+    float* d_tgt = nullptr;
+    int32_t* d_info = nullptr;
+    float* d_h = nullptr;
+    size_t lds_bytes = 0;
+    // timing
+    bool timing = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double t_sum_ms = 0;
+    int t_count = 0;
+    bool ev_pending = false;
+};
+
+namespace {
+
+template <int N>
+int launch_step(snk_handle* h, float* act, float* obs, float* rew, uint8_t* done, int32_t* sub, int vec_mode,
+                hipStream_t st) {
+    hipLaunchKernelGGL((snk::env_step_kernel<N>), dim3(h->n_envs), dim3(64), h->lds_bytes, st, h->d_model, h->d_recs,
+                       h->d_mu, act, obs, rew, done, sub, vec_mode, h->n_envs);
+    return 0;
+}
+template <int N>
+int launch_substep(snk_handle* h, const float* tgt, int k, int32_t* info, hipStream_t st) {
+    hipLaunchKernelGGL((snk::substep_kernel<N>), dim3(h->n_envs), dim3(64), h->lds_bytes, st, h->d_model, h->d_recs,
+                       h->d_mu, tgt, k, info, h->n_envs);
+    return 0;
+}
+template <int N>
+int launch_reset(snk_handle* h, const uint8_t* mask, float* obs, int hard, hipStream_t st) {
+    hipLaunchKernelGGL((snk::reset_kernel<N>), dim3(h->n_envs), dim3(64), h->lds_bytes, st, h->d_recs, mask, obs, hard,
+                       h->n_envs);
+    return 0;
+}
+template <int N>
+int launch_obs(snk_handle* h, float* obs, float* height, hipStream_t st) {
+    hipLaunchKernelGGL((snk::obs_kernel<N>), dim3(h->n_envs), dim3(64), h->lds_bytes, st, h->d_model, h->d_recs, obs,
+                       height, h->n_envs);
+    return 0;
+}
+template <int N>
+int set_lds_attr(size_t bytes) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&snk::env_step_kernel<N>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&snk::substep_kernel<N>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&snk::reset_kernel<N>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&snk::obs_kernel<N>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return 0;
+}
+
+// Kernels are instantiated for the chain lengths the BASELINE configs use.
+#define SNK_DISPATCH(h, CALL16, CALL32)                                       \
+    ((h)->n == 16 ? (CALL16) : ((h)->n == 32 ? (CALL32) : fail("unsupported n_modules (16 or 32)")))
+
+int check_launch() {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(std::string("kernel launch: ") + hipGetErrorString(e));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* snk_last_error(void) { return g_err.c_str(); }
+
+void snk_default_params(snk_params* p) {
+    memset(p, 0, sizeof(*p));
+    p->n_modules = 16;
+    p->inertia_from_file = 0;
+    p->default_mass = 1.0;
+    p->collision_margin = 0.001;
+    p->dt = 1.0 / 240.0;
+    p->gravity_z = -9.8;
+    p->lin_damping = 0.04;
+    p->ang_damping = 0.04;
+    p->joint_damping = 0.1;
+    p->max_coord_vel = 100.0;
+    p->kp = 0.1;
+    p->kd = 1.0;
+    p->max_motor_impulse = std::numeric_limits<double>::infinity();
+    p->joint_lo = -1.57;
+    p->joint_hi = 1.57;
+    p->limit_erp = 0.2;
+    p->limit_max_impulse = 100.0;
+    p->mu_link = 2.0;
+    p->aniso[0] = 1.0; p->aniso[1] = 0.1; p->aniso[2] = 0.01;
+    p->contact_erp = 0.08;
+    p->linear_slop = 1e-5;
+    p->breaking_threshold = 0.02;
+    p->cone_friction = 1;
+    p->n_iterations = 50;
+    p->residual_threshold = 1e-7;
+    p->scaling_factor = 3.14159265358979323846 / 6.0;
+    p->gait = 1;
+    p->servo_tol = 0.05;
+    p->max_counter = 40;
+    p->height_threshold = 0.1;
+    p->energy_dt = 1.0 / 100.0;
+    p->alpha = 1.0; p->beta = 0.01; p->gamma = 0.1;
+    p->term_angle = 0.5;
+    p->term_index = 9;
+    p->collision_force = 10.0;
+    p->collision_penalty = -10.0;
+    p->done_penalty = -5.0;
+}
+
+int snk_create(const snk_params* p, int32_t n_envs, int32_t device, snk_handle** out) {
+    if (!p || !out) return fail("snk_create: null argument");
+    if (n_envs <= 0) return fail("snk_create: n_envs must be positive");
+    if (p->n_modules != 16 && p->n_modules != 32) return fail("snk_create: n_modules must be 16 or 32");
+    if (p->term_index < 0 || p->term_index >= 3 * p->n_modules + 8) return fail("snk_create: term_index out of range");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail("snk_create: no such HIP device");
+    HIP_TRY(hipSetDevice(device));
+    snk_handle* h = new snk_handle();
+    h->P = *p;
+    h->n_envs = n_envs;
+    h->device = device;
+    h->n = p->n_modules;
+    snk::build_host_model(*p, h->H);
+    snk::build_dev_model(*p, h->H, h->D);
+    h->rec = h->D.rec_floats;
+    h->lds_bytes = h->n == 16 ? sizeof(snk::Lds<16>) : sizeof(snk::Lds<32>);
+    int rc = h->n == 16 ? set_lds_attr<16>(h->lds_bytes) : set_lds_attr<32>(h->lds_bytes);
+    if (rc) { delete h; return rc; }
+    const size_t ne = (size_t)n_envs;
+    HIP_TRY(hipMalloc(&h->d_model, sizeof(snk::DevModel)));
+    HIP_TRY(hipMemcpy(h->d_model, &h->D, sizeof(snk::DevModel), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc(&h->d_recs, ne * h->rec * sizeof(float)));
+    HIP_TRY(hipMemset(h->d_recs, 0, ne * h->rec * sizeof(float)));
+    HIP_TRY(hipMalloc(&h->d_mu, ne * sizeof(float)));
+    std::vector<float> ones(ne, 1.0f);   // plane.urdf lateral_friction = 1 [U]
+    HIP_TRY(hipMemcpy(h->d_mu, ones.data(), ne * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc(&h->d_act, ne * h->D.act_dim * sizeof(float)));
+    HIP_TRY(hipMalloc(&h->d_obs, ne * h->D.obs_dim * sizeof(float)));
+    HIP_TRY(hipMalloc(&h->d_rew, ne * sizeof(float)));
+    HIP_TRY(hipMalloc(&h->d_done, ne));
+    HIP_TRY(hipMalloc(&h->d_sub, ne * sizeof(int32_t)));
+    HIP_TRY(hipMalloc(&h->d_mask, ne));
+    HIP_TRY(hipMalloc(&h->d_tgt, ne * h->n * sizeof(float)));
+    HIP_TRY(hipMalloc(&h->d_info, ne * 2 * sizeof(int32_t)));
+    HIP_TRY(hipMalloc(&h->d_h, ne * sizeof(float)));
+    HIP_TRY(hipEventCreate(&h->ev0));
+    HIP_TRY(hipEventCreate(&h->ev1));
+    // hard reset (snake.py:88-95)
+    SNK_DISPATCH(h, launch_reset<16>(h, nullptr, nullptr, 1, nullptr), launch_reset<32>(h, nullptr, nullptr, 1, nullptr));
+    if (check_launch()) { return 1; }
+    HIP_TRY(hipDeviceSynchronize());
+    *out = h;
+    return 0;
+}
+
+int snk_destroy(snk_handle* h) {
+    if (!h) return 0;
+    (void)hipSetDevice(h->device);
+    (void)hipDeviceSynchronize();
+    void* bufs[] = {h->d_model, h->d_recs, h->d_mu, h->d_act, h->d_obs, h->d_rew, h->d_done,
+                    h->d_sub, h->d_mask, h->d_tgt, h->d_info, h->d_h};
+    for (void* b : bufs) (void)hipFree(b);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    delete h;
+    return 0;
+}
+
+int32_t snk_num_envs(const snk_handle* h) { return h->n_envs; }
+int32_t snk_obs_dim(const snk_handle* h) { return h->D.obs_dim; }
+int32_t snk_act_dim(const snk_handle* h) { return h->D.act_dim; }
+int32_t snk_state_dim(const snk_handle* h) { return h->D.state_dim; }
+int32_t snk_record_floats(const snk_handle* h) { return h->rec; }
+
+int snk_reset(snk_handle* h, const uint8_t* mask_dev, float* obs_dev, void* stream) {
+    if (!h) return fail("snk_reset: null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream;
+    SNK_DISPATCH(h, launch_reset<16>(h, mask_dev, obs_dev, 0, st), launch_reset<32>(h, mask_dev, obs_dev, 0, st));
+    return check_launch();
+}
+
+static void timing_collect(snk_handle* h) {
+    if (h->ev_pending) {
+        float ms = 0.f;
+        if (hipEventSynchronize(h->ev1) == hipSuccess && hipEventElapsedTime(&ms, h->ev0, h->ev1) == hipSuccess) {
+            h->t_sum_ms += ms;
+            h->t_count++;
+        }
+        h->ev_pending = false;
+    }
+}
+
+int snk_step(snk_handle* h, float* actions_dev, float* obs_dev, float* rew_dev, uint8_t* done_dev,
+             int32_t* substeps_dev, int32_t vec_mode, void* stream) {
+    if (!h) return fail("snk_step: null handle");
+    if (!actions_dev || !obs_dev || !rew_dev || !done_dev) return fail("snk_step: null buffer");
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream;
+    if (h->timing) {
+        timing_collect(h);
+        HIP_TRY(hipEventRecord(h->ev0, st));
+    }
+    SNK_DISPATCH(h, launch_step<16>(h, actions_dev, obs_dev, rew_dev, done_dev, substeps_dev, vec_mode, st),
+                 launch_step<32>(h, actions_dev, obs_dev, rew_dev, done_dev, substeps_dev, vec_mode, st));
+    if (h->timing) {
+        HIP_TRY(hipEventRecord(h->ev1, st));
+        h->ev_pending = true;
+    }
+    return check_launch();
+}
+
+int snk_timing_enable(snk_handle* h, int32_t on) {
+    if (!h) return fail("null handle");
+    timing_collect(h);
+    h->timing = on != 0;
+    h->t_sum_ms = 0;
+    h->t_count = 0;
+    return 0;
+}
+int snk_timing_read(snk_handle* h, double* mean_ms, int32_t* count) {
+    if (!h) return fail("null handle");
+    timing_collect(h);
+    if (mean_ms) *mean_ms = h->t_count ? h->t_sum_ms / h->t_count : 0.0;
+    if (count) *count = h->t_count;
+    return 0;
+}
+
+int snk_reset_host(snk_handle* h, const uint8_t* mask, float* obs) {
+    if (!h) return fail("snk_reset_host: null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t ne = (size_t)h->n_envs;
+    if (mask) HIP_TRY(hipMemcpy(h->d_mask, mask, ne, hipMemcpyHostToDevice));
+    if (obs) HIP_TRY(hipMemcpy(h->d_obs, obs, ne * h->D.obs_dim * sizeof(float), hipMemcpyHostToDevice));
+    int rc = snk_reset(h, mask ? h->d_mask : nullptr, obs ? h->d_obs : nullptr, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    if (obs) HIP_TRY(hipMemcpy(obs, h->d_obs, ne * h->D.obs_dim * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int snk_step_host(snk_handle* h, float* actions, float* obs, float* rew, uint8_t* done, int32_t* substeps,
+                  int32_t vec_mode) {
+    if (!h) return fail("snk_step_host: null handle");
+    if (!actions || !obs || !rew || !done) return fail("snk_step_host: null buffer");
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t ne = (size_t)h->n_envs;
+    HIP_TRY(hipMemcpy(h->d_act, actions, ne * h->D.act_dim * sizeof(float), hipMemcpyHostToDevice));
+    int rc = snk_step(h, h->d_act, h->d_obs, h->d_rew, h->d_done, h->d_sub, vec_mode, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(actions, h->d_act, ne * h->D.act_dim * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(obs, h->d_obs, ne * h->D.obs_dim * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(rew, h->d_rew, ne * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(done, h->d_done, ne, hipMemcpyDeviceToHost));
+    if (substeps) HIP_TRY(hipMemcpy(substeps, h->d_sub, ne * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int snk_substep_host(snk_handle* h, const float* targets, int32_t k, int32_t* info) {
+    if (!h || !targets) return fail("snk_substep_host: null argument");
+    if (k < 0) return fail("snk_substep_host: k < 0");
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t ne = (size_t)h->n_envs;
+    HIP_TRY(hipMemcpy(h->d_tgt, targets, ne * h->n * sizeof(float), hipMemcpyHostToDevice));
+    SNK_DISPATCH(h, launch_substep<16>(h, h->d_tgt, k, h->d_info, nullptr), launch_substep<32>(h, h->d_tgt, k, h->d_info, nullptr));
+    if (check_launch()) return 1;
+    HIP_TRY(hipDeviceSynchronize());
+    if (info) HIP_TRY(hipMemcpy(info, h->d_info, ne * 2 * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int snk_get_state(snk_handle* h, float* state, float* aux) {
+    if (!h) return fail("snk_get_state: null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t ne = (size_t)h->n_envs;
+    std::vector<float> recs(ne * h->rec);
+    HIP_TRY(hipMemcpy(recs.data(), h->d_recs, recs.size() * sizeof(float), hipMemcpyDeviceToHost));
+    const int sd = h->D.state_dim, n = h->n;
+    for (size_t e = 0; e < ne; e++) {
+        if (state) memcpy(state + e * sd, &recs[e * h->rec], sd * sizeof(float));
+        if (aux) memcpy(aux + e * (n + 2), &recs[e * h->rec + sd], (n + 2) * sizeof(float));
+    }
+    return 0;
+}
+
+int snk_set_state(snk_handle* h, const float* state, const float* aux) {
+    if (!h) return fail("snk_set_state: null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t ne = (size_t)h->n_envs;
+    std::vector<float> recs(ne * h->rec);
+    HIP_TRY(hipMemcpy(recs.data(), h->d_recs, recs.size() * sizeof(float), hipMemcpyDeviceToHost));
+    const int sd = h->D.state_dim, n = h->n;
+    for (size_t e = 0; e < ne; e++) {
+        if (state) memcpy(&recs[e * h->rec], state + e * sd, sd * sizeof(float));
+        if (aux) memcpy(&recs[e * h->rec + sd], aux + e * (n + 2), (n + 2) * sizeof(float));
+    }
+    HIP_TRY(hipMemcpy(h->d_recs, recs.data(), recs.size() * sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int snk_get_obs(snk_handle* h, float* obs) {
+    if (!h || !obs) return fail("snk_get_obs: null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    SNK_DISPATCH(h, launch_obs<16>(h, h->d_obs, nullptr, nullptr), launch_obs<32>(h, h->d_obs, nullptr, nullptr));
+    if (check_launch()) return 1;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(obs, h->d_obs, (size_t)h->n_envs * h->D.obs_dim * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int snk_mean_height(snk_handle* h, float* out) {
+    if (!h || !out) return fail("snk_mean_height: null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    SNK_DISPATCH(h, launch_obs<16>(h, nullptr, h->d_h, nullptr), launch_obs<32>(h, nullptr, h->d_h, nullptr));
+    if (check_launch()) return 1;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, h->d_h, (size_t)h->n_envs * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int snk_set_ground_friction(snk_handle* h, const float* mu) {
+    if (!h || !mu) return fail("snk_set_ground_friction: null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipMemcpy(h->d_mu, mu, (size_t)h->n_envs * sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int snk_selftest(int32_t device) {
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail("snk_selftest: no such HIP device");
+    HIP_TRY(hipSetDevice(device));
+    float* d = nullptr;
+    HIP_TRY(hipMalloc(&d, 4 * sizeof(float)));
+    hipLaunchKernelGGL(snk::selftest_kernel, dim3(1), dim3(64), 0, nullptr, d);
+    if (check_launch()) return 1;
+    float o[4];
+    HIP_TRY(hipMemcpy(o, d, sizeof(o), hipMemcpyDeviceToHost));
+    (void)hipFree(d);
+    const float s22 = 22.f * 23.f / 2.f, s64 = 64.f * 65.f / 2.f, s38 = 38.f * 39.f / 4.f;
+    if (o[0] != s22 || o[1] != s64 || o[2] != 18.f || o[3] != s38) {
+        char buf[160];
+        snprintf(buf, sizeof(buf), "selftest mismatch: sum32=%g (want %g) sum64=%g (want %g) bcast=%g (want 18) sum38=%g (want %g)",
+                 o[0], s22, o[1], s64, o[2], o[3], s38);
+        return fail(buf);
+    }
+    return 0;
+}
+
+int snk_model_describe(const snk_handle* h, double* out_bodies, double* out_origins) {
+    if (!h) return fail("snk_model_describe: null handle");
+    const int n = h->n;
+    double Rp[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, op[3] = {0, 0, 0};
+    for (int b = 0; b <= n; b++) {
+        if (out_bodies) {
+            double* o = out_bodies + 10 * b;
+            o[0] = h->H.mass[b];
+            for (int i = 0; i < 3; i++) o[1 + i] = h->H.com[b][i];
+            const double* I = h->H.Ib[b];
+            o[4] = I[0]; o[5] = I[1]; o[6] = I[2]; o[7] = I[4]; o[8] = I[5]; o[9] = I[8];
+        }
+        if (b >= 1) {
+            double t[3], Rn[9];
+            snk::detail::mv(Rp, h->H.pfix[b], t);
+            for (int i = 0; i < 3; i++) op[i] += t[i];
+            for (int i = 0; i < 3; i++)
+                for (int j = 0; j < 3; j++) {
+                    double s = 0;
+                    for (int k = 0; k < 3; k++) s += Rp[3 * i + k] * h->H.Rfix[b][3 * k + j];
+                    Rn[3 * i + j] = s;
+                }
+            memcpy(Rp, Rn, sizeof(Rn));
+        }
+        if (out_origins)
+            for (int i = 0; i < 3; i++) out_origins[3 * b + i] = op[i];
+    }
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,1027 @@
+// snk_device.hpp -- gfx950 device code of the batched snake stepper.
+//
+// ONE WAVEFRONT (64 lanes) PER ENVIRONMENT, one wave per workgroup.  The env's state
+// record is loaded coalesced from HBM into LDS once per env-step and written back once;
+// every physics substep (0..41 per env-step, snake.py:284-304) runs on chip.
+//
+// Formulation (differs on purpose from oracle/): the chain of n+1 composite bodies is
+// described in WORLD-ALIGNED axes with each body's quantities referenced to its own joint
+// origin o_b, and classical accelerations [alpha_b ; a(o_b)].  Transfers between
+// neighbouring bodies are then pure translations by r_b = o_b - o_{b-1}; the joint
+// subspace is S_b = [axis_b ; 0].  Articulated-body algorithm = Featherstone's three
+// sweeps in those coordinates.
+//
+// What replaces what (reference call sites, /root/reference):
+//   env_step_kernel      SnakeGymEnv.step (SnakeGymEnv.py:33-50) + Snake.step servo loop
+//                        (snake.py:274-306) + worker auto-reset (multiprocessing_env.py:13-15)
+//   substep()            pybullet.stepSimulation (snake.py:286) after
+//                        setJointMotorControlArray(POSITION_CONTROL) (snake.py:221)
+//   write_obs()          Snake.getObservation (snake.py:209-217)
+//   mean_height()        Snake.checkSnakeHeight (snake.py:237-245)
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "snk_model.hpp"
+
+namespace snk {
+
+// ----------------------------------------------------------------------------------
+// small vector helpers
+// ----------------------------------------------------------------------------------
+struct f3 {
+    float x, y, z;
+};
+__device__ __forceinline__ f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ f3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
+__device__ __forceinline__ void st3(float* p, f3 a) { p[0] = a.x; p[1] = a.y; p[2] = a.z; }
+__device__ __forceinline__ f3 operator+(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ f3 operator-(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ f3 operator*(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ f3 operator-(f3 a) { return mk3(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ f3 cross(f3 a, f3 b) {
+    return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+// y = R v (R row-major 3x3)
+__device__ __forceinline__ f3 mulRv(const float* R, f3 v) {
+    return mk3(R[0] * v.x + R[1] * v.y + R[2] * v.z, R[3] * v.x + R[4] * v.y + R[5] * v.z,
+               R[6] * v.x + R[7] * v.y + R[8] * v.z);
+}
+__device__ __forceinline__ f3 mulRtv(const float* R, f3 v) {
+    return mk3(R[0] * v.x + R[3] * v.y + R[6] * v.z, R[1] * v.x + R[4] * v.y + R[7] * v.z,
+               R[2] * v.x + R[5] * v.y + R[8] * v.z);
+}
+// symmetric 3x3 stored xx xy xz yy yz zz
+__device__ __forceinline__ f3 mulSv(const float* S, f3 v) {
+    return mk3(S[0] * v.x + S[1] * v.y + S[2] * v.z, S[1] * v.x + S[3] * v.y + S[4] * v.z,
+               S[2] * v.x + S[4] * v.y + S[5] * v.z);
+}
+// W = R S R^T for symmetric S (body -> world), result symmetric
+__device__ __forceinline__ void rotSym(const float* R, const float* S, float* W) {
+    float T[9];   // T = R S
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        T[3 * i + 0] = R[3 * i] * S[0] + R[3 * i + 1] * S[1] + R[3 * i + 2] * S[2];
+        T[3 * i + 1] = R[3 * i] * S[1] + R[3 * i + 1] * S[3] + R[3 * i + 2] * S[4];
+        T[3 * i + 2] = R[3 * i] * S[2] + R[3 * i + 1] * S[4] + R[3 * i + 2] * S[5];
+    }
+    W[0] = T[0] * R[0] + T[1] * R[1] + T[2] * R[2];
+    W[1] = T[0] * R[3] + T[1] * R[4] + T[2] * R[5];
+    W[2] = T[0] * R[6] + T[1] * R[7] + T[2] * R[8];
+    W[3] = T[3] * R[3] + T[4] * R[4] + T[5] * R[5];
+    W[4] = T[3] * R[6] + T[4] * R[7] + T[5] * R[8];
+    W[5] = T[6] * R[6] + T[7] * R[7] + T[8] * R[8];
+}
+
+// ----------------------------------------------------------------------------------
+// wave primitives (wave64, DPP; gfx9 row_shr / row_bcast forms)
+// ----------------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float x) {
+    // x + (x moved by the DPP pattern; lanes with no source or masked rows add 0)
+    int y = __builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, ROW_MASK, 0xf, true);
+    return x + __int_as_float(y);
+}
+// Sum over lanes 0..W-1 (W = 32 or 64), returned wave-uniform.
+template <int W>
+__device__ __forceinline__ float wave_sum(float x) {
+    x = dpp_add<0xB1, 0xf>(x);    // quad_perm [1,0,3,2]
+    x = dpp_add<0x4E, 0xf>(x);    // quad_perm [2,3,0,1]
+    x = dpp_add<0x114, 0xf>(x);   // row_shr:4
+    x = dpp_add<0x118, 0xf>(x);   // row_shr:8   -> lane 15 of each row = row total
+    x = dpp_add<0x142, 0xa>(x);   // row_bcast:15 into rows 1,3 -> lane 31 = sum 0..31
+    if (W == 64) {
+        x = dpp_add<0x143, 0xc>(x);   // row_bcast:31 into rows 2,3 -> lane 63 = sum 0..63
+        return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
+    }
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 31));
+}
+__device__ __forceinline__ float lane_bcast(float x, int src_lane_uniform) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), src_lane_uniform));
+}
+
+// ----------------------------------------------------------------------------------
+// LDS image of one environment
+// ----------------------------------------------------------------------------------
+template <int N>
+struct Lds {
+    static constexpr int NB = N + 1;     // composite bodies
+    static constexpr int ND = N + 6;     // generalized velocity [omega_w, v_w, qd]
+    static constexpr int NC = 4 * N;     // contact slots: 2n cylinders x 2 end caps
+    static constexpr int NR = 3 * NC;    // contact rows: normal + 2 friction
+    static constexpr int REC = (N <= 16) ? 64 : 128;
+    // HBM record, same order: base[13] q[N] qd[N] taum[N] fz prev_x
+    float rec[REC];
+    // per body, world axes
+    float R[NB][9], o[NB][3], r[NB][3], ax[NB][3], cw[NB][3];
+    float w[NB][3], v[NB][3], zeta[NB][6], p[NB][6], ext[NB][6];
+    float IA[NB][21];            // articulated inertia: A(6 sym) B(9) C(6 sym)
+    float Ua[NB][3], Ub[NB][3], Dinv[NB], u[NB];
+    float Inv0[36];
+    float qd_old[N], tauj[N], qdd[N], targets[N];
+    float acc0[6];
+    // contacts
+    float cP[NC][3], cdist[NC], cdA[NC][3], cdB[NC][3];
+    int clist[NC];
+    // constraint rows
+    float Mm[N][ND];             // M^-1 e_j for the motor / limit rows
+    float Jc[NR][ND], Mc[NR][ND];
+    float c_rhs[NR], c_dinv[NR], c_den[NR], c_app[NR];
+    int nc_joint[2 * N];
+    float nc_sign[2 * N], nc_rhs[2 * N], nc_dinv[2 * N], nc_den[2 * N], nc_lo[2 * N], nc_hi[2 * N], nc_app[2 * N];
+
+    __device__ __forceinline__ float* base() { return rec; }
+    __device__ __forceinline__ float* q() { return rec + 13; }
+    __device__ __forceinline__ float* qd() { return rec + 13 + N; }
+    __device__ __forceinline__ float* taum() { return rec + 13 + 2 * N; }
+    __device__ __forceinline__ float& fz() { return rec[13 + 3 * N]; }
+    __device__ __forceinline__ float& prev_x() { return rec[14 + 3 * N]; }
+};
+
+__device__ __forceinline__ void lds_sync() { __syncthreads(); }
+
+// ----------------------------------------------------------------------------------
+// S1: forward kinematics + link velocities of the chain (serial recurrence, evaluated
+// uniformly by the wave; lane 0 stores)
+// ----------------------------------------------------------------------------------
+template <int N>
+__device__ void fk_vel(Lds<N>& L, const DevModel& M, int lane) {
+    const float* bs = L.base();
+    float qx = bs[3], qy = bs[4], qz = bs[5], qw = bs[6];
+    float dd = qx * qx + qy * qy + qz * qz + qw * qw;
+    float s2 = 2.0f / dd;
+    float xs = qx * s2, ys = qy * s2, zs = qz * s2;
+    float wx = qw * xs, wy = qw * ys, wz = qw * zs;
+    float xx = qx * xs, xy = qx * ys, xz = qx * zs, yy = qy * ys, yz = qy * zs, zz = qz * zs;
+    float Rp[9] = {1 - (yy + zz), xy - wz, xz + wy, xy + wz, 1 - (xx + zz), yz - wx, xz - wy, yz + wx, 1 - (xx + yy)};
+    f3 op = ld3(bs), wp = ld3(bs + 7), vp = ld3(bs + 10);
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) L.R[0][i] = Rp[i];
+        st3(L.o[0], op); st3(L.w[0], wp); st3(L.v[0], vp);
+        st3(L.r[0], mk3(0, 0, 0)); st3(L.ax[0], mk3(0, 0, 0));
+#pragma unroll
+        for (int i = 0; i < 6; i++) L.zeta[0][i] = 0.f;
+    }
+    for (int b = 1; b <= N; b++) {
+        const float* Rf = M.Rfix[b];
+        float T[9];
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++)
+                T[3 * i + j] = Rp[3 * i] * Rf[j] + Rp[3 * i + 1] * Rf[3 + j] + Rp[3 * i + 2] * Rf[6 + j];
+        float qb = L.q()[b - 1], qdb = L.qd()[b - 1];
+        float sn, cs;
+        sincosf(qb, &sn, &cs);
+        float Rn[9];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            Rn[3 * i + 0] = cs * T[3 * i] - sn * T[3 * i + 2];
+            Rn[3 * i + 1] = T[3 * i + 1];
+            Rn[3 * i + 2] = sn * T[3 * i] + cs * T[3 * i + 2];
+        }
+        f3 rb = mulRv(Rp, ld3(M.pfix[b]));
+        f3 o = op + rb;
+        f3 ax = mk3(T[1], T[4], T[7]);
+        f3 w = wp + ax * qdb;
+        f3 v = vp + cross(wp, rb);
+        f3 za = cross(wp, ax) * qdb;
+        f3 zl = cross(wp, cross(wp, rb));
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 9; i++) L.R[b][i] = Rn[i];
+            st3(L.o[b], o); st3(L.r[b], rb); st3(L.ax[b], ax); st3(L.w[b], w); st3(L.v[b], v);
+            st3(&L.zeta[b][0], za); st3(&L.zeta[b][3], zl);
+        }
+#pragma unroll
+        for (int i = 0; i < 9; i++) Rp[i] = Rn[i];
+        op = o; wp = w; vp = v;
+    }
+    lds_sync();
+}
+
+// checkSnakeHeight's mean z over {`base` link COM, OUTPUT_BODY origins} (snake.py:237-245)
+template <int N>
+__device__ float mean_height(Lds<N>& L, const DevModel& M, int lane) {
+    float z = 0.f;
+    if (lane == 0) z = L.o[0][2] + L.R[0][6] * M.hbase[0] + L.R[0][7] * M.hbase[1] + L.R[0][8] * M.hbase[2];
+    else if (lane <= N) z = L.o[lane][2];
+    return wave_sum<64>(z) * (1.0f / (N + 1));
+}
+
+// ----------------------------------------------------------------------------------
+// S2: per-body bias forces (lane = body): p_b = [w x I w ; m w x (w x c)] - external
+// ----------------------------------------------------------------------------------
+template <int N, bool FIRST>
+__device__ void body_bias(Lds<N>& L, const DevModel& M, int lane) {
+    if (lane <= N) {
+        const int b = lane;
+        const float* R = L.R[b];
+        f3 w = ld3(L.w[b]), v = ld3(L.v[b]);
+        float m = M.mass[b];
+        f3 cw = mulRv(R, ld3(M.com[b]));
+        float Ibar[6];
+        rotSym(R, M.Ib[b], Ibar);
+        f3 pN = cross(w, mulSv(Ibar, w));
+        f3 pF = cross(w, cross(w, cw)) * m;
+        // [U] btMultiBody link damping, per original URDF link of the composite
+        float Irw[6];
+        rotSym(R, M.Irot[b], Irw);
+        float nw = sqrtf(dot(w, w));
+        pN = pN + mulSv(Irw, w) * (M.ang_damp + M.ang_damp * nw);
+        const int ns = M.nsub[b];
+        for (int s = 0; s < ns; s++) {
+            f3 cs = mulRv(R, ld3(M.sub_c[b][s]));
+            f3 vs = v + cross(w, cs);
+            float nv = sqrtf(dot(vs, vs));
+            f3 F = vs * (M.sub_m[b][s] * (M.lin_damp + M.lin_damp * nv));   // opposes motion
+            pF = pF + F;
+            pN = pN + cross(cs, F);
+        }
+        if (FIRST) {
+            f3 G = mk3(0.f, 0.f, m * M.gz);
+            pF = pF - G;
+            pN = pN - cross(cw, G);
+            st3(L.cw[b], cw);
+            // articulated inertia initial value  [[Ibar, m[c]x], [-m[c]x, m 1]]
+            float* IA = L.IA[b];
+#pragma unroll
+            for (int i = 0; i < 6; i++) IA[i] = Ibar[i];
+            float hx = m * cw.x, hy = m * cw.y, hz = m * cw.z;
+            IA[6] = 0.f; IA[7] = -hz; IA[8] = hy;
+            IA[9] = hz;  IA[10] = 0.f; IA[11] = -hx;
+            IA[12] = -hy; IA[13] = hx; IA[14] = 0.f;
+            IA[15] = m; IA[16] = 0.f; IA[17] = 0.f; IA[18] = m; IA[19] = 0.f; IA[20] = m;
+        } else {
+            pN = pN - ld3(&L.ext[b][0]);
+            pF = pF - ld3(&L.ext[b][3]);
+        }
+        st3(&L.p[b][0], pN);
+        st3(&L.p[b][3], pF);
+    }
+}
+
+// ----------------------------------------------------------------------------------
+// ground contacts (lane = slot): cylinder c = slot/2 on body (c+1)/2, end cap = slot&1.
+// Implicit cylinder + margin against the plane z = 0; kept when closer than the
+// breaking threshold [U].  Friction directions (0,-1,0),(1,0,0) scaled anisotropically in
+// the cylinder link's axes: d' = Rc diag(aniso) Rc^T d  (snake.py:104-106).
+// ----------------------------------------------------------------------------------
+template <int N>
+__device__ int find_contacts(Lds<N>& L, const DevModel& M, int lane) {
+    int total = 0;
+    for (int base = 0; base < 4 * N; base += 64) {
+        const int slot = base + lane;
+        bool active = false;
+        if (slot < 4 * N) {
+            const int c = slot >> 1;
+            const int b = (c + 1) >> 1;
+            const float* Rb = L.R[b];
+            const float* Rc = M.cyl_R[c];
+            float Rw[9];
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+#pragma unroll
+                for (int j = 0; j < 3; j++)
+                    Rw[3 * i + j] = Rb[3 * i] * Rc[j] + Rb[3 * i + 1] * Rc[3 + j] + Rb[3 * i + 2] * Rc[6 + j];
+            f3 dl = mk3(-Rw[6], -Rw[7], -Rw[8]);
+            float rr = sqrtf(dl.x * dl.x + dl.y * dl.y);
+            float lx = 0.f, ly = 0.f;
+            if (rr > 1e-12f) { lx = M.cyl_r * dl.x / rr; ly = M.cyl_r * dl.y / rr; }
+            float lz = (slot & 1) ? M.cyl_hl : -M.cyl_hl;
+            f3 loc = mk3(lx + M.margin * dl.x, ly + M.margin * dl.y, lz + M.margin * dl.z);
+            f3 P = ld3(L.o[b]) + mulRv(Rb, ld3(M.cyl_c[c])) + mulRv(Rw, loc);
+            float dist = P.z;
+            active = dist < M.break_thr;
+            st3(L.cP[slot], P);
+            L.cdist[slot] = dist;
+            f3 a = mk3(M.aniso[0], M.aniso[1], M.aniso[2]);
+            f3 l1 = mulRtv(Rw, mk3(0.f, -1.f, 0.f));
+            f3 l2 = mulRtv(Rw, mk3(1.f, 0.f, 0.f));
+            st3(L.cdA[slot], mulRv(Rw, mk3(l1.x * a.x, l1.y * a.y, l1.z * a.z)));
+            st3(L.cdB[slot], mulRv(Rw, mk3(l2.x * a.x, l2.y * a.y, l2.z * a.z)));
+        }
+        unsigned long long bal = __ballot(active);
+        if (active) {
+            int idx = total + __popcll(bal & ((1ull << lane) - 1ull));
+            L.clist[idx] = slot;
+        }
+        total += __popcll(bal);
+    }
+    return total;
+}
+
+// ----------------------------------------------------------------------------------
+// S3: ABA sweeps, evaluated uniformly by the wave (serial recurrence over the chain).
+// FACTOR: also builds the articulated inertias IA, U = IA S, D = S^T U and the base inverse.
+// ----------------------------------------------------------------------------------
+template <int N, bool FACTOR>
+__device__ void aba_main(Lds<N>& L, const DevModel& M, int lane) {
+    float cA[6], cB[9], cC[6];   // child contribution to the parent's articulated inertia
+#pragma unroll
+    for (int i = 0; i < 6; i++) { cA[i] = 0.f; cC[i] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < 9; i++) cB[i] = 0.f;
+    f3 cN = mk3(0, 0, 0), cF = mk3(0, 0, 0);
+    for (int b = N; b >= 1; b--) {
+        float A[6], B[9], C[6];
+        float* IA = L.IA[b];
+#pragma unroll
+        for (int i = 0; i < 6; i++) { A[i] = IA[i]; C[i] = IA[15 + i]; }
+#pragma unroll
+        for (int i = 0; i < 9; i++) B[i] = IA[6 + i];
+        if (FACTOR) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) { A[i] += cA[i]; C[i] += cC[i]; }
+#pragma unroll
+            for (int i = 0; i < 9; i++) B[i] += cB[i];
+        }
+        f3 pN = ld3(&L.p[b][0]) + cN, pF = ld3(&L.p[b][3]) + cF;
+        f3 ax = ld3(L.ax[b]);
+        f3 Ua, Ub;
+        float Dinv;
+        if (FACTOR) {
+            Ua = mulSv(A, ax);
+            Ub = mk3(B[0] * ax.x + B[3] * ax.y + B[6] * ax.z, B[1] * ax.x + B[4] * ax.y + B[7] * ax.z,
+                     B[2] * ax.x + B[5] * ax.y + B[8] * ax.z);
+            Dinv = 1.0f / dot(ax, Ua);
+        } else {
+            Ua = ld3(L.Ua[b]); Ub = ld3(L.Ub[b]); Dinv = L.Dinv[b];
+        }
+        f3 za = ld3(&L.zeta[b][0]), zl = ld3(&L.zeta[b][3]);
+        float u = L.tauj[b - 1] - dot(ax, pN);
+        // IA zeta
+        f3 tN = mulSv(A, za) + mk3(B[0] * zl.x + B[1] * zl.y + B[2] * zl.z, B[3] * zl.x + B[4] * zl.y + B[5] * zl.z,
+                                   B[6] * zl.x + B[7] * zl.y + B[8] * zl.z);
+        f3 tF = mk3(B[0] * za.x + B[3] * za.y + B[6] * za.z, B[1] * za.x + B[4] * za.y + B[7] * za.z,
+                    B[2] * za.x + B[5] * za.y + B[8] * za.z) + mulSv(C, zl);
+        float uz = dot(Ua, za) + dot(Ub, zl);
+        float s = (u - uz) * Dinv;
+        f3 paN = pN + tN + Ua * s, paF = pF + tF + Ub * s;
+        f3 r = ld3(L.r[b]);
+        cN = paN + cross(r, paF);
+        cF = paF;
+        if (lane == 0) {
+            L.u[b] = u;
+            if (FACTOR) {
+#pragma unroll
+                for (int i = 0; i < 6; i++) { IA[i] = A[i]; IA[15 + i] = C[i]; }
+#pragma unroll
+                for (int i = 0; i < 9; i++) IA[6 + i] = B[i];
+                st3(L.Ua[b], Ua); st3(L.Ub[b], Ub); L.Dinv[b] = Dinv;
+            }
+        }
+        if (FACTOR) {
+            // Ia = IA - U U^T / D
+            float ua[3] = {Ua.x, Ua.y, Ua.z}, ub[3] = {Ub.x, Ub.y, Ub.z};
+            float Ap[6], Bp[9], Cp[6];
+            Ap[0] = A[0] - ua[0] * ua[0] * Dinv; Ap[1] = A[1] - ua[0] * ua[1] * Dinv; Ap[2] = A[2] - ua[0] * ua[2] * Dinv;
+            Ap[3] = A[3] - ua[1] * ua[1] * Dinv; Ap[4] = A[4] - ua[1] * ua[2] * Dinv; Ap[5] = A[5] - ua[2] * ua[2] * Dinv;
+            Cp[0] = C[0] - ub[0] * ub[0] * Dinv; Cp[1] = C[1] - ub[0] * ub[1] * Dinv; Cp[2] = C[2] - ub[0] * ub[2] * Dinv;
+            Cp[3] = C[3] - ub[1] * ub[1] * Dinv; Cp[4] = C[4] - ub[1] * ub[2] * Dinv; Cp[5] = C[5] - ub[2] * ub[2] * Dinv;
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+#pragma unroll
+                for (int j = 0; j < 3; j++) Bp[3 * i + j] = B[3 * i + j] - ua[i] * ub[j] * Dinv;
+            // shift to the parent's origin: X = [[1,0],[-rx,1]];  IA_parent += X^T Ia X
+            //   Bn = Bp + rx Cp ;  An = Ap - Bp rx + rx Bn^T ;  Cn = Cp
+            f3 c0 = cross(r, mk3(Cp[0], Cp[1], Cp[2]));   // rx * column j of Cp (symmetric)
+            f3 c1 = cross(r, mk3(Cp[1], Cp[3], Cp[4]));
+            f3 c2 = cross(r, mk3(Cp[2], Cp[4], Cp[5]));
+            float Bn[9] = {Bp[0] + c0.x, Bp[1] + c1.x, Bp[2] + c2.x, Bp[3] + c0.y, Bp[4] + c1.y, Bp[5] + c2.y,
+                           Bp[6] + c0.z, Bp[7] + c1.z, Bp[8] + c2.z};
+            // (-Bp rx) row i = r x row_i(Bp);  (rx Bn^T) column j = r x row_j(Bn)
+            f3 e0 = cross(r, mk3(Bp[0], Bp[1], Bp[2])), e1 = cross(r, mk3(Bp[3], Bp[4], Bp[5])),
+               e2 = cross(r, mk3(Bp[6], Bp[7], Bp[8]));
+            f3 g0 = cross(r, mk3(Bn[0], Bn[1], Bn[2])), g1 = cross(r, mk3(Bn[3], Bn[4], Bn[5])),
+               g2 = cross(r, mk3(Bn[6], Bn[7], Bn[8]));
+            cA[0] = Ap[0] + e0.x + g0.x;
+            cA[1] = Ap[1] + e0.y + g1.x;
+            cA[2] = Ap[2] + e0.z + g2.x;
+            cA[3] = Ap[3] + e1.y + g1.y;
+            cA[4] = Ap[4] + e1.z + g2.y;
+            cA[5] = Ap[5] + e2.z + g2.z;
+#pragma unroll
+            for (int i = 0; i < 9; i++) cB[i] = Bn[i];
+#pragma unroll
+            for (int i = 0; i < 6; i++) cC[i] = Cp[i];
+        }
+    }
+    // base: [alpha0; a0] = -IA0^-1 p0
+    f3 pN = ld3(&L.p[0][0]) + cN, pF = ld3(&L.p[0][3]) + cF;
+    float p0[6] = {pN.x, pN.y, pN.z, pF.x, pF.y, pF.z};
+    if (FACTOR) {
+        float* IA = L.IA[0];
+        float A[6], B[9], C[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) { A[i] = IA[i] + cA[i]; C[i] = IA[15 + i] + cC[i]; }
+#pragma unroll
+        for (int i = 0; i < 9; i++) B[i] = IA[6 + i] + cB[i];
+        float G[6][6];
+        G[0][0] = A[0]; G[0][1] = A[1]; G[0][2] = A[2]; G[1][1] = A[3]; G[1][2] = A[4]; G[2][2] = A[5];
+        G[1][0] = A[1]; G[2][0] = A[2]; G[2][1] = A[4];
+        G[3][3] = C[0]; G[3][4] = C[1]; G[3][5] = C[2]; G[4][4] = C[3]; G[4][5] = C[4]; G[5][5] = C[5];
+        G[4][3] = C[1]; G[5][3] = C[2]; G[5][4] = C[4];
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) { G[i][3 + j] = B[3 * i + j]; G[3 + j][i] = B[3 * i + j]; }
+        // Gauss-Jordan inverse of the SPD 6x6 (no pivoting)
+        float V[6][6];
+#pragma unroll
+        for (int i = 0; i < 6; i++)
+#pragma unroll
+            for (int j = 0; j < 6; j++) V[i][j] = (i == j) ? 1.f : 0.f;
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            float piv = 1.0f / G[k][k];
+#pragma unroll
+            for (int j = 0; j < 6; j++) { G[k][j] *= piv; V[k][j] *= piv; }
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+                if (i != k) {
+                    float f = G[i][k];
+#pragma unroll
+                    for (int j = 0; j < 6; j++) { G[i][j] -= f * G[k][j]; V[i][j] -= f * V[k][j]; }
+                }
+            }
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 6; i++)
+#pragma unroll
+                for (int j = 0; j < 6; j++) L.Inv0[6 * i + j] = V[i][j];
+        }
+        float a0[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < 6; j++) s -= V[i][j] * p0[j];
+            a0[i] = s;
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) L.acc0[i] = a0[i];
+        }
+    } else {
+        float a0[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < 6; j++) s -= L.Inv0[6 * i + j] * p0[j];
+            a0[i] = s;
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) L.acc0[i] = a0[i];
+        }
+    }
+    lds_sync();
+    // forward sweep: joint accelerations
+    f3 al = ld3(&L.acc0[0]), a = ld3(&L.acc0[3]);
+    for (int b = 1; b <= N; b++) {
+        f3 r = ld3(L.r[b]);
+        f3 ap = a + cross(al, r) + ld3(&L.zeta[b][3]);
+        f3 alp = al + ld3(&L.zeta[b][0]);
+        float qdd = (L.u[b] - (dot(ld3(L.Ua[b]), alp) + dot(ld3(L.Ub[b]), ap))) * L.Dinv[b];
+        al = alp + ld3(L.ax[b]) * qdd;
+        a = ap;
+        if (lane == 0) L.qdd[b - 1] = qdd;
+    }
+    lds_sync();
+}
+
+// ----------------------------------------------------------------------------------
+// S5: constraint rows, lane = row.  Each lane runs the ABA delta sweeps for a unit
+// (generalized) impulse -> M^-1 J^T, and builds J, the diagonal and the right-hand side
+// (btMultiBodyConstraintSolver::setupMultiBodyContactConstraint / btMultiBodyJointMotor [U]).
+// ----------------------------------------------------------------------------------
+template <int N>
+__device__ void build_rows(Lds<N>& L, const DevModel& M, int lane, int nc, int& n_noncontact) {
+    constexpr int ND = N + 6;
+    const int nrows = N + 3 * nc;
+    const float* gb = L.base() + 7;   // omega_w, v_w (after the unconstrained update)
+    for (int rid = lane; rid < nrows; rid += 64) {
+        const bool motor = rid < N;
+        int k, slot = 0, kind = 0;
+        f3 P = mk3(0, 0, 0), d = mk3(0, 0, 0);
+        float* Mrow;
+        float* Jrow = nullptr;
+        if (motor) {
+            k = rid + 1;
+            Mrow = L.Mm[rid];
+        } else {
+            const int ci = (rid - N) / 3;
+            kind = (rid - N) - 3 * ci;
+            slot = L.clist[ci];
+            k = ((slot >> 1) + 1) >> 1;
+            P = ld3(L.cP[slot]);
+            d = kind == 0 ? mk3(0.f, 0.f, 1.f) : (kind == 1 ? ld3(L.cdA[slot]) : ld3(L.cdB[slot]));
+            Mrow = L.Mc[rid - N];
+            Jrow = L.Jc[rid - N];
+        }
+        // backward sweep of the delta problem (zero velocity, impulse only)
+        f3 pN = mk3(0, 0, 0), pF = mk3(0, 0, 0);
+        for (int b = N; b >= 1; b--) {
+            f3 ax = ld3(L.ax[b]);
+            if (!motor && b == k) {
+                pN = pN - cross(P - ld3(L.o[b]), d);
+                pF = pF - d;
+            }
+            float u = -dot(ax, pN);
+            if (motor && b == k) u += 1.0f;
+            Mrow[6 + b - 1] = u;
+            float t = u * L.Dinv[b];
+            f3 paN = pN + ld3(L.Ua[b]) * t, paF = pF + ld3(L.Ub[b]) * t;
+            pN = paN + cross(ld3(L.r[b]), paF);
+            pF = paF;
+        }
+        f3 J0 = mk3(0, 0, 0), J1 = mk3(0, 0, 0);
+        if (!motor) {
+            J0 = cross(P - ld3(L.o[0]), d);
+            J1 = d;
+            if (k == 0) { pN = pN - J0; pF = pF - d; }
+        }
+        float p0[6] = {pN.x, pN.y, pN.z, pF.x, pF.y, pF.z}, a0[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < 6; j++) s -= L.Inv0[6 * i + j] * p0[j];
+            a0[i] = s;
+            Mrow[i] = s;
+        }
+        f3 al = mk3(a0[0], a0[1], a0[2]), a = mk3(a0[3], a0[4], a0[5]);
+        float den = dot(J0, al) + dot(J1, a);
+        float rv = dot(J0, ld3(gb)) + dot(J1, ld3(gb + 3));
+        if (!motor) { st3(Jrow, J0); st3(Jrow + 3, J1); }
+        for (int b = 1; b <= N; b++) {
+            a = a + cross(al, ld3(L.r[b]));
+            float u = Mrow[6 + b - 1];
+            float qdd = (u - (dot(ld3(L.Ua[b]), al) + dot(ld3(L.Ub[b]), a))) * L.Dinv[b];
+            f3 ax = ld3(L.ax[b]);
+            al = al + ax * qdd;
+            Mrow[6 + b - 1] = qdd;
+            if (!motor) {
+                float Jb = (b <= k) ? dot(ax, cross(P - ld3(L.o[b]), d)) : 0.f;
+                Jrow[6 + b - 1] = Jb;
+                den += Jb * qdd;
+                rv += Jb * L.qd()[b - 1];
+            } else if (b == k) {
+                den = qdd;
+            }
+        }
+        if (!motor) {
+            const int row = rid - N;
+            float dinv = den > 1.1920929e-7f ? 1.0f / den : 0.f;
+            float target;
+            if (kind == 0) {
+                float pen = L.cdist[slot] + M.slop;
+                target = -rv + (pen > 0.f ? -pen * M.inv_dt : -pen * M.contact_erp * M.inv_dt);
+            } else {
+                target = -rv;
+            }
+            L.c_rhs[row] = target * dinv;
+            L.c_dinv[row] = dinv;
+            L.c_den[row] = den;
+            L.c_app[row] = 0.f;
+        }
+    }
+    lds_sync();
+    // non-contact rows: violated joint limits first, then the n motors
+    // (btMultiBodyJointLimitConstraint, btMultiBodyJointMotor [U])
+    int nlim = 0;
+    {
+        bool viol = false;
+        float sgn = 0.f, pen = 0.f;
+        if (lane < N) {
+            float qj = L.q()[lane];
+            float plo = qj - M.jlo, phi = M.jhi - qj;
+            if (plo <= 0.f) { viol = true; sgn = 1.f; pen = plo; }
+            else if (phi <= 0.f) { viol = true; sgn = -1.f; pen = phi; }
+        }
+        unsigned long long bal = __ballot(viol);
+        nlim = __popcll(bal);
+        if (viol) {
+            int idx = __popcll(bal & ((1ull << lane) - 1ull));
+            float den = L.Mm[lane][6 + lane];
+            float dinv = den > 1.1920929e-7f ? 1.0f / den : 0.f;
+            float rel = sgn * L.qd()[lane];
+            L.nc_joint[idx] = lane; L.nc_sign[idx] = sgn;
+            L.nc_rhs[idx] = (-rel + (-pen) * M.limit_erp * M.inv_dt) * dinv;
+            L.nc_dinv[idx] = dinv; L.nc_den[idx] = den;
+            L.nc_lo[idx] = 0.f; L.nc_hi[idx] = M.limit_max; L.nc_app[idx] = 0.f;
+        }
+        if (lane < N) {
+            int idx = nlim + lane;
+            float den = L.Mm[lane][6 + lane];
+            float dinv = den > 1.1920929e-7f ? 1.0f / den : 0.f;
+            float cur = L.qd()[lane];
+            float want = M.kp * (L.targets[lane] - L.q()[lane]) * M.inv_dt + cur + M.kd * (0.f - cur);
+            L.nc_joint[idx] = lane; L.nc_sign[idx] = 1.f;
+            L.nc_rhs[idx] = (want - cur) * dinv;
+            L.nc_dinv[idx] = dinv; L.nc_den[idx] = den;
+            L.nc_lo[idx] = -M.max_motor_imp; L.nc_hi[idx] = M.max_motor_imp; L.nc_app[idx] = 0.f;
+        }
+    }
+    n_noncontact = nlim + N;
+    lds_sync();
+}
+
+// ----------------------------------------------------------------------------------
+// S6: projected Gauss-Seidel, lane = generalized-velocity component
+// (btMultiBodyConstraintSolver::solveSingleIteration / resolveSingleConstraintRowGeneric /
+//  resolveConeFrictionConstraintRows [U]).  Returns delta-v of this lane.
+// ----------------------------------------------------------------------------------
+template <int N>
+__device__ float pgs(Lds<N>& L, const DevModel& M, int lane, int nc, int nn, float mu, int& iters) {
+    constexpr int ND = N + 6;
+    constexpr int W = (ND <= 32) ? 32 : 64;
+    const bool act = lane < ND;
+    float dv = 0.f;
+    int it = 0;
+    for (; it < M.n_iter; it++) {
+        float lsq = 0.f;
+        for (int jj = 0; jj < nn; jj++) {
+            const int idx = (it & 1) ? jj : nn - 1 - jj;
+            const int j = __builtin_amdgcn_readfirstlane(L.nc_joint[idx]);
+            const float sg = L.nc_sign[idx];
+            float un = sg * lane_bcast(dv, 6 + j);
+            float a0 = L.nc_app[idx];
+            float dI = L.nc_rhs[idx] - un * L.nc_dinv[idx];
+            float sum = fminf(fmaxf(a0 + dI, L.nc_lo[idx]), L.nc_hi[idx]);
+            dI = sum - a0;
+            L.nc_app[idx] = sum;   // uniform value, every lane stores it: no barrier needed
+            float mv = act ? L.Mm[j][lane] : 0.f;
+            dv += sg * mv * dI;
+            float rr = dI * L.nc_den[idx];
+            lsq = fmaxf(lsq, rr * rr);
+        }
+        for (int ci = 0; ci < nc; ci++) {
+            const int row = 3 * ci;
+            float jv = act ? L.Jc[row][lane] : 0.f;
+            float un = wave_sum<W>(jv * dv);
+            float a0 = L.c_app[row];
+            float dI = L.c_rhs[row] - un * L.c_dinv[row];
+            float sum = fminf(fmaxf(a0 + dI, 0.f), 1e10f);
+            dI = sum - a0;
+            L.c_app[row] = sum;
+            float mv = act ? L.Mc[row][lane] : 0.f;
+            dv += mv * dI;
+            float rr = dI * L.c_den[row];
+            lsq = fmaxf(lsq, rr * rr);
+        }
+        for (int ci = 0; ci < nc; ci++) {
+            const int rA = 3 * ci + 1, rB = 3 * ci + 2;
+            float lim = mu * L.c_app[3 * ci];
+            float jA = act ? L.Jc[rA][lane] : 0.f, jB = act ? L.Jc[rB][lane] : 0.f;
+            float mA = act ? L.Mc[rA][lane] : 0.f, mB = act ? L.Mc[rB][lane] : 0.f;
+            float aA = L.c_app[rA], aB = L.c_app[rB];
+            if (M.cone) {
+                float uA = wave_sum<W>(jA * dv), uB = wave_sum<W>(jB * dv);
+                float sA = aA + (L.c_rhs[rA] - uA * L.c_dinv[rA]);
+                float sB = aB + (L.c_rhs[rB] - uB * L.c_dinv[rB]);
+                float rr = sqrtf(sA * sA + sB * sB);
+                if (rr > lim) {
+                    float sc = rr > 0.f ? lim / rr : 0.f;
+                    sA *= sc; sB *= sc;
+                }
+                float dA = sA - aA, dB = sB - aB;
+                L.c_app[rA] = sA; L.c_app[rB] = sB;
+                dv += mA * dA + mB * dB;
+                float ra = dA * L.c_den[rA], rb = dB * L.c_den[rB];
+                lsq = fmaxf(lsq, fmaxf(ra * ra, rb * rb));
+            } else if (lim > 0.f) {
+                float uA = wave_sum<W>(jA * dv);
+                float sA = fminf(fmaxf(aA + (L.c_rhs[rA] - uA * L.c_dinv[rA]), -lim), lim);
+                float dA = sA - aA;
+                dv += mA * dA;
+                float uB = wave_sum<W>(jB * dv);
+                float sB = fminf(fmaxf(aB + (L.c_rhs[rB] - uB * L.c_dinv[rB]), -lim), lim);
+                float dB = sB - aB;
+                dv += mB * dB;
+                L.c_app[rA] = sA; L.c_app[rB] = sB;
+                float ra = dA * L.c_den[rA], rb = dB * L.c_den[rB];
+                lsq = fmaxf(lsq, fmaxf(ra * ra, rb * rb));
+            }
+        }
+        if (lsq <= M.resid_thr || it >= M.n_iter - 1) { it++; break; }
+    }
+    lds_sync();
+    iters = it;
+    return dv;
+}
+
+// ----------------------------------------------------------------------------------
+// one physics substep
+// ----------------------------------------------------------------------------------
+template <int N>
+__device__ void substep(Lds<N>& L, const DevModel& M, int lane, float mu, int& iters, int& ncontacts) {
+    constexpr int ND = N + 6;
+    const float dt = M.dt;
+    // (1) contacts of the current pose, (2) bias forces with gravity, joint damping torque
+    const int nc = find_contacts<N>(L, M, lane);
+    ncontacts = nc;
+    if (lane < N) {
+        float qd = L.qd()[lane];
+        L.qd_old[lane] = qd;
+        L.tauj[lane] = -M.joint_damp * qd;   // PyBullet adds URDF joint damping as a torque [U]
+    }
+    body_bias<N, true>(L, M, lane);
+    lds_sync();
+    aba_main<N, true>(L, M, lane);
+    // joint-0 force sensor, first pass [U]: -zb . [m_r (a - g) + m_r v (k + k|v|)]
+    f3 zb = mulRv(L.R[0], ld3(M.zbase));
+    f3 v_old = ld3(L.base() + 10);
+    float nv0 = sqrtf(dot(v_old, v_old));
+    f3 a1 = ld3(&L.acc0[3]);
+    float fz = -dot(zb, (a1 - mk3(0.f, 0.f, M.gz)) * M.m_root + v_old * (M.m_root * (M.lin_damp + M.lin_damp * nv0)));
+    // (3) v += a dt (clamped)
+    if (lane < 6) {
+        float x = L.base()[7 + lane] + L.acc0[lane] * dt;
+        L.base()[7 + lane] = fminf(fmaxf(x, -M.max_vel), M.max_vel);
+    } else if (lane < ND) {
+        float x = L.qd()[lane - 6] + L.qdd[lane - 6] * dt;
+        L.qd()[lane - 6] = fminf(fmaxf(x, -M.max_vel), M.max_vel);
+    }
+    lds_sync();
+    // (4) rows, (5) PGS
+    int nn = 0;
+    build_rows<N>(L, M, lane, nc, nn);
+    float dv = pgs<N>(L, M, lane, nc, nn, mu, iters);
+    // (6) constraint pass for the joint-0 sensor [U]: ABA at the velocities after (3) with the
+    // constraint forces as the only link forces, joint torques still applied
+    if (lane <= N) {
+        const int b = lane;
+        f3 eN = mk3(0, 0, 0), eF = mk3(0, 0, 0);
+        // contact slots of body b: cylinders 2b-1, 2b (body 0: cylinder 0)
+        for (int ci = 0; ci < nc; ci++) {
+            const int slot = L.clist[ci];
+            if ((((slot >> 1) + 1) >> 1) == b) {
+                f3 F = (mk3(0.f, 0.f, 1.f) * L.c_app[3 * ci] + ld3(L.cdA[slot]) * L.c_app[3 * ci + 1] +
+                        ld3(L.cdB[slot]) * L.c_app[3 * ci + 2]) * M.inv_dt;
+                eF = eF + F;
+                eN = eN + cross(ld3(L.cP[slot]) - ld3(L.o[b]), F);
+            }
+        }
+        st3(&L.ext[b][0], eN);
+        st3(&L.ext[b][3], eF);
+    }
+    if (lane < N) L.tauj[lane] = -M.joint_damp * L.qd_old[lane];
+    lds_sync();
+    if (lane == 0) {
+        for (int i = 0; i < nn; i++) L.tauj[L.nc_joint[i]] += L.nc_sign[i] * L.nc_app[i] * M.inv_dt;
+    }
+    lds_sync();
+    // velocities changed in (3): refresh w, v, zeta of every body (pose unchanged)
+    {
+        f3 wp = ld3(L.base() + 7), vp = ld3(L.base() + 10);
+        if (lane == 0) { st3(L.w[0], wp); st3(L.v[0], vp); }
+        for (int b = 1; b <= N; b++) {
+            f3 ax = ld3(L.ax[b]), rb = ld3(L.r[b]);
+            float qdb = L.qd()[b - 1];
+            f3 w = wp + ax * qdb, v = vp + cross(wp, rb);
+            f3 za = cross(wp, ax) * qdb, zl = cross(wp, cross(wp, rb));
+            if (lane == 0) { st3(L.w[b], w); st3(L.v[b], v); st3(&L.zeta[b][0], za); st3(&L.zeta[b][3], zl); }
+            wp = w; vp = v;
+        }
+    }
+    lds_sync();
+    body_bias<N, false>(L, M, lane);
+    lds_sync();
+    aba_main<N, false>(L, M, lane);
+    {
+        f3 v1 = ld3(L.base() + 10);
+        float nv1 = sqrtf(dot(v1, v1));
+        f3 a2 = ld3(&L.acc0[3]);
+        fz += -dot(zb, a2 * M.m_root + v1 * (M.m_root * (M.lin_damp + M.lin_damp * nv1)));
+    }
+    // (7) apply the solver's delta-v (clamped), motor torques, integrate positions
+    if (lane < 6) {
+        float x = L.base()[7 + lane] + dv;
+        L.base()[7 + lane] = fminf(fmaxf(x, -M.max_vel), M.max_vel);
+    } else if (lane < ND) {
+        float x = L.qd()[lane - 6] + dv;
+        x = fminf(fmaxf(x, -M.max_vel), M.max_vel);
+        L.qd()[lane - 6] = x;
+        L.q()[lane - 6] += dt * x;
+    }
+    if (lane < N) {
+        // motor rows sit after the limit rows in the non-contact list
+        L.taum()[lane] = L.nc_app[nn - N + lane] * M.inv_dt;
+    }
+    lds_sync();
+    {
+        float* bs = L.base();
+        f3 om = ld3(bs + 7), vl = ld3(bs + 10);
+        float fA = sqrtf(dot(om, om));
+        const float kThr = 0.78539816339744831f;   // 0.5 * pi/2  [U] ANGULAR_MOTION_THRESHOLD
+        if (fA * dt > kThr) fA = kThr / dt;
+        float sc;
+        if (fA < 0.001f) sc = 0.5f * dt - (dt * dt * dt) * 0.020833333333f * fA * fA;
+        else sc = sinf(0.5f * fA * dt) / fA;
+        float dx = om.x * sc, dy = om.y * sc, dz = om.z * sc, dw = cosf(fA * dt * 0.5f);
+        float qx = bs[3], qy = bs[4], qz = bs[5], qw = bs[6];
+        float nw = dw * qw - dx * qx - dy * qy - dz * qz;
+        float nx = dw * qx + dx * qw + dy * qz - dz * qy;
+        float ny = dw * qy - dx * qz + dy * qw + dz * qx;
+        float nz = dw * qz + dx * qy - dy * qx + dz * qw;
+        float inv = 1.0f / sqrtf(nx * nx + ny * ny + nz * nz + nw * nw);
+        lds_sync();
+        if (lane == 0) {
+            bs[0] += dt * vl.x; bs[1] += dt * vl.y; bs[2] += dt * vl.z;
+            bs[3] = nx * inv; bs[4] = ny * inv; bs[5] = nz * inv; bs[6] = nw * inv;
+            L.fz() = fz;
+        }
+    }
+    lds_sync();
+    // pose of the new state: feeds checkSnakeHeight and the next substep
+    fk_vel<N>(L, M, lane);
+}
+
+// ----------------------------------------------------------------------------------
+// record <-> LDS, observation packing (snake.py:209-217)
+// ----------------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ void load_rec(Lds<N>& L, const float* __restrict__ rec, int lane) {
+#pragma unroll
+    for (int i = lane; i < Lds<N>::REC; i += 64) L.rec[i] = rec[i];
+    lds_sync();
+}
+template <int N>
+__device__ __forceinline__ void store_rec(Lds<N>& L, float* __restrict__ rec, int lane) {
+    lds_sync();
+#pragma unroll
+    for (int i = lane; i < Lds<N>::REC; i += 64) rec[i] = L.rec[i];
+}
+template <int N>
+__device__ __forceinline__ void write_obs(Lds<N>& L, float* __restrict__ obs, int lane) {
+    // obs = [q, qd, tau_motor | pos3 quat4 | fz]; rec = [pos3 quat4 w3 v3 | q qd taum | fz px]
+    for (int i = lane; i < 3 * N + 8; i += 64) {
+        float x;
+        if (i < 3 * N) x = L.rec[13 + i];
+        else if (i < 3 * N + 7) x = L.rec[i - 3 * N];
+        else x = L.rec[13 + 3 * N];
+        obs[i] = x;
+    }
+}
+template <int N>
+__device__ __forceinline__ void soft_reset(Lds<N>& L, int lane) {
+    // snake.py:96-99,119-127: base pose/twist and joint q, qd; motor-torque and sensor caches persist [U]
+    for (int i = lane; i < 13 + 2 * N; i += 64) L.rec[i] = (i == 6) ? 1.0f : 0.0f;
+}
+
+// ----------------------------------------------------------------------------------
+// kernels
+// ----------------------------------------------------------------------------------
+template <int N>
+__global__ __launch_bounds__(64) void env_step_kernel(const DevModel* __restrict__ Mp, float* __restrict__ recs,
+                                                      const float* __restrict__ mu_plane,
+                                                      float* __restrict__ actions, float* __restrict__ obs,
+                                                      float* __restrict__ rew, uint8_t* __restrict__ done,
+                                                      int32_t* __restrict__ substeps, int vec_mode, int n_envs) {
+    extern __shared__ float4 smem_raw[];
+    Lds<N>& L = *reinterpret_cast<Lds<N>*>(smem_raw);
+    const DevModel& M = *Mp;
+    const int env = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (env >= n_envs) return;
+    load_rec<N>(L, recs + (size_t)env * Lds<N>::REC, lane);
+    const int A = M.act_dim;
+    // checkBound (SnakeGymEnv.py:82-88) clips the caller's array in place
+    float act = 0.f;
+    if (lane < A) {
+        act = actions[(size_t)env * A + lane];
+        float cl = fminf(fmaxf(act, -1.0f), 1.0f);
+        if (cl != act) actions[(size_t)env * A + lane] = cl;
+        act = cl;
+    }
+    // createAction (snake.py:247-269) + convertActionToJointCommand (snake.py:223-225)
+    if (lane < N) L.targets[lane] = 0.f;
+    lds_sync();
+    if (lane < A) {
+        int slot = (M.gait == 0) ? 2 * lane : ((M.gait == 1) ? 2 * lane + 1 : lane);
+        L.targets[slot] = act * M.scaling;
+    }
+    lds_sync();
+    float mu = fminf(M.mu_link * mu_plane[env], 10.0f);
+    fk_vel<N>(L, M, lane);
+    // Snake.step servo loop (snake.py:283-304)
+    int counter = 0;
+    bool end_height = false;
+    int it_dummy = 0, nc_dummy = 0;
+    while (true) {
+        float e = (lane < N) ? (L.targets[lane] - L.q()[lane]) : 0.f;
+        float nrm = sqrtf(wave_sum<64>(e * e));
+        if (!(nrm > M.servo_tol)) break;
+        substep<N>(L, M, lane, mu, it_dummy, nc_dummy);
+        counter++;
+        if (mean_height<N>(L, M, lane) > M.height_thr) { end_height = true; break; }
+        if (counter > M.max_counter) break;
+    }
+    // SnakeGymEnv.step (SnakeGymEnv.py:36-42)
+    float en = (lane < N) ? L.qd()[lane] * L.taum()[lane] * M.energy_dt : 0.f;   // snake.py:336-341
+    float energy = wave_sum<64>(en);
+    float x = L.rec[0], y = L.rec[1], fzv = L.fz();
+    float r = M.alpha * (x - L.prev_x()) + (fabsf(fzv) > M.coll_force ? M.coll_pen : 0.f) - M.beta * fabsf(y) -
+              M.gamma * energy;
+    bool dn = fabsf(L.rec[13 + M.term_index]) > M.term_angle;
+    if (!dn) dn = mean_height<N>(L, M, lane) > M.height_thr;
+    if (!dn) dn = end_height;
+    if (dn) r += M.done_pen;
+    float* ob = obs + (size_t)env * (3 * N + 8);
+    if (!(dn && vec_mode)) write_obs<N>(L, ob, lane);
+    lds_sync();
+    if (dn) {
+        soft_reset<N>(L, lane);
+        lds_sync();
+        if (vec_mode) write_obs<N>(L, ob, lane);   // worker returns env.reset()'s obs
+    }
+    lds_sync();
+    if (lane == 0) {
+        // _observation = terminal obs (SnakeGymEnv.py:42); the worker's reset() refreshes it
+        L.prev_x() = (dn && vec_mode) ? 0.0f : x;
+        rew[env] = r;
+        done[env] = dn ? 1 : 0;
+        if (substeps) substeps[env] = counter;
+    }
+    store_rec<N>(L, recs + (size_t)env * Lds<N>::REC, lane);
+}
+
+template <int N>
+__global__ __launch_bounds__(64) void substep_kernel(const DevModel* __restrict__ Mp, float* __restrict__ recs,
+                                                     const float* __restrict__ mu_plane,
+                                                     const float* __restrict__ targets, int k,
+                                                     int32_t* __restrict__ info, int n_envs) {
+    extern __shared__ float4 smem_raw[];
+    Lds<N>& L = *reinterpret_cast<Lds<N>*>(smem_raw);
+    const DevModel& M = *Mp;
+    const int env = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (env >= n_envs) return;
+    load_rec<N>(L, recs + (size_t)env * Lds<N>::REC, lane);
+    if (lane < N) L.targets[lane] = targets[(size_t)env * N + lane];
+    lds_sync();
+    float mu = fminf(M.mu_link * mu_plane[env], 10.0f);
+    fk_vel<N>(L, M, lane);
+    int iters = 0, nc = 0;
+    for (int s = 0; s < k; s++) substep<N>(L, M, lane, mu, iters, nc);
+    if (info && lane == 0) { info[2 * env] = iters; info[2 * env + 1] = nc; }
+    store_rec<N>(L, recs + (size_t)env * Lds<N>::REC, lane);
+}
+
+template <int N>
+__global__ __launch_bounds__(64) void reset_kernel(float* __restrict__ recs, const uint8_t* __restrict__ mask,
+                                                   float* __restrict__ obs, int hard, int n_envs) {
+    extern __shared__ float4 smem_raw[];
+    Lds<N>& L = *reinterpret_cast<Lds<N>*>(smem_raw);
+    const int env = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (env >= n_envs) return;
+    if (mask && !mask[env]) return;
+    load_rec<N>(L, recs + (size_t)env * Lds<N>::REC, lane);
+    soft_reset<N>(L, lane);
+    lds_sync();
+    if (hard) {
+        for (int i = 13 + 2 * N + lane; i < Lds<N>::REC; i += 64) L.rec[i] = 0.f;
+        lds_sync();
+    }
+    if (lane == 0) L.prev_x() = 0.0f;   // _observation = reset obs (SnakeGymEnv.py:30), x = 0
+    lds_sync();
+    if (obs) write_obs<N>(L, obs + (size_t)env * (3 * N + 8), lane);
+    store_rec<N>(L, recs + (size_t)env * Lds<N>::REC, lane);
+}
+
+template <int N>
+__global__ __launch_bounds__(64) void obs_kernel(const DevModel* __restrict__ Mp, const float* __restrict__ recs,
+                                                 float* __restrict__ obs, float* __restrict__ height, int n_envs) {
+    extern __shared__ float4 smem_raw[];
+    Lds<N>& L = *reinterpret_cast<Lds<N>*>(smem_raw);
+    const DevModel& M = *Mp;
+    const int env = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (env >= n_envs) return;
+    load_rec<N>(L, recs + (size_t)env * Lds<N>::REC, lane);
+    if (obs) write_obs<N>(L, obs + (size_t)env * (3 * N + 8), lane);
+    if (height) {
+        fk_vel<N>(L, M, lane);
+        float h = mean_height<N>(L, M, lane);
+        if (lane == 0) height[env] = h;
+    }
+}
+
+// self test of wave_sum / lane_bcast: out[0] = sum32, out[1] = sum64, out[2] = bcast
+__global__ __launch_bounds__(64) void selftest_kernel(float* out) {
+    const int lane = threadIdx.x;
+    float x = (float)(lane + 1);
+    float s32 = wave_sum<32>(lane < 22 ? x : 0.f);
+    float s64 = wave_sum<64>(x);
+    float s64b = wave_sum<64>(lane < 38 ? x * 0.5f : 0.f);
+    float b = lane_bcast(x, 17);
+    if (lane == 5) { out[0] = s32; out[1] = s64; out[2] = b; out[3] = s64b; }
+}
+
+}  // namespace snk

@@ -1,0 +1,147 @@
+/*
+ * snk.h -- C ABI of the MI355X batched snake stepper (libsnk.so).
+ *
+ * Drop-in boundary for ONE path of vinits5/bullet-envs: SnakeGymEnv.step()/reset(),
+ * whose arithmetic the reference delegates to pybullet.stepSimulation on the CPU.
+ * Everything here is plain C: pointers, sizes, int status codes; no torch types.
+ * Paths cited below are under /root/reference.
+ *
+ * One handle = N independent environments resident on one GPU.  Calls on a handle
+ * are serialised by the caller (the reference is single-threaded per env process,
+ * multiprocessing_env.py:7-29).  Functions return 0 on success, non-zero on error;
+ * snk_last_error() gives the message.  No exceptions cross this boundary.
+ */
+#ifndef SNK_H
+#define SNK_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Every knob the reference path depends on.  [U] = PyBullet/Bullet default taken from
+ * knowledge of bullet3 (not verifiable here). */
+typedef struct snk_params {
+    /* model: snake/snake.urdf (constants generated parametrically, not parsed) */
+    int32_t n_modules;          /* 16 = snake.urdf; 32 = BASELINE config 4 (8 <= n <= 32, even) */
+    int32_t inertia_from_file;  /* 0: inertia from collision AABB [U] (snake.py:93 passes no
+                                   URDF_USE_INERTIA_FROM_FILE); 1: urdf:815,871 values       */
+    double  default_mass;       /* links without <inertial> (urdf:7,14,818): mass 1 [U]       */
+    double  collision_margin;   /* 0.001 [U]                                                  */
+    /* pybullet world */
+    double  dt;                 /* 1/240 [U]: setTimeSteps is never called (snake.py:271-272) */
+    double  gravity_z;          /* snake.py:8,91   -9.8                                       */
+    double  lin_damping;        /* 0.04 [U]                                                   */
+    double  ang_damping;        /* 0.04 [U]                                                   */
+    double  joint_damping;      /* snake.urdf:838  0.1                                        */
+    double  max_coord_vel;      /* 100 [U]                                                    */
+    /* setJointMotorControlArray(POSITION_CONTROL) defaults, snake.py:219-221 */
+    double  kp;                 /* 0.1 [U]                                                    */
+    double  kd;                 /* 1.0 [U]                                                    */
+    double  max_motor_impulse;  /* forces=[inf] (snake.py:26-27) -> +inf                      */
+    double  joint_lo, joint_hi; /* snake.urdf:839  -1.57, 1.57                                */
+    double  limit_erp;          /* 0.2 [U]                                                    */
+    double  limit_max_impulse;  /* 100 [U]                                                    */
+    /* changeDynamics, snake.py:103-107 */
+    double  mu_link;            /* lateralFriction = 2                                        */
+    double  aniso[3];           /* anisotropicFriction = [1, 0.1, 0.01] (snake.py:25)         */
+    double  contact_erp;        /* 0.08 [U]                                                   */
+    double  linear_slop;        /* 1e-5 [U]                                                   */
+    double  breaking_threshold; /* 0.02 [U]                                                   */
+    int32_t cone_friction;      /* 1 [U]                                                      */
+    int32_t n_iterations;       /* 50 [U]                                                     */
+    double  residual_threshold; /* 1e-7 [U]; 0 disables the early exit                        */
+    /* Snake / SnakeGymEnv */
+    double  scaling_factor;     /* snake.py:63   pi/6                                         */
+    int32_t gait;               /* snake.py:62   1: actions drive odd motor slots             */
+    double  servo_tol;          /* snake.py:232  0.05                                         */
+    int32_t max_counter;        /* snake.py:303  40  (=> at most 41 substeps)                 */
+    double  height_threshold;   /* snake.py:238  0.1                                          */
+    double  energy_dt;          /* snake.py:9,339  1/100                                      */
+    double  alpha, beta, gamma; /* SnakeGymEnv.py:14-16  1, 0.01, 0.1                         */
+    double  term_angle;         /* SnakeGymEnv.py:100  0.5                                    */
+    int32_t term_index;         /* SnakeGymEnv.py:100  obs index 9                            */
+    double  collision_force;    /* SnakeGymEnv.py:94   10                                     */
+    double  collision_penalty;  /* SnakeGymEnv.py:94   -10                                    */
+    double  done_penalty;       /* SnakeGymEnv.py:40   -5                                     */
+} snk_params;
+
+typedef struct snk_handle snk_handle;
+
+/* Fills the reference's defaults (Snake.defaultParams snake.py:55-63, SnakeGymEnv.py:13-17). */
+void snk_default_params(snk_params* p);
+
+/* Replaces: Snake.__init__ + SnakeGymEnv.__init__ -> robot.reset(hardReset=True)
+ * (snake.py:14-32,88-95; SnakeGymEnv.py:5-26) for n_envs worlds at once, and the N worker
+ * processes of SubprocVecEnv.__init__ (ppo/multiprocessing_env.py:97-117).
+ * device = HIP device ordinal.  State after create = hard reset. */
+int snk_create(const snk_params* p, int32_t n_envs, int32_t device, snk_handle** out);
+int snk_destroy(snk_handle* h);
+
+int32_t snk_num_envs(const snk_handle* h);
+int32_t snk_obs_dim(const snk_handle* h);    /* 3n+8  (snake.py:163-164)            */
+int32_t snk_act_dim(const snk_handle* h);    /* n/2 for gait 0/1 (SnakeGymEnv.py:74-76) */
+int32_t snk_state_dim(const snk_handle* h);  /* 13+2n: pos3 quat_xyzw4 omega3 vel3 q qd */
+int32_t snk_record_floats(const snk_handle* h); /* floats per env in the HBM state record */
+
+/* Replaces SnakeGymEnv.reset() (SnakeGymEnv.py:28-31 -> snake.py:96-99,119-127) for every
+ * env whose mask byte is non-zero (mask == NULL: all).  obs_dev [n_envs x obs_dim] f32,
+ * device pointer; rows of unmasked envs are left untouched.  stream = hipStream_t or NULL. */
+int snk_reset(snk_handle* h, const uint8_t* mask_dev, float* obs_dev, void* stream);
+
+/* Replaces SubprocVecEnv.step (ppo/multiprocessing_env.py:119-128) = per env
+ * SnakeGymEnv.step (SnakeGymEnv.py:33-50) -> Snake.step (snake.py:274-306) with its
+ * 0..41 stepSimulation calls, reward, termination, -5 and auto-reset.
+ *   actions_dev  [n_envs x act_dim] f32, device; clipped to [-1,1] IN PLACE like
+ *                checkBound (SnakeGymEnv.py:82-88)
+ *   obs_dev      [n_envs x obs_dim] f32   rew_dev [n_envs] f32   done_dev [n_envs] u8
+ *   substeps_dev [n_envs] i32 (may be NULL): Snake.counter
+ *   vec_mode     1: worker semantics, obs of a done env is the post-reset one
+ *                (multiprocessing_env.py:13-15); 0: SnakeGymEnv.step semantics, terminal obs
+ * Asynchronous on `stream`; results are ready after the stream is synchronised. */
+int snk_step(snk_handle* h, float* actions_dev, float* obs_dev, float* rew_dev,
+             uint8_t* done_dev, int32_t* substeps_dev, int32_t vec_mode, void* stream);
+
+/* Host-buffer convenience forms (upload, run, download, synchronise). */
+int snk_reset_host(snk_handle* h, const uint8_t* mask, float* obs);
+int snk_step_host(snk_handle* h, float* actions, float* obs, float* rew, uint8_t* done,
+                  int32_t* substeps, int32_t vec_mode);
+
+/* Replaces pybullet.stepSimulation (snake.py:286) preceded by setJointMotorControlArray
+ * (snake.py:221): k physics substeps with motor targets [n_envs x n] (radians), host buffer.
+ * info (may be NULL) [n_envs x 2] i32: solver iterations and contact count of the last substep.
+ * For single-substep parity tests. */
+int snk_substep_host(snk_handle* h, const float* targets, int32_t k, int32_t* info);
+
+/* State access (host buffers), for parity tests and checkpointing.
+ * state [n_envs x state_dim]; aux [n_envs x (n+2)] = motor torques n, joint-0 Fz, prev obs x. */
+int snk_get_state(snk_handle* h, float* state, float* aux);
+int snk_set_state(snk_handle* h, const float* state, const float* aux);
+/* getObservation (snake.py:209-217) of every env, host buffer [n_envs x obs_dim]. */
+int snk_get_obs(snk_handle* h, float* obs);
+/* checkSnakeHeight's mean z (snake.py:237-245), host buffer [n_envs]. */
+int snk_mean_height(snk_handle* h, float* out);
+
+/* BASELINE config 5: per-env lateral friction of the ground plane (reference: plane.urdf = 1). */
+int snk_set_ground_friction(snk_handle* h, const float* mu /* host [n_envs] */);
+
+/* Device-side self test of the wave primitives (DPP reductions); 0 = pass. */
+int snk_selftest(int32_t device);
+
+/* Dominant-kernel timing: mean duration in ms of the last `count` snk_step launches,
+ * measured with HIP events on the launch stream (enable first; adds two event records
+ * per step). */
+int snk_timing_enable(snk_handle* h, int32_t on);
+int snk_timing_read(snk_handle* h, double* mean_ms, int32_t* count);
+
+/* Merged-model introspection for tests: per composite body [mass, com3, I_origin6] and
+ * rest-pose world origins.  out_bodies [(n+1) x 10], out_origins [(n+1) x 3] (host). */
+int snk_model_describe(const snk_handle* h, double* out_bodies, double* out_origins);
+
+const char* snk_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,98 @@
+"""GPU parity tests: the HIP path (through the C ABI, host-buffer forms) against the CPU
+oracle on the same seeded inputs.  Run with `-m gpu` on an MI355X.
+
+Tolerances (float32 GPU vs float64 oracle, same algorithm, different formulation):
+  single substep, free flight (no contacts):        |dq| <= 2e-6,  |dqd| <= 2e-4 * (1 + |qd|)
+  single substep, on the ground (<= 64 contacts):   |dq| <= 2e-4,  |dqd| <= 2e-2 * (1 + |qd|)
+The ground tolerance is float32 round-off through the 16-joint articulated chain and 50
+unconverged Gauss-Seidel sweeps over ~200 rows: the oracle itself compiled in float32
+(liboracle32.so) differs from the float64 oracle by 1.5e-4 / 1.2e-2 on the same inputs, and
+the test also requires the GPU to be no worse than twice that.
+"""
+import numpy as np
+import pytest
+
+from conftest import random_state
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(pkg, oracle_mod, n_envs, n=16, **over):
+    st = pkg.Stepper(n_envs, device=0, n_modules=n, **over)
+    orcs = [oracle_mod.OracleEnv(n_modules=n, **over) for _ in range(n_envs)]
+    return st, orcs
+
+
+def test_wave_primitives(pkg):
+    lib = pkg.load()
+    rc = lib.snk_selftest(0)
+    assert rc == 0, lib.snk_last_error().decode()
+
+
+def test_model_matches_oracle_rest_pose(pkg, oracle_mod):
+    st = pkg.Stepper(1)
+    bodies, origins = st.model_describe()
+    e = oracle_mod.OracleEnv()
+    inert = e.link_inertials()
+    assert abs(bodies[:, 0].sum() - inert[:, 0].sum()) < 1e-12
+    _, org = e.joint_axes_world()
+    assert np.allclose(origins[1:], org, atol=1e-12)
+    assert abs(st.mean_height()[0] - 0.026) < 1e-6
+
+
+@pytest.mark.parametrize("case", ["air", "ground"])
+def test_single_substep_parity(pkg, oracle_mod, case):
+    n, B = 16, 64
+    rng = np.random.default_rng(123 if case == "air" else 321)
+    over = dict(residual_threshold=0.0)
+    st, orcs = _mk(pkg, oracle_mod, B, **over)
+    S = np.zeros((B, 13 + 2 * n))
+    for i in range(B):
+        if case == "air":
+            S[i] = random_state(rng, n, z=1.0, qamp=0.5, vamp=0.5)
+        else:
+            S[i] = random_state(rng, n, z=0.026, qamp=0.3, vamp=0.3, flat=True)
+            S[i, 9] *= 0.1
+            S[i, 7:9] *= 0.1
+    S32 = S.astype(np.float32)
+    T = rng.uniform(-0.5, 0.5, (B, n)).astype(np.float32)
+    st.set_state(S32)
+    info = st.substep(T, 1)
+    G, Gaux = st.get_state()
+    err_q, err_v = 0.0, 0.0
+    for i in range(B):
+        o = orcs[i]
+        o.set_state(S32[i].astype(np.float64))
+        o.substep(T[i].astype(np.float64))
+        ref = o.get_state()
+        tau, fz, _ = o.get_aux()
+        assert info[i, 1] == o.last_num_contacts
+        assert info[i, 0] == o.last_iterations
+        dq = np.abs(G[i, :13 + n] - ref[:13 + n])
+        dv = np.abs(G[i, 13 + n:] - ref[13 + n:]) / (1.0 + np.abs(ref[13 + n:]))
+        dw = np.abs(G[i, 7:13] - ref[7:13]) / (1.0 + np.abs(ref[7:13]))
+        err_q = max(err_q, dq[:7].max(), dq[13:].max())
+        err_v = max(err_v, dv.max(), dw.max())
+        # motor torque and joint-0 force sensor
+        # (impulse/dt: a 240x amplification of the solver's float32 round-off)
+        assert np.abs(Gaux[i, :n] - tau).max() < 2e-3 * (1.0 + np.abs(tau).max())
+        assert abs(Gaux[i, n] - fz) < 5e-3 * (1 + abs(fz))
+    # calibration: float32 build of the oracle against the float64 one, same inputs
+    o32 = oracle_mod.OracleEnv(f32=True, n_modules=n, **over)
+    cq, cv = 0.0, 0.0
+    for i in range(B):
+        o = orcs[i]
+        o.set_state(S32[i].astype(np.float64))
+        o32.set_state(S32[i].astype(np.float64))
+        o.substep(T[i].astype(np.float64))
+        o32.substep(T[i].astype(np.float64))
+        ra, rb = o.get_state(), o32.get_state()
+        cq = max(cq, np.abs(ra[:7] - rb[:7]).max(), np.abs(ra[13:13 + n] - rb[13:13 + n]).max())
+        cv = max(cv, (np.abs(ra[13 + n:] - rb[13 + n:]) / (1 + np.abs(ra[13 + n:]))).max(),
+                 (np.abs(ra[7:13] - rb[7:13]) / (1 + np.abs(ra[7:13]))).max())
+    print("case", case, "GPU-f32 vs oracle-f64: max |dq|", err_q, "max rel |dqd|", err_v,
+          "| oracle-f32 vs oracle-f64:", cq, cv)
+    tol_q, tol_v = (2e-6, 2e-4) if case == "air" else (2e-4, 2e-2)
+    assert err_q < tol_q
+    assert err_v < tol_v
+    assert err_q < 2 * cq + 1e-6 and err_v < 2 * cv + 1e-5
