@@ -1,7 +1,10 @@
 """bullet-envs_amd -- MI355X-native batched stepper for the SnakeGymEnv step/reset path.
 
-Import through importlib (the directory name carries the reference's hyphen):
+The directory name carries the reference's hyphen, so import it through importlib
     pkg = importlib.import_module("bullet-envs_amd")
-or use the top-level shim `import bullet_envs_amd`.
+or through the top-level shim:  import bullet_envs_amd as pkg
 """
 from ._lib import SnkParams, Stepper, default_params, load, LIB_PATH  # noqa: F401
+from .snake_env import (Snake, SnakeGymEnv, SnakeVecEnv, SubprocVecEnv, VecEnv,  # noqa: F401
+                        params_from_args)
+from .device_env import DeviceVecEnv, ShardedVecEnv  # noqa: F401

@@ -81,6 +81,14 @@ def load():
         raise RuntimeError(
             "bullet-envs_amd: %s is missing -- build it with `python bullet-envs_amd/build.py` "
             "(hipcc, gfx950).  There is no CPU fallback." % LIB_PATH)
+    # PyTorch-ROCm wheels bundle their own HIP/HSA runtime (same SONAME libamdhip64.so.7 as
+    # /opt/rocm's).  Two HSA runtimes cannot share a GPU in one process, so when torch is
+    # installed it is imported FIRST: libsnk.so's NEEDED entry then binds to the copy torch
+    # already mapped and the process has exactly one runtime.  Without torch, /opt/rocm's is used.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     try:
         lib = C.CDLL(LIB_PATH)
     except OSError as e:
@@ -224,8 +232,8 @@ class Stepper:
     def reset_device(self, mask_ptr=0, obs_ptr=0, stream=0):
         check(self.lib.snk_reset(self.h, mask_ptr or None, obs_ptr or None, stream or None), "snk_reset")
 
-    def timing_enable(self, on=True):
-        check(self.lib.snk_timing_enable(self.h, 1 if on else 0), "snk_timing_enable")
+    def timing_enable(self, capacity):
+        check(self.lib.snk_timing_enable(self.h, int(capacity)), "snk_timing_enable")
 
     def timing_read(self):
         ms = C.c_double()

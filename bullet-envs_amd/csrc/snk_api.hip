@@ -49,12 +49,9 @@ struct snk_handle {
     int32_t* d_info = nullptr;
     float* d_h = nullptr;
     size_t lds_bytes = 0;
-    // timing
-    bool timing = false;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    double t_sum_ms = 0;
-    int t_count = 0;
-    bool ev_pending = false;
+    // timing: pool of event pairs, one pair per snk_step launch, read back in one go
+    std::vector<hipEvent_t> ev;
+    int ev_used = 0;
 };
 
 namespace {
@@ -191,8 +188,6 @@ int snk_create(const snk_params* p, int32_t n_envs, int32_t device, snk_handle**
     HIP_TRY(hipMalloc(&h->d_tgt, ne * h->n * sizeof(float)));
     HIP_TRY(hipMalloc(&h->d_info, ne * 2 * sizeof(int32_t)));
     HIP_TRY(hipMalloc(&h->d_h, ne * sizeof(float)));
-    HIP_TRY(hipEventCreate(&h->ev0));
-    HIP_TRY(hipEventCreate(&h->ev1));
     // hard reset (snake.py:88-95)
     SNK_DISPATCH(h, launch_reset<16>(h, nullptr, nullptr, 1, nullptr), launch_reset<32>(h, nullptr, nullptr, 1, nullptr));
     if (check_launch()) { return 1; }
@@ -208,8 +203,7 @@ int snk_destroy(snk_handle* h) {
     void* bufs[] = {h->d_model, h->d_recs, h->d_mu, h->d_act, h->d_obs, h->d_rew, h->d_done,
                     h->d_sub, h->d_mask, h->d_tgt, h->d_info, h->d_h};
     for (void* b : bufs) (void)hipFree(b);
-    if (h->ev0) (void)hipEventDestroy(h->ev0);
-    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
     delete h;
     return 0;
 }
@@ -228,49 +222,49 @@ int snk_reset(snk_handle* h, const uint8_t* mask_dev, float* obs_dev, void* stre
     return check_launch();
 }
 
-static void timing_collect(snk_handle* h) {
-    if (h->ev_pending) {
-        float ms = 0.f;
-        if (hipEventSynchronize(h->ev1) == hipSuccess && hipEventElapsedTime(&ms, h->ev0, h->ev1) == hipSuccess) {
-            h->t_sum_ms += ms;
-            h->t_count++;
-        }
-        h->ev_pending = false;
-    }
-}
-
 int snk_step(snk_handle* h, float* actions_dev, float* obs_dev, float* rew_dev, uint8_t* done_dev,
              int32_t* substeps_dev, int32_t vec_mode, void* stream) {
     if (!h) return fail("snk_step: null handle");
     if (!actions_dev || !obs_dev || !rew_dev || !done_dev) return fail("snk_step: null buffer");
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t st = (hipStream_t)stream;
-    if (h->timing) {
-        timing_collect(h);
-        HIP_TRY(hipEventRecord(h->ev0, st));
-    }
+    const bool timed = 2 * h->ev_used + 1 < (int)h->ev.size();
+    if (timed) HIP_TRY(hipEventRecord(h->ev[2 * h->ev_used], st));
     SNK_DISPATCH(h, launch_step<16>(h, actions_dev, obs_dev, rew_dev, done_dev, substeps_dev, vec_mode, st),
                  launch_step<32>(h, actions_dev, obs_dev, rew_dev, done_dev, substeps_dev, vec_mode, st));
-    if (h->timing) {
-        HIP_TRY(hipEventRecord(h->ev1, st));
-        h->ev_pending = true;
+    if (timed) {
+        HIP_TRY(hipEventRecord(h->ev[2 * h->ev_used + 1], st));
+        h->ev_used++;
     }
     return check_launch();
 }
 
-int snk_timing_enable(snk_handle* h, int32_t on) {
+int snk_timing_enable(snk_handle* h, int32_t capacity) {
     if (!h) return fail("null handle");
-    timing_collect(h);
-    h->timing = on != 0;
-    h->t_sum_ms = 0;
-    h->t_count = 0;
+    HIP_TRY(hipSetDevice(h->device));
+    for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
+    h->ev.clear();
+    h->ev_used = 0;
+    for (int i = 0; i < 2 * capacity; i++) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreate(&e));
+        h->ev.push_back(e);
+    }
     return 0;
 }
 int snk_timing_read(snk_handle* h, double* mean_ms, int32_t* count) {
     if (!h) return fail("null handle");
-    timing_collect(h);
-    if (mean_ms) *mean_ms = h->t_count ? h->t_sum_ms / h->t_count : 0.0;
-    if (count) *count = h->t_count;
+    HIP_TRY(hipSetDevice(h->device));
+    double sum = 0;
+    for (int i = 0; i < h->ev_used; i++) {
+        float ms = 0.f;
+        HIP_TRY(hipEventSynchronize(h->ev[2 * i + 1]));
+        HIP_TRY(hipEventElapsedTime(&ms, h->ev[2 * i], h->ev[2 * i + 1]));
+        sum += ms;
+    }
+    if (mean_ms) *mean_ms = h->ev_used ? sum / h->ev_used : 0.0;
+    if (count) *count = h->ev_used;
+    h->ev_used = 0;
     return 0;
 }
 

@@ -129,10 +129,11 @@ int snk_set_ground_friction(snk_handle* h, const float* mu /* host [n_envs] */);
 /* Device-side self test of the wave primitives (DPP reductions); 0 = pass. */
 int snk_selftest(int32_t device);
 
-/* Dominant-kernel timing: mean duration in ms of the last `count` snk_step launches,
- * measured with HIP events on the launch stream (enable first; adds two event records
- * per step). */
-int snk_timing_enable(snk_handle* h, int32_t on);
+/* Dominant-kernel timing with HIP events on the launch stream: enable(capacity) arms a pool
+ * of `capacity` event pairs (0 disarms); each following snk_step launch is bracketed by one
+ * pair, without any host synchronisation; read() waits for them, returns the mean launch
+ * duration in ms and how many launches it covers, and re-arms the pool. */
+int snk_timing_enable(snk_handle* h, int32_t capacity);
 int snk_timing_read(snk_handle* h, double* mean_ms, int32_t* count);
 
 /* Merged-model introspection for tests: per composite body [mass, com3, I_origin6] and

@@ -1,0 +1,98 @@
+"""World-size-2 test of the sharded vector env on CPU (gloo).  The per-rank stepper is a
+test double backed by the CPU oracle, so this exercises exactly the product's sharding /
+scatter / gather plumbing (bullet-envs_amd/device_env.py:ShardedVecEnv), which on the GPU box
+runs over RCCL."""
+import importlib
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+E, STEPS = 2, 3
+
+
+class OracleLocalEnv:
+    """DeviceVecEnv look-alike on the CPU: E oracle envs, torch CPU tensors."""
+
+    def __init__(self, ids):
+        import torch
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle as orc
+        self.torch = torch
+        self.envs = [orc.OracleEnv() for _ in ids]
+        self.num_envs, self.obs_dim, self.act_dim = len(ids), 56, 8
+        self.device = torch.device("cpu")
+
+    def reset(self):
+        return self.torch.tensor(np.stack([e.reset() for e in self.envs]), dtype=self.torch.float32)
+
+    def step(self, actions):
+        o, r, d = [], [], []
+        for e, a in zip(self.envs, actions.numpy()):
+            oo, rr, dd, _, _ = e.env_step(a.astype(np.float64), vec_mode=True)
+            o.append(oo); r.append(rr); d.append(dd)
+        t = self.torch
+        return (t.tensor(np.stack(o), dtype=t.float32), t.tensor(r, dtype=t.float32),
+                t.tensor(d, dtype=t.uint8))
+
+
+def _actions(j, n):
+    k = np.arange(8)
+    return (-np.sin((2 * k[None, :] + 1) * 4.0 + 0.2 * j + 0.7 * np.arange(n)[:, None])).astype(np.float32)
+
+
+def _worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = importlib.import_module("bullet-envs_amd")
+    local = OracleLocalEnv(list(range(rank * E, (rank + 1) * E)))
+    env = pkg.ShardedVecEnv(local, root=0)
+    assert env.num_envs == world * E and len(env) == world * E
+    assert env.shard_slice() == slice(rank * E, (rank + 1) * E)
+    res = {}
+    obs0 = env.reset()
+    if rank == 0:
+        res["reset"] = obs0.numpy().copy()
+    else:
+        assert obs0 is None
+    for j in range(STEPS):
+        out = env.step(_actions(j, world * E) if rank == 0 else None)
+        if rank == 0:
+            obs, rew, done, infos = out
+            assert len(infos) == world * E and obs.shape == (world * E, 56)
+            res["obs%d" % j] = obs.numpy().copy()
+            res["rew%d" % j] = rew.numpy().copy()
+            res["done%d" % j] = done.numpy().copy()
+        else:
+            assert out[0] is None
+    if rank == 0:
+        np.savez(out_path, **res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_env_world2_gloo(tmp_path, oracle_mod):
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out_path = str(tmp_path / "sharded.npz")
+    mp.spawn(_worker, args=(2, port, out_path), nprocs=2, join=True)
+    got = np.load(out_path)
+    # the same 4 envs stepped directly, unsharded
+    ref = [oracle_mod.OracleEnv() for _ in range(2 * E)]
+    assert np.allclose(got["reset"], np.stack([e.reset() for e in ref]))
+    for j in range(STEPS):
+        a = _actions(j, 2 * E)
+        for i, e in enumerate(ref):
+            o, r, d, _, _ = e.env_step(a[i].astype(np.float64), vec_mode=True)
+            assert np.allclose(got["obs%d" % j][i], o.astype(np.float32))
+            assert abs(got["rew%d" % j][i] - r) < 1e-6
+            assert bool(got["done%d" % j][i]) == d

