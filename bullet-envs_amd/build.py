@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsnk.so")
-SOURCES = ["snk_api.hip", "snk_device.hpp", "snk_model.hpp"]
+SOURCES = ["snk_api.hip", "snk_device.hpp", "snk_pgs_v2.hpp", "snk_model.hpp"]
 HEADER = os.path.join(os.path.dirname(HERE), "include", "snk.h")
 
 
@@ -28,7 +28,7 @@ def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-shared", "-fPIC",
            os.path.join(CSRC, "snk_api.hip"), "-o", LIB]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")

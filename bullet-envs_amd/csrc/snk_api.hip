@@ -168,7 +168,7 @@ int snk_create(const snk_params* p, int32_t n_envs, int32_t device, snk_handle**
     snk::build_host_model(*p, h->H);
     snk::build_dev_model(*p, h->H, h->D);
     h->rec = h->D.rec_floats;
-    h->lds_bytes = h->n == 16 ? sizeof(snk::Lds<16>) : sizeof(snk::Lds<32>);
+    h->lds_bytes = h->n == 16 ? sizeof(snk::Lds<16, true>) : sizeof(snk::Lds<32, false>);
     int rc = h->n == 16 ? set_lds_attr<16>(h->lds_bytes) : set_lds_attr<32>(h->lds_bytes);
     if (rc) { delete h; return rc; }
     const size_t ne = (size_t)n_envs;
@@ -374,12 +374,28 @@ int snk_selftest(int32_t device) {
     if (device < 0 || device >= ndev) return fail("snk_selftest: no such HIP device");
     HIP_TRY(hipSetDevice(device));
     float* d = nullptr;
-    HIP_TRY(hipMalloc(&d, 4 * sizeof(float)));
+    HIP_TRY(hipMalloc(&d, 136 * sizeof(float)));
     hipLaunchKernelGGL(snk::selftest_kernel, dim3(1), dim3(64), 0, nullptr, d);
     if (check_launch()) return 1;
-    float o[4];
+    float o[136];
     HIP_TRY(hipMemcpy(o, d, sizeof(o), hipMemcpyDeviceToHost));
     (void)hipFree(d);
+    if (o[4] != 32.f * 33.f / 2.f || o[5] != (64.f * 65.f - 32.f * 33.f) / 2.f) {
+        char buf[120];
+        snprintf(buf, sizeof(buf), "selftest mismatch: half_reduce lower=%g upper=%g", o[4], o[5]);
+        return fail(buf);
+    }
+    for (int l = 0; l < 64; l++) {
+        // half_swap(x, y): a = [x.lo, y.lo], b = [x.hi, y.hi]
+        float wa = l < 32 ? (float)(l + 1) : 100.f * (float)(l - 32 + 1);
+        float wb = l < 32 ? (float)(l + 32 + 1) : 100.f * (float)(l + 1);
+        if (o[8 + l] != wa || o[72 + l] != wb) {
+            char buf[160];
+            snprintf(buf, sizeof(buf), "selftest mismatch: half_swap lane %d a=%g (want %g) b=%g (want %g)", l, o[8 + l], wa,
+                     o[72 + l], wb);
+            return fail(buf);
+        }
+    }
     const float s22 = 22.f * 23.f / 2.f, s64 = 64.f * 65.f / 2.f, s38 = 38.f * 39.f / 4.f;
     if (o[0] != s22 || o[1] != s64 || o[2] != 18.f || o[3] != s38) {
         char buf[160];

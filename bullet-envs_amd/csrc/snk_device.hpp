@@ -104,7 +104,8 @@ __device__ __forceinline__ float lane_bcast(float x, int src_lane_uniform) {
 // LDS image of one environment
 // ----------------------------------------------------------------------------------
 template <int N>
-struct Lds {
+struct LdsCommon {
+    static constexpr int kN = N;
     static constexpr int NB = N + 1;     // composite bodies
     static constexpr int ND = N + 6;     // generalized velocity [omega_w, v_w, qd]
     static constexpr int NC = 4 * N;     // contact slots: 2n cylinders x 2 end caps
@@ -120,15 +121,10 @@ struct Lds {
     float Inv0[36];
     float qd_old[N], tauj[N], qdd[N], targets[N];
     float acc0[6];
-    // contacts
-    float cP[NC][3], cdist[NC], cdA[NC][3], cdB[NC][3];
-    int clist[NC];
-    // constraint rows
-    float Mm[N][ND];             // M^-1 e_j for the motor / limit rows
-    float Jc[NR][ND], Mc[NR][ND];
-    float c_rhs[NR], c_dinv[NR], c_den[NR], c_app[NR];
+    // non-contact rows kept in LDS: in v1 limits + motors, in v2 only the (rare) limit rows
     int nc_joint[2 * N];
     float nc_sign[2 * N], nc_rhs[2 * N], nc_dinv[2 * N], nc_den[2 * N], nc_lo[2 * N], nc_hi[2 * N], nc_app[2 * N];
+    float Mm[N][ND];             // M^-1 e_j for the motor / limit rows
 
     __device__ __forceinline__ float* base() { return rec; }
     __device__ __forceinline__ float* q() { return rec + 13; }
@@ -138,14 +134,43 @@ struct Lds {
     __device__ __forceinline__ float& prev_x() { return rec[14 + 3 * N]; }
 };
 
+template <int N, bool V2>
+struct Lds;
+
+// v1: every constraint row staged in LDS (any chain length; used for the 32-link config)
+template <int N>
+struct Lds<N, false> : LdsCommon<N> {
+    static constexpr bool kV2 = false;
+    static constexpr int NC = 4 * N, NR = 12 * N, ND = N + 6;
+    float cP[NC][3], cdist[NC], cdA[NC][3], cdB[NC][3];   // indexed by contact slot
+    int clist[NC];
+    float Jc[NR][ND], Mc[NR][ND];
+    float c_rhs[NR], c_dinv[NR], c_den[NR], c_app[NR];
+};
+
+// v2: rows live in VGPRs during the solve; LDS only stages one 64-row batch while they are built
+template <int N>
+struct Lds<N, true> : LdsCommon<N> {
+    static constexpr bool kV2 = true;
+    static constexpr int NC = 4 * N, ND = N + 6;
+    static_assert(N + 6 + 3 <= 32, "v2 packs two rows per 64-lane register");
+    float ccP[NC][3], ccdist[NC], ccdir[NC][2][3];        // indexed by COMPACT contact index
+    int ccbody[NC];
+    float stM[64][25];           // staging of one 64-row batch: M^-1 J^T [22], rhs, den, 1/den
+    float MmS[N][3];             // the motors' rhs, den, 1/den (their M^-1 rows are Mm)
+    float fz_park;               // first-pass part of the joint-0 force, parked across the solve
+    float app[2 * (N / 2 + NC / 2 + NC)];   // accumulated impulses by (register slot, half)
+};
+
 __device__ __forceinline__ void lds_sync() { __syncthreads(); }
 
 // ----------------------------------------------------------------------------------
 // S1: forward kinematics + link velocities of the chain (serial recurrence, evaluated
 // uniformly by the wave; lane 0 stores)
 // ----------------------------------------------------------------------------------
-template <int N>
-__device__ void fk_vel(Lds<N>& L, const DevModel& M, int lane) {
+template <class LT>
+__device__ void fk_vel(LT& L, const DevModel& M, int lane) {
+    constexpr int N = LT::kN;
     const float* bs = L.base();
     float qx = bs[3], qy = bs[4], qz = bs[5], qw = bs[6];
     float dd = qx * qx + qy * qy + qz * qz + qw * qw;
@@ -202,8 +227,9 @@ __device__ void fk_vel(Lds<N>& L, const DevModel& M, int lane) {
 }
 
 // checkSnakeHeight's mean z over {`base` link COM, OUTPUT_BODY origins} (snake.py:237-245)
-template <int N>
-__device__ float mean_height(Lds<N>& L, const DevModel& M, int lane) {
+template <class LT>
+__device__ float mean_height(LT& L, const DevModel& M, int lane) {
+    constexpr int N = LT::kN;
     float z = 0.f;
     if (lane == 0) z = L.o[0][2] + L.R[0][6] * M.hbase[0] + L.R[0][7] * M.hbase[1] + L.R[0][8] * M.hbase[2];
     else if (lane <= N) z = L.o[lane][2];
@@ -213,8 +239,9 @@ __device__ float mean_height(Lds<N>& L, const DevModel& M, int lane) {
 // ----------------------------------------------------------------------------------
 // S2: per-body bias forces (lane = body): p_b = [w x I w ; m w x (w x c)] - external
 // ----------------------------------------------------------------------------------
-template <int N, bool FIRST>
-__device__ void body_bias(Lds<N>& L, const DevModel& M, int lane) {
+template <class LT, bool FIRST>
+__device__ void body_bias(LT& L, const DevModel& M, int lane) {
+    constexpr int N = LT::kN;
     if (lane <= N) {
         const int b = lane;
         const float* R = L.R[b];
@@ -268,8 +295,9 @@ __device__ void body_bias(Lds<N>& L, const DevModel& M, int lane) {
 // breaking threshold [U].  Friction directions (0,-1,0),(1,0,0) scaled anisotropically in
 // the cylinder link's axes: d' = Rc diag(aniso) Rc^T d  (snake.py:104-106).
 // ----------------------------------------------------------------------------------
-template <int N>
-__device__ int find_contacts(Lds<N>& L, const DevModel& M, int lane) {
+template <class LT>
+__device__ int find_contacts_v1(LT& L, const DevModel& M, int lane) {
+    constexpr int N = LT::kN;
     int total = 0;
     for (int base = 0; base < 4 * N; base += 64) {
         const int slot = base + lane;
@@ -316,8 +344,9 @@ __device__ int find_contacts(Lds<N>& L, const DevModel& M, int lane) {
 // S3: ABA sweeps, evaluated uniformly by the wave (serial recurrence over the chain).
 // FACTOR: also builds the articulated inertias IA, U = IA S, D = S^T U and the base inverse.
 // ----------------------------------------------------------------------------------
-template <int N, bool FACTOR>
-__device__ void aba_main(Lds<N>& L, const DevModel& M, int lane) {
+template <class LT, bool FACTOR>
+__device__ void aba_main(LT& L, const DevModel& M, int lane) {
+    constexpr int N = LT::kN;
     float cA[6], cB[9], cC[6];   // child contribution to the parent's articulated inertia
 #pragma unroll
     for (int i = 0; i < 6; i++) { cA[i] = 0.f; cC[i] = 0.f; }
@@ -499,8 +528,9 @@ __device__ void aba_main(Lds<N>& L, const DevModel& M, int lane) {
 // (generalized) impulse -> M^-1 J^T, and builds J, the diagonal and the right-hand side
 // (btMultiBodyConstraintSolver::setupMultiBodyContactConstraint / btMultiBodyJointMotor [U]).
 // ----------------------------------------------------------------------------------
-template <int N>
-__device__ void build_rows(Lds<N>& L, const DevModel& M, int lane, int nc, int& n_noncontact) {
+template <class LT>
+__device__ void build_rows_v1(LT& L, const DevModel& M, int lane, int nc, int& n_noncontact) {
+    constexpr int N = LT::kN;
     constexpr int ND = N + 6;
     const int nrows = N + 3 * nc;
     const float* gb = L.base() + 7;   // omega_w, v_w (after the unconstrained update)
@@ -636,8 +666,9 @@ __device__ void build_rows(Lds<N>& L, const DevModel& M, int lane, int nc, int& 
 // (btMultiBodyConstraintSolver::solveSingleIteration / resolveSingleConstraintRowGeneric /
 //  resolveConeFrictionConstraintRows [U]).  Returns delta-v of this lane.
 // ----------------------------------------------------------------------------------
-template <int N>
-__device__ float pgs(Lds<N>& L, const DevModel& M, int lane, int nc, int nn, float mu, int& iters) {
+template <class LT>
+__device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, float mu, int& iters) {
+    constexpr int N = LT::kN;
     constexpr int ND = N + 6;
     constexpr int W = (ND <= 32) ? 32 : 64;
     const bool act = lane < ND;
@@ -718,21 +749,22 @@ __device__ float pgs(Lds<N>& L, const DevModel& M, int lane, int nc, int nn, flo
 // ----------------------------------------------------------------------------------
 // one physics substep
 // ----------------------------------------------------------------------------------
-template <int N>
-__device__ void substep(Lds<N>& L, const DevModel& M, int lane, float mu, int& iters, int& ncontacts) {
+template <class LT>
+__device__ void substep_v1(LT& L, const DevModel& M, int lane, float mu, int& iters, int& ncontacts) {
+    constexpr int N = LT::kN;
     constexpr int ND = N + 6;
     const float dt = M.dt;
     // (1) contacts of the current pose, (2) bias forces with gravity, joint damping torque
-    const int nc = find_contacts<N>(L, M, lane);
+    const int nc = find_contacts_v1(L, M, lane);
     ncontacts = nc;
     if (lane < N) {
         float qd = L.qd()[lane];
         L.qd_old[lane] = qd;
         L.tauj[lane] = -M.joint_damp * qd;   // PyBullet adds URDF joint damping as a torque [U]
     }
-    body_bias<N, true>(L, M, lane);
+    body_bias<LT, true>(L, M, lane);
     lds_sync();
-    aba_main<N, true>(L, M, lane);
+    aba_main<LT, true>(L, M, lane);
     // joint-0 force sensor, first pass [U]: -zb . [m_r (a - g) + m_r v (k + k|v|)]
     f3 zb = mulRv(L.R[0], ld3(M.zbase));
     f3 v_old = ld3(L.base() + 10);
@@ -750,8 +782,8 @@ __device__ void substep(Lds<N>& L, const DevModel& M, int lane, float mu, int& i
     lds_sync();
     // (4) rows, (5) PGS
     int nn = 0;
-    build_rows<N>(L, M, lane, nc, nn);
-    float dv = pgs<N>(L, M, lane, nc, nn, mu, iters);
+    build_rows_v1(L, M, lane, nc, nn);
+    float dv = pgs_v1(L, M, lane, nc, nn, mu, iters);
     // (6) constraint pass for the joint-0 sensor [U]: ABA at the velocities after (3) with the
     // constraint forces as the only link forces, joint torques still applied
     if (lane <= N) {
@@ -790,9 +822,9 @@ __device__ void substep(Lds<N>& L, const DevModel& M, int lane, float mu, int& i
         }
     }
     lds_sync();
-    body_bias<N, false>(L, M, lane);
+    body_bias<LT, false>(L, M, lane);
     lds_sync();
-    aba_main<N, false>(L, M, lane);
+    aba_main<LT, false>(L, M, lane);
     {
         f3 v1 = ld3(L.base() + 10);
         float nv1 = sqrtf(dot(v1, v1));
@@ -839,26 +871,48 @@ __device__ void substep(Lds<N>& L, const DevModel& M, int lane, float mu, int& i
     }
     lds_sync();
     // pose of the new state: feeds checkSnakeHeight and the next substep
-    fk_vel<N>(L, M, lane);
+    fk_vel(L, M, lane);
+}
+
+}  // namespace snk
+#include "snk_pgs_v2.hpp"
+namespace snk {
+
+template <class LT>
+__device__ __forceinline__ void substep(LT& L, const DevModel& M0, int lane_in, float mu, int& iters, int& ncontacts) {
+    int lane = lane_in;
+    // Launder the model pointer once per substep: otherwise ~100 per-lane model constants are
+    // hoisted out of the substep loop and stay live (or spilled) across the whole solve.
+    const DevModel* Mq = &M0;
+    asm volatile("" : "+s"(Mq));
+    const DevModel& M = *Mq;
+    // ... and the lane id: hundreds of per-lane LDS addresses are loop-invariant and would
+    // otherwise be computed in the kernel prologue and spilled.
+    asm volatile("" : "+v"(lane));
+    if constexpr (LT::kV2) substep_v2(L, M, lane, mu, iters, ncontacts);
+    else substep_v1(L, M, lane, mu, iters, ncontacts);
 }
 
 // ----------------------------------------------------------------------------------
 // record <-> LDS, observation packing (snake.py:209-217)
 // ----------------------------------------------------------------------------------
-template <int N>
-__device__ __forceinline__ void load_rec(Lds<N>& L, const float* __restrict__ rec, int lane) {
+template <class LT>
+__device__ __forceinline__ void load_rec(LT& L, const float* __restrict__ rec, int lane) {
+    constexpr int N = LT::kN;
 #pragma unroll
-    for (int i = lane; i < Lds<N>::REC; i += 64) L.rec[i] = rec[i];
+    for (int i = lane; i < LT::REC; i += 64) L.rec[i] = rec[i];
     lds_sync();
 }
-template <int N>
-__device__ __forceinline__ void store_rec(Lds<N>& L, float* __restrict__ rec, int lane) {
+template <class LT>
+__device__ __forceinline__ void store_rec(LT& L, float* __restrict__ rec, int lane) {
+    constexpr int N = LT::kN;
     lds_sync();
 #pragma unroll
-    for (int i = lane; i < Lds<N>::REC; i += 64) rec[i] = L.rec[i];
+    for (int i = lane; i < LT::REC; i += 64) rec[i] = L.rec[i];
 }
-template <int N>
-__device__ __forceinline__ void write_obs(Lds<N>& L, float* __restrict__ obs, int lane) {
+template <class LT>
+__device__ __forceinline__ void write_obs(LT& L, float* __restrict__ obs, int lane) {
+    constexpr int N = LT::kN;
     // obs = [q, qd, tau_motor | pos3 quat4 | fz]; rec = [pos3 quat4 w3 v3 | q qd taum | fz px]
     for (int i = lane; i < 3 * N + 8; i += 64) {
         float x;
@@ -868,8 +922,9 @@ __device__ __forceinline__ void write_obs(Lds<N>& L, float* __restrict__ obs, in
         obs[i] = x;
     }
 }
-template <int N>
-__device__ __forceinline__ void soft_reset(Lds<N>& L, int lane) {
+template <class LT>
+__device__ __forceinline__ void soft_reset(LT& L, int lane) {
+    constexpr int N = LT::kN;
     // snake.py:96-99,119-127: base pose/twist and joint q, qd; motor-torque and sensor caches persist [U]
     for (int i = lane; i < 13 + 2 * N; i += 64) L.rec[i] = (i == 6) ? 1.0f : 0.0f;
 }
@@ -878,18 +933,19 @@ __device__ __forceinline__ void soft_reset(Lds<N>& L, int lane) {
 // kernels
 // ----------------------------------------------------------------------------------
 template <int N>
-__global__ __launch_bounds__(64) void env_step_kernel(const DevModel* __restrict__ Mp, float* __restrict__ recs,
+__global__ __launch_bounds__(64, 2) void env_step_kernel(const DevModel* __restrict__ Mp, float* __restrict__ recs,
                                                       const float* __restrict__ mu_plane,
                                                       float* __restrict__ actions, float* __restrict__ obs,
                                                       float* __restrict__ rew, uint8_t* __restrict__ done,
                                                       int32_t* __restrict__ substeps, int vec_mode, int n_envs) {
     extern __shared__ float4 smem_raw[];
-    Lds<N>& L = *reinterpret_cast<Lds<N>*>(smem_raw);
+    using LT = Lds<N, (N == 16)>;
+    LT& L = *reinterpret_cast<LT*>(smem_raw);
     const DevModel& M = *Mp;
     const int env = blockIdx.x;
     const int lane = threadIdx.x;
     if (env >= n_envs) return;
-    load_rec<N>(L, recs + (size_t)env * Lds<N>::REC, lane);
+    load_rec(L, recs + (size_t)env * LT::REC, lane);
     const int A = M.act_dim;
     // checkBound (SnakeGymEnv.py:82-88) clips the caller's array in place
     float act = 0.f;
@@ -908,7 +964,7 @@ __global__ __launch_bounds__(64) void env_step_kernel(const DevModel* __restrict
     }
     lds_sync();
     float mu = fminf(M.mu_link * mu_plane[env], 10.0f);
-    fk_vel<N>(L, M, lane);
+    fk_vel(L, M, lane);
     // Snake.step servo loop (snake.py:283-304)
     int counter = 0;
     bool end_height = false;
@@ -917,9 +973,9 @@ __global__ __launch_bounds__(64) void env_step_kernel(const DevModel* __restrict
         float e = (lane < N) ? (L.targets[lane] - L.q()[lane]) : 0.f;
         float nrm = sqrtf(wave_sum<64>(e * e));
         if (!(nrm > M.servo_tol)) break;
-        substep<N>(L, M, lane, mu, it_dummy, nc_dummy);
+        substep(L, M, lane, mu, it_dummy, nc_dummy);
         counter++;
-        if (mean_height<N>(L, M, lane) > M.height_thr) { end_height = true; break; }
+        if (mean_height(L, M, lane) > M.height_thr) { end_height = true; break; }
         if (counter > M.max_counter) break;
     }
     // SnakeGymEnv.step (SnakeGymEnv.py:36-42)
@@ -929,16 +985,16 @@ __global__ __launch_bounds__(64) void env_step_kernel(const DevModel* __restrict
     float r = M.alpha * (x - L.prev_x()) + (fabsf(fzv) > M.coll_force ? M.coll_pen : 0.f) - M.beta * fabsf(y) -
               M.gamma * energy;
     bool dn = fabsf(L.rec[13 + M.term_index]) > M.term_angle;
-    if (!dn) dn = mean_height<N>(L, M, lane) > M.height_thr;
+    if (!dn) dn = mean_height(L, M, lane) > M.height_thr;
     if (!dn) dn = end_height;
     if (dn) r += M.done_pen;
     float* ob = obs + (size_t)env * (3 * N + 8);
-    if (!(dn && vec_mode)) write_obs<N>(L, ob, lane);
+    if (!(dn && vec_mode)) write_obs(L, ob, lane);
     lds_sync();
     if (dn) {
-        soft_reset<N>(L, lane);
+        soft_reset(L, lane);
         lds_sync();
-        if (vec_mode) write_obs<N>(L, ob, lane);   // worker returns env.reset()'s obs
+        if (vec_mode) write_obs(L, ob, lane);   // worker returns env.reset()'s obs
     }
     lds_sync();
     if (lane == 0) {
@@ -948,67 +1004,70 @@ __global__ __launch_bounds__(64) void env_step_kernel(const DevModel* __restrict
         done[env] = dn ? 1 : 0;
         if (substeps) substeps[env] = counter;
     }
-    store_rec<N>(L, recs + (size_t)env * Lds<N>::REC, lane);
+    store_rec(L, recs + (size_t)env * LT::REC, lane);
 }
 
 template <int N>
-__global__ __launch_bounds__(64) void substep_kernel(const DevModel* __restrict__ Mp, float* __restrict__ recs,
+__global__ __launch_bounds__(64, 2) void substep_kernel(const DevModel* __restrict__ Mp, float* __restrict__ recs,
                                                      const float* __restrict__ mu_plane,
                                                      const float* __restrict__ targets, int k,
                                                      int32_t* __restrict__ info, int n_envs) {
     extern __shared__ float4 smem_raw[];
-    Lds<N>& L = *reinterpret_cast<Lds<N>*>(smem_raw);
+    using LT = Lds<N, (N == 16)>;
+    LT& L = *reinterpret_cast<LT*>(smem_raw);
     const DevModel& M = *Mp;
     const int env = blockIdx.x;
     const int lane = threadIdx.x;
     if (env >= n_envs) return;
-    load_rec<N>(L, recs + (size_t)env * Lds<N>::REC, lane);
+    load_rec(L, recs + (size_t)env * LT::REC, lane);
     if (lane < N) L.targets[lane] = targets[(size_t)env * N + lane];
     lds_sync();
     float mu = fminf(M.mu_link * mu_plane[env], 10.0f);
-    fk_vel<N>(L, M, lane);
+    fk_vel(L, M, lane);
     int iters = 0, nc = 0;
-    for (int s = 0; s < k; s++) substep<N>(L, M, lane, mu, iters, nc);
+    for (int s = 0; s < k; s++) substep(L, M, lane, mu, iters, nc);
     if (info && lane == 0) { info[2 * env] = iters; info[2 * env + 1] = nc; }
-    store_rec<N>(L, recs + (size_t)env * Lds<N>::REC, lane);
+    store_rec(L, recs + (size_t)env * LT::REC, lane);
 }
 
 template <int N>
 __global__ __launch_bounds__(64) void reset_kernel(float* __restrict__ recs, const uint8_t* __restrict__ mask,
                                                    float* __restrict__ obs, int hard, int n_envs) {
     extern __shared__ float4 smem_raw[];
-    Lds<N>& L = *reinterpret_cast<Lds<N>*>(smem_raw);
+    using LT = Lds<N, (N == 16)>;
+    LT& L = *reinterpret_cast<LT*>(smem_raw);
     const int env = blockIdx.x;
     const int lane = threadIdx.x;
     if (env >= n_envs) return;
     if (mask && !mask[env]) return;
-    load_rec<N>(L, recs + (size_t)env * Lds<N>::REC, lane);
-    soft_reset<N>(L, lane);
+    load_rec(L, recs + (size_t)env * LT::REC, lane);
+    soft_reset(L, lane);
     lds_sync();
     if (hard) {
-        for (int i = 13 + 2 * N + lane; i < Lds<N>::REC; i += 64) L.rec[i] = 0.f;
+        for (int i = 13 + 2 * N + lane; i < LT::REC; i += 64) L.rec[i] = 0.f;
         lds_sync();
     }
     if (lane == 0) L.prev_x() = 0.0f;   // _observation = reset obs (SnakeGymEnv.py:30), x = 0
     lds_sync();
-    if (obs) write_obs<N>(L, obs + (size_t)env * (3 * N + 8), lane);
-    store_rec<N>(L, recs + (size_t)env * Lds<N>::REC, lane);
+    if (obs) write_obs(L, obs + (size_t)env * (3 * N + 8), lane);
+    store_rec(L, recs + (size_t)env * LT::REC, lane);
 }
 
 template <int N>
 __global__ __launch_bounds__(64) void obs_kernel(const DevModel* __restrict__ Mp, const float* __restrict__ recs,
                                                  float* __restrict__ obs, float* __restrict__ height, int n_envs) {
     extern __shared__ float4 smem_raw[];
-    Lds<N>& L = *reinterpret_cast<Lds<N>*>(smem_raw);
+    using LT = Lds<N, (N == 16)>;
+    LT& L = *reinterpret_cast<LT*>(smem_raw);
     const DevModel& M = *Mp;
     const int env = blockIdx.x;
     const int lane = threadIdx.x;
     if (env >= n_envs) return;
-    load_rec<N>(L, recs + (size_t)env * Lds<N>::REC, lane);
-    if (obs) write_obs<N>(L, obs + (size_t)env * (3 * N + 8), lane);
+    load_rec(L, recs + (size_t)env * LT::REC, lane);
+    if (obs) write_obs(L, obs + (size_t)env * (3 * N + 8), lane);
     if (height) {
-        fk_vel<N>(L, M, lane);
-        float h = mean_height<N>(L, M, lane);
+        fk_vel(L, M, lane);
+        float h = mean_height(L, M, lane);
         if (lane == 0) height[env] = h;
     }
 }
@@ -1022,6 +1081,13 @@ __global__ __launch_bounds__(64) void selftest_kernel(float* out) {
     float s64b = wave_sum<64>(lane < 38 ? x * 0.5f : 0.f);
     float b = lane_bcast(x, 17);
     if (lane == 5) { out[0] = s32; out[1] = s64; out[2] = b; out[3] = s64b; }
+    // v2 primitives: per-half sums at lanes 31 / 63, and the half swap
+    float hr = half_reduce(x);
+    if (lane == 31) out[4] = hr;
+    if (lane == 63) out[5] = hr;
+    swap2 sw = half_swap(x, x * 100.f);
+    out[8 + lane] = sw.a;        // expect [x.lo, (100x).lo]
+    out[8 + 64 + lane] = sw.b;   // expect [x.hi, (100x).hi]
 }
 
 }  // namespace snk
