@@ -208,6 +208,19 @@ def main():
         local_sub = float(sub_total.item())
         alg_bytes_launch = (local_sub * BYTES_PER_SUBSTEP + E * K * BYTES_PER_ENVSTEP) / K
         achieved = alg_bytes_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        # HBM traffic per launch comes from rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 +
+        # WRITE_SIZE, calibrated on reset_kernel), run separately and committed under profiles/
+        traffic, traffic_src = None, None
+        try:
+            import glob
+            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_summary.json")))
+            if cands:
+                with open(cands[-1]) as f:
+                    pm = json.load(f)
+                traffic = pm.get("hbm_bytes_per_launch")
+                traffic_src = os.path.relpath(cands[-1], ROOT)
+        except Exception:  # noqa: BLE001
+            pass
         out = {
             "metric": "env-steps/sec (whole node), 16-link snake, 4096 envs/GPU",
             "value": n_env_steps / elapsed,
@@ -228,7 +241,7 @@ def main():
             "mean_substeps_per_env_step": substeps / n_env_steps,
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": "env_step_kernel<16>", "kernel_ms": kernel_ms, "launches": kcount,
                 "algorithmic_bytes_per_launch": alg_bytes_launch,
                 "note": "recurrence-bound path: ~1e3 flop per algorithmic byte; the HBM fraction is "
