@@ -48,6 +48,8 @@ struct snk_handle {
     float* d_tgt = nullptr;
     int32_t* d_info = nullptr;
     float* d_h = nullptr;
+    int32_t* d_order = nullptr;
+    bool plan = true;
     size_t lds_bytes = 0;
     // timing: pool of event pairs, one pair per snk_step launch, read back in one go
     std::vector<hipEvent_t> ev;
@@ -59,8 +61,11 @@ namespace {
 template <int N>
 int launch_step(snk_handle* h, float* act, float* obs, float* rew, uint8_t* done, int32_t* sub, int vec_mode,
                 hipStream_t st) {
+    if (h->plan)
+        hipLaunchKernelGGL((snk::plan_kernel<N>), dim3(1), dim3(1024), 0, st, h->d_model, h->d_recs, act, h->d_order,
+                           h->n_envs);
     hipLaunchKernelGGL((snk::env_step_kernel<N>), dim3(h->n_envs), dim3(64), h->lds_bytes, st, h->d_model, h->d_recs,
-                       h->d_mu, act, obs, rew, done, sub, vec_mode, h->n_envs);
+                       h->d_mu, act, obs, rew, done, sub, vec_mode, h->n_envs, h->plan ? h->d_order : nullptr);
     return 0;
 }
 template <int N>
@@ -188,6 +193,8 @@ int snk_create(const snk_params* p, int32_t n_envs, int32_t device, snk_handle**
     HIP_TRY(hipMalloc(&h->d_tgt, ne * h->n * sizeof(float)));
     HIP_TRY(hipMalloc(&h->d_info, ne * 2 * sizeof(int32_t)));
     HIP_TRY(hipMalloc(&h->d_h, ne * sizeof(float)));
+    HIP_TRY(hipMalloc(&h->d_order, ne * sizeof(int32_t)));
+    h->plan = getenv("SNK_NO_PLAN") == nullptr;
     // hard reset (snake.py:88-95)
     SNK_DISPATCH(h, launch_reset<16>(h, nullptr, nullptr, 1, nullptr), launch_reset<32>(h, nullptr, nullptr, 1, nullptr));
     if (check_launch()) { return 1; }
@@ -201,7 +208,7 @@ int snk_destroy(snk_handle* h) {
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
     void* bufs[] = {h->d_model, h->d_recs, h->d_mu, h->d_act, h->d_obs, h->d_rew, h->d_done,
-                    h->d_sub, h->d_mask, h->d_tgt, h->d_info, h->d_h};
+                    h->d_sub, h->d_mask, h->d_tgt, h->d_info, h->d_h, h->d_order};
     for (void* b : bufs) (void)hipFree(b);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
     delete h;

@@ -937,14 +937,16 @@ __global__ __launch_bounds__(64, 2) void env_step_kernel(const DevModel* __restr
                                                       const float* __restrict__ mu_plane,
                                                       float* __restrict__ actions, float* __restrict__ obs,
                                                       float* __restrict__ rew, uint8_t* __restrict__ done,
-                                                      int32_t* __restrict__ substeps, int vec_mode, int n_envs) {
+                                                      int32_t* __restrict__ substeps, int vec_mode, int n_envs,
+                                                      const int32_t* __restrict__ order) {
     extern __shared__ float4 smem_raw[];
     using LT = Lds<N, (N == 16)>;
     LT& L = *reinterpret_cast<LT*>(smem_raw);
     const DevModel& M = *Mp;
-    const int env = blockIdx.x;
+    if ((int)blockIdx.x >= n_envs) return;
+    // longest-first schedule: workgroup b takes the env with the b-th largest predicted work
+    const int env = order ? __builtin_amdgcn_readfirstlane(order[blockIdx.x]) : (int)blockIdx.x;
     const int lane = threadIdx.x;
-    if (env >= n_envs) return;
     load_rec(L, recs + (size_t)env * LT::REC, lane);
     const int A = M.act_dim;
     // checkBound (SnakeGymEnv.py:82-88) clips the caller's array in place
@@ -1069,6 +1071,55 @@ __global__ __launch_bounds__(64) void obs_kernel(const DevModel* __restrict__ Mp
         fk_vel(L, M, lane);
         float h = mean_height(L, M, lane);
         if (lane == 0) height[env] = h;
+    }
+}
+
+// ----------------------------------------------------------------------------------
+// Launch planning.  An env-step costs 0..41 substeps depending on how far the joints are
+// from their targets (snake.py:228-235), and a substep is a latency-bound ~0.5 ms chain, so
+// the launch time is set by envs with many substeps that start late.  This one-block kernel
+// sorts the envs by their initial servo error, largest first (counting sort on a 256-bin
+// key); env_step_kernel's workgroup b then runs order[b].  Pure scheduling: results do not
+// depend on the order.
+// ----------------------------------------------------------------------------------
+template <int N>
+__global__ __launch_bounds__(1024) void plan_kernel(const DevModel* __restrict__ Mp, const float* __restrict__ recs,
+                                                    const float* __restrict__ actions, int32_t* __restrict__ order,
+                                                    int n_envs) {
+    constexpr int REC = (N <= 16) ? 64 : 128;
+    constexpr int NBIN = 256;
+    __shared__ int hist[NBIN];
+    __shared__ int base[NBIN];
+    const DevModel& M = *Mp;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < NBIN; i += blockDim.x) hist[i] = 0;
+    __syncthreads();
+    const int A = M.act_dim;
+    auto key_of = [&](int e) {
+        const float* q = recs + (size_t)e * REC + 13;
+        float err2 = 0.f;
+        for (int j = 0; j < N; j++) {
+            int k = (M.gait == 0) ? ((j & 1) ? -1 : j / 2) : ((M.gait == 1) ? ((j & 1) ? j / 2 : -1) : j);
+            float t = 0.f;
+            if (k >= 0 && k < A) t = fminf(fmaxf(actions[(size_t)e * A + k], -1.f), 1.f) * M.scaling;
+            float d = t - q[j];
+            err2 += d * d;
+        }
+        // larger error -> smaller bin index -> earlier workgroup.  log scale, 256 bins.
+        float l = __log2f(fmaxf(err2, 1e-12f));          // about [-40, 8]
+        int b = (int)((8.0f - l) * 5.0f);
+        return b < 0 ? 0 : (b > NBIN - 1 ? NBIN - 1 : b);
+    };
+    for (int e = tid; e < n_envs; e += blockDim.x) atomicAdd(&hist[key_of(e)], 1);
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int i = 0; i < NBIN; i++) { base[i] = run; run += hist[i]; }
+    }
+    __syncthreads();
+    for (int e = tid; e < n_envs; e += blockDim.x) {
+        int pos = atomicAdd(&base[key_of(e)], 1);
+        order[pos] = e;
     }
 }
 

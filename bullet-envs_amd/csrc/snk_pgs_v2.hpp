@@ -20,8 +20,13 @@
 //   * single rows are processed in PHASES of one half with EXEC masked to that half (the
 //     other half's copy of delta-v is refreshed once per phase by v_permlane32_swap);
 //     friction pairs use both halves and exchange their contributions with the same swap
-//   * the early-exit residual (max over rows of |dI * den|) is only evaluated until the
-//     first row exceeds the threshold in an iteration: afterwards a scalar branch skips it
+//   * the solve is VALU-issue-bound (PMC: VALU active 48 % of wave cycles per wave, two waves
+//     per SIMD; I-cache hit rate 99.95 %), so the row updates are hand-written with the fewest
+//     VALU instructions: 12 per single row, 28 per friction pair; s_nops for the DPP hazards
+//     cost nothing because the other wave of the SIMD issues into them.  (A software-
+//     pipelined variant with look-ahead reductions was measured: +25 % instructions, slower.)
+//   * the early-exit residual (max over rows of |dI * den|) is evaluated only until the first
+//     row exceeds the threshold in an iteration; after that the residual-free code runs
 //
 // Row construction (M^-1 J^T by ABA delta sweeps, one row per lane) goes through a 64-row
 // LDS staging buffer, one batch per row kind; J itself is evaluated directly in the
@@ -266,44 +271,112 @@ __device__ __forceinline__ void load_slot(LT& L, const LaneK& K, int s, int coun
     RM = mine ? rm : RM;
 }
 
-// Single-row update of the row living in half H of its slot.  HM is 1 in that half's lanes
-// and 0 in the other's, so only that half's copy of delta-v changes (the other copy is
-// refreshed by a half swap before rows of the other half run); E is 1 at the half's lane 23.
-// lsq accumulates max |dI * den| in lane 24 (H=0) / 56 (H=1) for Bullet's early-exit test.
-template <int H>
-__device__ __forceinline__ void row_step(float& RJ, const float RM, float& dv, float lo, float hi, float E, float HM,
-                                         float& lsq, float INF) {
-    float s_dot = half_dot1<H>(RJ * dv);
-    float s_a = rdlane(RJ, H ? 55 : 23);
-    float nw = __builtin_amdgcn_fmed3f(-s_dot, lo, hi);
-    float dI = nw - s_a;
-    dv = fmaf(RM, dI * HM, dv);
-    RJ = fmaf(E, dI, RJ);
-    lsq = __builtin_amdgcn_fmed3f(lsq, fabsf(RJ * dI), INF);
-    __builtin_amdgcn_sched_barrier(0);   // one row at a time: overlapping rows only adds register pressure
+// old with lane l replaced by a wave-uniform value (once per substep: a select is fine)
+__device__ __forceinline__ float wrlane(float old, float v_uniform, int l) {
+    return ((int)threadIdx.x == l) ? v_uniform : old;
 }
 
-// Bullet's cone-friction pair: both dots from one reduction, radial projection onto the disc
-// of radius mu * lambda_n, contributions exchanged between the halves.
-__device__ __forceinline__ void cone_step(float& RJ, const float RM, float& dv, float s_an, float MU, float EPS,
-                                          float E2355, bool lower, float& lsq, float INF) {
-    float s_dA, s_dB;
-    half_dot2(RJ * dv, s_dA, s_dB);
-    float r2 = fmaf(s_dA, s_dA, EPS);
-    r2 = fmaf(s_dB, s_dB, r2);
-    float lim = s_an * MU;
-    float sc = __builtin_amdgcn_fmed3f(lim * __builtin_amdgcn_rsqf(r2), 0.0f, 1.0f);
-    float nA = -s_dA * sc, nB = -s_dB * sc;
-    float s_aA = rdlane(RJ, 23), s_aB = rdlane(RJ, 55);
-    float dIA = nA - s_aA, dIB = nB - s_aB;
-    float dIh = lower ? dIA : dIB;
-    float c = RM * dIh;
-    swap2 sw = half_swap(c, c);
-    dv += sw.a;
-    dv += sw.b;
-    RJ = fmaf(E2355, dIh, RJ);
-    lsq = __builtin_amdgcn_fmed3f(lsq, fabsf(RJ * dIh), INF);
-    __builtin_amdgcn_sched_barrier(0);
+// Single-row update of the row living in half H of its slot (hand-written, 12 VALU):
+//   dot = sum over the half of RJ*dv  (v_mul + 5 v_add_dpp + v_readlane)
+//   a' = med3(-dot, LO, HI);  dI = a' - a;  dv += RM*dI in THIS half's lanes only (the fmac is
+//   issued as DPP with the identity permutation and row_mask selecting the half);  a += dI
+//   through E (1 at this half's lane 23).  RES: also accumulate max |dI * den| into lsq.
+template <int H, bool RES>
+__device__ __forceinline__ void row_step(float& RJ, const float RM, float& dv, float LO, float HI, float E, float& lsq) {
+    float t, x, dI;
+    float s0, s1;
+    asm volatile(
+        "v_mul_f32 %[t], %[RJ], %[dv]\n\t"
+        "v_readlane_b32 %[s1], %[RJ], %[ALn]\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %[t], %[t], %[t] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %[t], %[t], %[t] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %[t], %[t], %[t] row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %[t], %[t], %[t] row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %[t], %[t], %[t] row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_readlane_b32 %[s0], %[t], %[RLn]\n\t"
+        "s_nop 1\n\t"
+        "v_med3_f32 %[x], -%[s0], %[LO], %[HI]\n\t"
+        "v_subrev_f32 %[dI], %[s1], %[x]\n\t"
+        "s_nop 0\n\t"
+        "v_fmac_f32_dpp %[dv], %[RM], %[dI] quad_perm:[0,1,2,3] row_mask:%[RMn] bank_mask:0xf\n\t"
+        "v_fmac_f32 %[RJ], %[E], %[dI]\n\t"
+        : [t] "=&v"(t), [x] "=&v"(x), [dI] "=&v"(dI), [s0] "=&s"(s0), [s1] "=&s"(s1), [RJ] "+v"(RJ), [dv] "+v"(dv)
+        : [RM] "v"(RM), [LO] "v"(LO), [HI] "v"(HI), [E] "v"(E), [ALn] "n"(H ? 55 : 23), [RLn] "n"(H ? 63 : 31),
+          [RMn] "n"(H ? 0xc : 0x3));
+    if (RES) {
+        asm volatile("v_mul_f32 %[x], %[dI], %[RJ]\n\t"
+                     "v_max_f32 %[lsq], %[lsq], |%[x]|\n\t"
+                     "s_nop 1"
+                     : [x] "=&v"(x), [lsq] "+v"(lsq)
+                     : [dI] "v"(dI), [RJ] "v"(RJ));
+    } else {
+        asm volatile("s_nop 1");
+    }
+}
+
+// Bullet's cone-friction pair (hand-written, 28 VALU): direction A in the lower half and B in
+// the upper half of one register, so one reduction yields both dots; the accumulated pair is
+// projected radially onto the disc of radius mu * lambda_n (the normal's accumulated impulse:
+// lane NL of RJnorm); the two contributions to delta-v cross halves with v_permlane32_swap.
+template <int NL, bool RES>
+__device__ __forceinline__ void cone_step(float& RJ, const float RM, const float RJnorm, float& dv, float MU, float EPS,
+                                          float E2355, unsigned long long lowmask, float& lsq) {
+    float t, xA, xB, r2, c2, lim;
+    float s0, s1, s2, s3, s4;
+    asm volatile(
+        "v_mul_f32 %[t], %[RJ], %[dv]\n\t"
+        "v_readlane_b32 %[s4], %[RJnorm], %[NLn]\n\t"
+        "v_readlane_b32 %[s0], %[RJ], 23\n\t"
+        "v_add_f32_dpp %[t], %[t], %[t] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_readlane_b32 %[s2], %[RJ], 55\n\t"
+        "v_mul_f32 %[lim], %[s4], %[MU]\n\t"
+        "v_add_f32_dpp %[t], %[t], %[t] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_mov_b32 %[xA], %[s0]\n\t"
+        "v_mov_b32 %[xB], %[s2]\n\t"
+        "v_add_f32_dpp %[t], %[t], %[t] row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %[t], %[t], %[t] row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %[t], %[t], %[t] row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_readlane_b32 %[s1], %[t], 31\n\t"
+        "v_readlane_b32 %[s3], %[t], 63\n\t"
+        "s_nop 1\n\t"
+        "v_fma_f32 %[r2], %[s1], %[s1], %[EPS]\n\t"
+        "v_fma_f32 %[r2], %[s3], %[s3], %[r2]\n\t"
+        "v_rsq_f32 %[r2], %[r2]\n\t"
+        "s_nop 1\n\t"
+        "v_mul_f32_e64 %[r2], %[lim], %[r2] clamp\n\t"
+        "v_fma_f32 %[xA], %[r2], -%[s1], -%[xA]\n\t"
+        "v_fma_f32 %[xB], %[r2], -%[s3], -%[xB]\n\t"
+        "v_cndmask_b32_e64 %[t], %[xB], %[xA], %[lowmask]\n\t"
+        "v_mul_f32 %[r2], %[RM], %[t]\n\t"
+        "v_fmac_f32 %[RJ], %[E], %[t]\n\t"
+        "v_mov_b32 %[c2], %[r2]\n\t"
+        "s_nop 1\n\t"
+        "v_permlane32_swap_b32 %[r2], %[c2]\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32 %[dv], %[dv], %[r2]\n\t"
+        "v_add_f32 %[dv], %[dv], %[c2]\n\t"
+        : [t] "=&v"(t), [xA] "=&v"(xA), [xB] "=&v"(xB), [r2] "=&v"(r2), [c2] "=&v"(c2), [lim] "=&v"(lim),
+          [s0] "=&s"(s0), [s1] "=&s"(s1), [s2] "=&s"(s2), [s3] "=&s"(s3), [s4] "=&s"(s4), [RJ] "+v"(RJ), [dv] "+v"(dv)
+        : [RM] "v"(RM), [RJnorm] "v"(RJnorm), [MU] "v"(MU), [EPS] "v"(EPS), [E] "v"(E2355), [lowmask] "s"(lowmask),
+          [NLn] "n"(NL));
+    if (RES) {
+        asm volatile("v_mul_f32 %[x], %[dI], %[RJ]\n\t"
+                     "v_max_f32 %[lsq], %[lsq], |%[x]|\n\t"
+                     "s_nop 1"
+                     : [x] "=&v"(xA), [lsq] "+v"(lsq)
+                     : [dI] "v"(t), [RJ] "v"(RJ));
+    } else {
+        asm volatile("s_nop 1");
+    }
 }
 
 // slot map
@@ -311,6 +384,26 @@ constexpr int kSlotMotor = 0;     // 8 slots
 constexpr int kSlotNormal = 8;    // 32 slots
 constexpr int kSlotFric = 40;     // 64 slots
 constexpr int kSlots = 104;
+
+// eight consecutive single rows of half H (slots BASE..BASE+7, backwards if REV)
+template <int H, bool RES, int BASE, bool REV>
+__device__ __forceinline__ void rows8(float (&RJ)[kSlots], float (&RM)[kSlots], float& dv, float LO, float HI, float E,
+                                      float& lsq) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int s = BASE + (REV ? 7 - i : i);
+        row_step<H, RES>(RJ[s], RM[s], dv, LO, HI, E, lsq);
+    }
+}
+// eight consecutive friction pairs (contacts 8G..8G+7)
+template <bool RES, int G>
+__device__ __forceinline__ void cones8(float (&RJ)[kSlots], float (&RM)[kSlots], float& dv, float MU, float EPS,
+                                       float E2355, unsigned long long lowmask, float& lsq) {
+#pragma unroll
+    for (int ci = 8 * G; ci < 8 * G + 8; ci++)
+        cone_step<(G < 4 ? 23 : 55), RES>(RJ[kSlotFric + ci], RM[kSlotFric + ci], RJ[kSlotNormal + (ci & 31)], dv, MU, EPS,
+                                          E2355, lowmask, lsq);
+}
 
 template <class LT>
 __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane, float mu, int& iters, int& ncontacts) {
@@ -439,22 +532,26 @@ __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane, f
         const float E2355 = d == 23 ? 1.0f : 0.0f;
         const float E23 = lane == 23 ? 1.0f : 0.0f;
         const float E55 = lane == 55 ? 1.0f : 0.0f;
-        const bool lower = lane < 32;
-        const float HM0 = lower ? 1.0f : 0.0f;
-        const float HM1 = lower ? 0.0f : 1.0f;
         const float MU = mu;
         const float EPS = 1e-30f;
         const float mi = M.max_motor_imp;
+        const float NMI = -mi, PMI = mi, ZERO = 0.f, BIG = 1e10f;
+        const unsigned long long LOWMASK = 0x00000000FFFFFFFFull;
         const float thr = sqrtf(M.resid_thr);
         const int n_iter = M.n_iter;
         const bool cone = M.cone != 0;
         int it = 0;
-        const float INF = __builtin_inff();
         for (; it < n_iter; it++) {
-            float lsq0 = 0.f, lsq1 = 0.f, lsqP = 0.f;
+            // Bullet leaves the sweep when max_rows |dI * den| <= threshold.  `exceeded` becomes 1
+            // as soon as a group of rows shows a larger residual; from then on the residual-free
+            // variants (RES = false) run.
             int exceeded = 0;
             int ncl = nc;
             asm volatile("" : "+s"(ncl));   // keeps the group-active compares from being hoisted and spilled
+            auto check = [&](float lsq, int la, int lb) {
+                float m = fmaxf(rdlane(lsq, la), rdlane(lsq, lb));
+                exceeded = __builtin_amdgcn_readfirstlane(m > thr ? 1 : 0);
+            };
             auto limit_rows = [&](bool fwd) {
                 for (int jj = 0; jj < nlim; jj++) {
                     const int idx = fwd ? jj : nlim - 1 - jj;
@@ -474,77 +571,72 @@ __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane, f
             // give the other half the fresh copy of delta-v
             auto sync_from_lower = [&]() { swap2 sw = half_swap(dv, dv); dv = sw.a; };
             auto sync_from_upper = [&]() { swap2 sw = half_swap(dv, dv); dv = sw.b; };
+#define SNK_ROWS8(H, BASE, REV, LO, HI, E, LANE)                                                   \
+    if (exceeded) { float l_ = 0.f; rows8<H, false, BASE, REV>(RJ, RM, dv, LO, HI, E, l_); }        \
+    else { float l_ = 0.f; rows8<H, true, BASE, REV>(RJ, RM, dv, LO, HI, E, l_); check(l_, LANE, LANE); }
+#define SNK_CONES8(G)                                                                              \
+    if (exceeded) { float l_ = 0.f; cones8<false, G>(RJ, RM, dv, MU, EPS, E2355, LOWMASK, l_); }    \
+    else { float l_ = 0.f; cones8<true, G>(RJ, RM, dv, MU, EPS, E2355, LOWMASK, l_); check(l_, 24, 56); }
             // non-contact rows: list = [limits..., motors 0..15], walked forwards on odd
             // iterations and backwards on even ones; motors 0..7 live in the lower halves
             if (it & 1) {
                 limit_rows(true);
-#pragma unroll
-                for (int j = 0; j < 8; j++) row_step<0>(RJ[kSlotMotor + j], RM[kSlotMotor + j], dv, -mi, mi, E23, HM0, lsq0, INF);
+                SNK_ROWS8(0, kSlotMotor, false, NMI, PMI, E23, 24)
                 sync_from_lower();
-#pragma unroll
-                for (int j = 0; j < 8; j++) row_step<1>(RJ[kSlotMotor + j], RM[kSlotMotor + j], dv, -mi, mi, E55, HM1, lsq1, INF);
+                SNK_ROWS8(1, kSlotMotor, false, NMI, PMI, E55, 56)
                 sync_from_upper();
             } else {
-#pragma unroll
-                for (int j = 7; j >= 0; j--) row_step<1>(RJ[kSlotMotor + j], RM[kSlotMotor + j], dv, -mi, mi, E55, HM1, lsq1, INF);
+                SNK_ROWS8(1, kSlotMotor, true, NMI, PMI, E55, 56)
                 sync_from_upper();
-#pragma unroll
-                for (int j = 7; j >= 0; j--) row_step<0>(RJ[kSlotMotor + j], RM[kSlotMotor + j], dv, -mi, mi, E23, HM0, lsq0, INF);
+                SNK_ROWS8(0, kSlotMotor, true, NMI, PMI, E23, 24)
                 sync_from_lower();
                 limit_rows(false);
             }
             // contact normals in contact order: 0..31 live in the lower halves, 32..63 in the
             // upper; one scalar branch per group of 8, rows past the active count are inert
-#pragma unroll
-            for (int g = 0; g < 4; g++) {
-                if (ncl > 8 * g) {
-#pragma unroll
-                    for (int ci = 8 * g; ci < 8 * g + 8; ci++)
-                        row_step<0>(RJ[kSlotNormal + ci], RM[kSlotNormal + ci], dv, 0.f, 1e10f, E23, HM0, lsq0, INF);
-                }
-            }
+            if (ncl > 0) { SNK_ROWS8(0, kSlotNormal + 0, false, ZERO, BIG, E23, 24) }
+            if (ncl > 8) { SNK_ROWS8(0, kSlotNormal + 8, false, ZERO, BIG, E23, 24) }
+            if (ncl > 16) { SNK_ROWS8(0, kSlotNormal + 16, false, ZERO, BIG, E23, 24) }
+            if (ncl > 24) { SNK_ROWS8(0, kSlotNormal + 24, false, ZERO, BIG, E23, 24) }
             sync_from_lower();
             if (ncl > 32) {
-#pragma unroll
-                for (int g = 0; g < 4; g++) {
-                    if (ncl > 32 + 8 * g) {
-#pragma unroll
-                        for (int ci = 8 * g; ci < 8 * g + 8; ci++)
-                            row_step<1>(RJ[kSlotNormal + ci], RM[kSlotNormal + ci], dv, 0.f, 1e10f, E55, HM1, lsq1, INF);
-                    }
-                }
+                SNK_ROWS8(1, kSlotNormal + 0, false, ZERO, BIG, E55, 56)
+                if (ncl > 40) { SNK_ROWS8(1, kSlotNormal + 8, false, ZERO, BIG, E55, 56) }
+                if (ncl > 48) { SNK_ROWS8(1, kSlotNormal + 16, false, ZERO, BIG, E55, 56) }
+                if (ncl > 56) { SNK_ROWS8(1, kSlotNormal + 24, false, ZERO, BIG, E55, 56) }
                 sync_from_upper();
             }
             // friction pairs in contact order
             if (cone) {
-#pragma unroll
-                for (int g = 0; g < 8; g++) {
-                    if (ncl > 8 * g) {
-#pragma unroll
-                        for (int ci = 8 * g; ci < 8 * g + 8; ci++) {
-                            float s_an = rdlane(RJ[kSlotNormal + (ci & 31)], (ci & 32) ? 55 : 23);
-                            cone_step(RJ[kSlotFric + ci], RM[kSlotFric + ci], dv, s_an, MU, EPS, E2355, lower, lsqP, INF);
-                        }
-                    }
-                }
+                if (ncl > 0) { SNK_CONES8(0) }
+                if (ncl > 8) { SNK_CONES8(1) }
+                if (ncl > 16) { SNK_CONES8(2) }
+                if (ncl > 24) { SNK_CONES8(3) }
+                if (ncl > 32) { SNK_CONES8(4) }
+                if (ncl > 40) { SNK_CONES8(5) }
+                if (ncl > 48) { SNK_CONES8(6) }
+                if (ncl > 56) { SNK_CONES8(7) }
             } else {
+                // pyramid friction (not Bullet's default here): the two directions as single rows
 #pragma unroll
                 for (int g = 0; g < 8; g++) {
                     if (ncl > 8 * g) {
 #pragma unroll
                         for (int ci = 8 * g; ci < 8 * g + 8; ci++) {
                             float lim = rdlane(RJ[kSlotNormal + (ci & 31)], (ci & 32) ? 55 : 23) * MU;
+                            float nlim_ = -lim, lsq = 0.f;
                             // lim == 0 clamps both impulses to 0 (Bullet skips the rows: same result)
-                            row_step<0>(RJ[kSlotFric + ci], RM[kSlotFric + ci], dv, -lim, lim, E23, HM0, lsq0, INF);
+                            row_step<0, true>(RJ[kSlotFric + ci], RM[kSlotFric + ci], dv, nlim_, lim, E23, lsq);
                             sync_from_lower();
-                            row_step<1>(RJ[kSlotFric + ci], RM[kSlotFric + ci], dv, -lim, lim, E55, HM1, lsq1, INF);
+                            row_step<1, true>(RJ[kSlotFric + ci], RM[kSlotFric + ci], dv, nlim_, lim, E55, lsq);
                             sync_from_upper();
+                            if (!exceeded) exceeded = __builtin_amdgcn_readfirstlane(fmaxf(rdlane(lsq, 24), rdlane(lsq, 56)) > thr ? 1 : 0);
                         }
                     }
                 }
             }
-            float lsq = fmaxf(fmaxf(rdlane(lsq0, 24), rdlane(lsq1, 56)), fmaxf(rdlane(lsqP, 24), rdlane(lsqP, 56)));
-            if (__builtin_amdgcn_readfirstlane(lsq > thr ? 1 : 0)) exceeded = 1;
+#undef SNK_ROWS8
+#undef SNK_CONES8
             if (!exceeded || it >= n_iter - 1) { it++; break; }
         }
         iters = it;
