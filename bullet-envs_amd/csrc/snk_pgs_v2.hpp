@@ -12,14 +12,17 @@
 //     RJ = J / den (pre-scaled), RM = M^-1 J^T, both halves of `dv` carry the same delta-v.
 //     Then   sum_d RJ[d] dv[d] = (J.dv)/den - rhs - a   and the new accumulated impulse of
 //     the row is simply clamp(-sum): no per-row scalar is fetched from memory.
-//   * slots: 0..7 motors (motor s in the lower half, motor 8+s in the upper half),
-//     8..39 contact normals (contact s lower, contact 32+s upper), 40..103 friction pairs
-//     (direction A in the lower half, B in the upper half, so the two dots of Bullet's
-//     cone-friction pair come out of one DPP reduction)
-//   * a half's dot: 4 DPP row steps + row_bcast:15 -> lane 31 / 63 -> v_readlane
-//   * single rows are processed in PHASES of one half with EXEC masked to that half (the
-//     other half's copy of delta-v is refreshed once per phase by v_permlane32_swap);
-//     friction pairs use both halves and exchange their contributions with the same swap
+//   * slots: 0..7 motors (motors 2s, 2s+1 in the lower/upper half), 8..39 contact normals
+//     (contacts 2s, 2s+1), 40..103 friction pairs (direction A lower, B upper)
+//   * a half's dot: 4 DPP row steps + row_bcast:15 -> lane 31 / 63 -> v_readlane; one
+//     reduction therefore yields the dots of BOTH rows of a slot
+//   * friction pair: Bullet resolves both directions from the same velocity, so the two
+//     dots are used as they are.  Two consecutive single rows (a "duo"): the second row must
+//     see the first row's update; its dot is corrected exactly by  c * dI_first  with the
+//     coupling scalar c = RJ_second . RM_first, precomputed once per substep (lane 25 / 57).
+//     This halves the number of sequential steps of the Gauss-Seidel chain at equal work.
+//   * contributions to delta-v cross halves with v_permlane32_swap, so both halves always
+//     hold the complete delta-v
 //   * the solve is VALU-issue-bound (PMC: VALU active 48 % of wave cycles per wave, two waves
 //     per SIMD; I-cache hit rate 99.95 %), so the row updates are hand-written with the fewest
 //     VALU instructions: 12 per single row, 28 per friction pair; s_nops for the DPP hazards
@@ -238,11 +241,11 @@ struct LaneK {
 };
 
 // Fill the halves of one register slot from the rows staged by the last batch.
-// KIND 0 motor (row = s + 8h, from L.Mm), 1 normal (contact s + 32h; both halves),
+// KIND 0 motor (row = 2s + h, from L.Mm), 1 normal (contact 2s + h; both halves),
 // 2 friction A (contact s -> lower half only), 3 friction B (contact s -> upper half only).
 template <class LT, int KIND>
 __device__ __forceinline__ void load_slot(LT& L, const LaneK& K, int s, int count, float& RJ, float& RM) {
-    const int row = KIND == 0 ? s + 8 * K.h : (KIND == 1 ? s + 32 * K.h : s);
+    const int row = (KIND == 0 || KIND == 1) ? 2 * s + K.h : s;
     const bool valid = row < count;
     const int rs = valid ? row : 0;
     // staged normals: rows 0..31 of the batch sit in staging rows 0..31, rows 32..63 after them
@@ -276,45 +279,73 @@ __device__ __forceinline__ float wrlane(float old, float v_uniform, int l) {
     return ((int)threadIdx.x == l) ? v_uniform : old;
 }
 
-// Single-row update of the row living in half H of its slot (hand-written, 12 VALU):
-//   dot = sum over the half of RJ*dv  (v_mul + 5 v_add_dpp + v_readlane)
-//   a' = med3(-dot, LO, HI);  dI = a' - a;  dv += RM*dI in THIS half's lanes only (the fmac is
-//   issued as DPP with the identity permutation and row_mask selecting the half);  a += dI
-//   through E (1 at this half's lane 23).  RES: also accumulate max |dI * den| into lsq.
-template <int H, bool RES>
-__device__ __forceinline__ void row_step(float& RJ, const float RM, float& dv, float LO, float HI, float E, float& lsq) {
-    float t, x, dI;
-    float s0, s1;
-    asm volatile(
-        "v_mul_f32 %[t], %[RJ], %[dv]\n\t"
-        "v_readlane_b32 %[s1], %[RJ], %[ALn]\n\t"
-        "s_nop 0\n\t"
-        "v_add_f32_dpp %[t], %[t], %[t] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "s_nop 1\n\t"
-        "v_add_f32_dpp %[t], %[t], %[t] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "s_nop 1\n\t"
-        "v_add_f32_dpp %[t], %[t], %[t] row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "s_nop 1\n\t"
-        "v_add_f32_dpp %[t], %[t], %[t] row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "s_nop 1\n\t"
-        "v_add_f32_dpp %[t], %[t], %[t] row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_readlane_b32 %[s0], %[t], %[RLn]\n\t"
-        "s_nop 1\n\t"
-        "v_med3_f32 %[x], -%[s0], %[LO], %[HI]\n\t"
-        "v_subrev_f32 %[dI], %[s1], %[x]\n\t"
-        "s_nop 0\n\t"
-        "v_fmac_f32_dpp %[dv], %[RM], %[dI] quad_perm:[0,1,2,3] row_mask:%[RMn] bank_mask:0xf\n\t"
-        "v_fmac_f32 %[RJ], %[E], %[dI]\n\t"
-        : [t] "=&v"(t), [x] "=&v"(x), [dI] "=&v"(dI), [s0] "=&s"(s0), [s1] "=&s"(s1), [RJ] "+v"(RJ), [dv] "+v"(dv)
-        : [RM] "v"(RM), [LO] "v"(LO), [HI] "v"(HI), [E] "v"(E), [ALn] "n"(H ? 55 : 23), [RLn] "n"(H ? 63 : 31),
-          [RMn] "n"(H ? 0xc : 0x3));
+// Two consecutive single rows living in the two halves of one slot (hand-written, 25 VALU).
+// ORDER 0: lower-half row first, then the upper-half row (coupling scalar in lane 57);
+// ORDER 1: upper first, then lower (coupling in lane 25) -- motors are walked backwards on
+// even iterations.  For each row:  a' = med3(-dot, LO, HI), dI = a' - a; the second row's dot
+// first receives  c * dI_first.  Both contributions are exchanged between the halves, and the
+// accumulated impulses (lane 23 / 55) are updated through E2355.
+// RES: also accumulate max |dI * den| (lane 24 / 56) into lsq.
+#define SNK_DUO_ASM(SEL)                                                                          \
+    "v_mul_f32 %[t], %[RJ], %[dv]\n\t"                                                             \
+    "v_readlane_b32 %[s2], %[RJ], %[AF]\n\t"                                                       \
+    "v_readlane_b32 %[s3], %[RJ], %[AS]\n\t"                                                       \
+    "v_add_f32_dpp %[t], %[t], %[t] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+    "v_readlane_b32 %[s4], %[RJ], %[CL]\n\t"                                                       \
+    "s_nop 0\n\t"                                                                                  \
+    "v_add_f32_dpp %[t], %[t], %[t] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+    "s_nop 1\n\t"                                                                                  \
+    "v_add_f32_dpp %[t], %[t], %[t] row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"         \
+    "s_nop 1\n\t"                                                                                  \
+    "v_add_f32_dpp %[t], %[t], %[t] row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"         \
+    "s_nop 1\n\t"                                                                                  \
+    "v_add_f32_dpp %[t], %[t], %[t] row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"                   \
+    "s_nop 1\n\t"                                                                                  \
+    "v_readlane_b32 %[s0], %[t], %[DF]\n\t"                                                        \
+    "v_readlane_b32 %[s1], %[t], %[DS]\n\t"                                                        \
+    "s_nop 0\n\t"                                                                                  \
+    "v_med3_f32 %[dF], -%[s0], %[LO], %[HI]\n\t"                                                   \
+    "v_mov_b32 %[x], %[s1]\n\t"                                                                    \
+    "v_subrev_f32 %[dF], %[s2], %[dF]\n\t"                                                         \
+    "v_fmac_f32 %[x], %[s4], %[dF]\n\t"                                                            \
+    "v_med3_f32 %[x], -%[x], %[LO], %[HI]\n\t"                                                     \
+    "v_subrev_f32 %[dS], %[s3], %[x]\n\t"                                                          \
+    SEL                                                                                            \
+    "v_mul_f32 %[x], %[RM], %[t]\n\t"                                                              \
+    "v_mul_f32 %[c2], %[RM], %[t]\n\t"                                                             \
+    "v_fmac_f32 %[RJ], %[E], %[t]\n\t"                                                             \
+    "s_nop 0\n\t"                                                                                  \
+    "v_permlane32_swap_b32 %[x], %[c2]\n\t"                                                        \
+    "s_nop 1\n\t"                                                                                  \
+    "v_add_f32 %[dv], %[dv], %[x]\n\t"                                                             \
+    "v_add_f32 %[dv], %[dv], %[c2]\n\t"
+template <int ORDER, bool RES>
+__device__ __forceinline__ void duo_step(float& RJ, const float RM, float& dv, float LO, float HI, float E2355,
+                                         unsigned long long lowmask, float& lsq) {
+    float t, x, dF, dS, c2;
+    float s0, s1, s2, s3, s4;
+    // F = first row, S = second row.  Dots land in lane 31 (lower row) / 63 (upper row), the
+    // accumulated impulses sit in lanes 23 / 55; v_cndmask gives every lane its own half's dI
+    // (mask = lower half -> takes the lower row's value).
+    if (ORDER == 0) {
+        asm volatile(SNK_DUO_ASM("v_cndmask_b32_e64 %[t], %[dS], %[dF], %[lowmask]\n\t")
+                     : [t] "=&v"(t), [x] "=&v"(x), [dF] "=&v"(dF), [dS] "=&v"(dS), [c2] "=&v"(c2), [s0] "=&s"(s0),
+                       [s1] "=&s"(s1), [s2] "=&s"(s2), [s3] "=&s"(s3), [s4] "=&s"(s4), [RJ] "+v"(RJ), [dv] "+v"(dv)
+                     : [RM] "v"(RM), [LO] "v"(LO), [HI] "v"(HI), [E] "v"(E2355), [lowmask] "s"(lowmask), [AF] "n"(23),
+                       [AS] "n"(55), [CL] "n"(57), [DF] "n"(31), [DS] "n"(63));
+    } else {
+        asm volatile(SNK_DUO_ASM("v_cndmask_b32_e64 %[t], %[dF], %[dS], %[lowmask]\n\t")
+                     : [t] "=&v"(t), [x] "=&v"(x), [dF] "=&v"(dF), [dS] "=&v"(dS), [c2] "=&v"(c2), [s0] "=&s"(s0),
+                       [s1] "=&s"(s1), [s2] "=&s"(s2), [s3] "=&s"(s3), [s4] "=&s"(s4), [RJ] "+v"(RJ), [dv] "+v"(dv)
+                     : [RM] "v"(RM), [LO] "v"(LO), [HI] "v"(HI), [E] "v"(E2355), [lowmask] "s"(lowmask), [AF] "n"(55),
+                       [AS] "n"(23), [CL] "n"(25), [DF] "n"(63), [DS] "n"(31));
+    }
     if (RES) {
         asm volatile("v_mul_f32 %[x], %[dI], %[RJ]\n\t"
                      "v_max_f32 %[lsq], %[lsq], |%[x]|\n\t"
                      "s_nop 1"
                      : [x] "=&v"(x), [lsq] "+v"(lsq)
-                     : [dI] "v"(dI), [RJ] "v"(RJ));
+                     : [dI] "v"(t), [RJ] "v"(RJ));
     } else {
         asm volatile("s_nop 1");
     }
@@ -357,9 +388,9 @@ __device__ __forceinline__ void cone_step(float& RJ, const float RM, const float
         "v_fma_f32 %[xB], %[r2], -%[s3], -%[xB]\n\t"
         "v_cndmask_b32_e64 %[t], %[xB], %[xA], %[lowmask]\n\t"
         "v_mul_f32 %[r2], %[RM], %[t]\n\t"
+        "v_mul_f32 %[c2], %[RM], %[t]\n\t"
         "v_fmac_f32 %[RJ], %[E], %[t]\n\t"
-        "v_mov_b32 %[c2], %[r2]\n\t"
-        "s_nop 1\n\t"
+        "s_nop 0\n\t"
         "v_permlane32_swap_b32 %[r2], %[c2]\n\t"
         "s_nop 1\n\t"
         "v_add_f32 %[dv], %[dv], %[r2]\n\t"
@@ -385,24 +416,27 @@ constexpr int kSlotNormal = 8;    // 32 slots
 constexpr int kSlotFric = 40;     // 64 slots
 constexpr int kSlots = 104;
 
-// eight consecutive single rows of half H (slots BASE..BASE+7, backwards if REV)
-template <int H, bool RES, int BASE, bool REV>
-__device__ __forceinline__ void rows8(float (&RJ)[kSlots], float (&RM)[kSlots], float& dv, float LO, float HI, float E,
-                                      float& lsq) {
+// four consecutive duo slots (8 rows): slots BASE..BASE+3, backwards if ORDER == 1
+template <int ORDER, bool RES, int BASE>
+__device__ __forceinline__ void duos4(float (&RJ)[kSlots], float (&RM)[kSlots], float& dv, float LO, float HI, float E2355,
+                                      unsigned long long lowmask, float& lsq) {
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const int s = BASE + (REV ? 7 - i : i);
-        row_step<H, RES>(RJ[s], RM[s], dv, LO, HI, E, lsq);
+    for (int i = 0; i < 4; i++) {
+        const int s = BASE + (ORDER ? 3 - i : i);
+        duo_step<ORDER, RES>(RJ[s], RM[s], dv, LO, HI, E2355, lowmask, lsq);
     }
 }
-// eight consecutive friction pairs (contacts 8G..8G+7)
+// eight consecutive friction pairs (contacts 8G..8G+7); the normal impulse of contact ci sits
+// in slot kSlotNormal + ci/2, lane 23 (even ci) or 55 (odd ci)
 template <bool RES, int G>
 __device__ __forceinline__ void cones8(float (&RJ)[kSlots], float (&RM)[kSlots], float& dv, float MU, float EPS,
                                        float E2355, unsigned long long lowmask, float& lsq) {
 #pragma unroll
-    for (int ci = 8 * G; ci < 8 * G + 8; ci++)
-        cone_step<(G < 4 ? 23 : 55), RES>(RJ[kSlotFric + ci], RM[kSlotFric + ci], RJ[kSlotNormal + (ci & 31)], dv, MU, EPS,
-                                          E2355, lowmask, lsq);
+    for (int i = 0; i < 4; i++) {
+        const int c0 = 8 * G + 2 * i;
+        cone_step<23, RES>(RJ[kSlotFric + c0], RM[kSlotFric + c0], RJ[kSlotNormal + (c0 >> 1)], dv, MU, EPS, E2355, lowmask, lsq);
+        cone_step<55, RES>(RJ[kSlotFric + c0 + 1], RM[kSlotFric + c0 + 1], RJ[kSlotNormal + (c0 >> 1)], dv, MU, EPS, E2355, lowmask, lsq);
+    }
 }
 
 template <class LT>
@@ -485,7 +519,7 @@ __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane, f
         build_batch_v2<LT, 1>(L, M, lane, nc);
 #pragma unroll
         for (int g = 0; g < 4; g++) {
-            if (nc > 8 * g) {
+            if (nc > 16 * g) {
 #pragma unroll
                 for (int s = 8 * g; s < 8 * g + 8; s++) load_slot<LT, 1>(L, K, s, nc, RJ[kSlotNormal + s], RM[kSlotNormal + s]);
             } else {
@@ -496,6 +530,29 @@ __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane, f
 #pragma unroll
         for (int s = 0; s < 8; s++) load_slot<LT, 0>(L, K, s, N, RJ[kSlotMotor + s], RM[kSlotMotor + s]);
         lds_sync();
+    }
+
+    // coupling scalars of the duos (motors and normals), once per substep:
+    //   lower lane 25 <- RJ_lower . RM_upper  (used when the upper row goes first),
+    //   upper lane 57 <- RJ_upper . RM_lower  (used when the lower row goes first)
+    {
+        const bool lo_ = lane < 32;
+#pragma unroll
+        for (int s = 0; s < kSlotFric; s++) {
+            swap2 sw = half_swap(RM[s], RM[s]);             // a = [RM_lower, RM_lower], b = [RM_upper, RM_upper]
+            float t = half_reduce(RJ[s] * (lo_ ? sw.b : sw.a));
+            float c_lo = rdlane(t, 31), c_up = rdlane(t, 63);
+            RJ[s] = wrlane(wrlane(RJ[s], c_lo, 25), c_up, 57);
+        }
+        if (M.cone == 0) {   // pyramid friction resolves the two directions one after the other
+#pragma unroll
+            for (int s = kSlotFric; s < kSlots; s++) {
+                swap2 sw = half_swap(RM[s], RM[s]);
+                float t = half_reduce(RJ[s] * (lo_ ? sw.b : sw.a));
+                float c_lo = rdlane(t, 31), c_up = rdlane(t, 63);
+                RJ[s] = wrlane(wrlane(RJ[s], c_lo, 25), c_up, 57);
+            }
+        }
     }
 
     // violated joint limits (rare): kept as LDS rows, processed by a generic path
@@ -530,8 +587,6 @@ __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane, f
         const int d = lane & 31;
         dv = d == 22 ? 1.0f : (d == 23 ? -1.0f : 0.0f);
         const float E2355 = d == 23 ? 1.0f : 0.0f;
-        const float E23 = lane == 23 ? 1.0f : 0.0f;
-        const float E55 = lane == 55 ? 1.0f : 0.0f;
         const float MU = mu;
         const float EPS = 1e-30f;
         const float mi = M.max_motor_imp;
@@ -548,8 +603,8 @@ __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane, f
             int exceeded = 0;
             int ncl = nc;
             asm volatile("" : "+s"(ncl));   // keeps the group-active compares from being hoisted and spilled
-            auto check = [&](float lsq, int la, int lb) {
-                float m = fmaxf(rdlane(lsq, la), rdlane(lsq, lb));
+            auto check = [&](float lsq) {
+                float m = fmaxf(rdlane(lsq, 24), rdlane(lsq, 56));
                 exceeded = __builtin_amdgcn_readfirstlane(m > thr ? 1 : 0);
             };
             auto limit_rows = [&](bool fwd) {
@@ -568,44 +623,33 @@ __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane, f
                     if (__builtin_amdgcn_readfirstlane(fabsf(dI * L.nc_den[idx]) > thr ? 1 : 0)) exceeded = 1;
                 }
             };
-            // give the other half the fresh copy of delta-v
-            auto sync_from_lower = [&]() { swap2 sw = half_swap(dv, dv); dv = sw.a; };
-            auto sync_from_upper = [&]() { swap2 sw = half_swap(dv, dv); dv = sw.b; };
-#define SNK_ROWS8(H, BASE, REV, LO, HI, E, LANE)                                                   \
-    if (exceeded) { float l_ = 0.f; rows8<H, false, BASE, REV>(RJ, RM, dv, LO, HI, E, l_); }        \
-    else { float l_ = 0.f; rows8<H, true, BASE, REV>(RJ, RM, dv, LO, HI, E, l_); check(l_, LANE, LANE); }
+#define SNK_DUOS4(ORDER, BASE, LO, HI)                                                              \
+    if (exceeded) { float l_ = 0.f; duos4<ORDER, false, BASE>(RJ, RM, dv, LO, HI, E2355, LOWMASK, l_); } \
+    else { float l_ = 0.f; duos4<ORDER, true, BASE>(RJ, RM, dv, LO, HI, E2355, LOWMASK, l_); check(l_); }
 #define SNK_CONES8(G)                                                                              \
     if (exceeded) { float l_ = 0.f; cones8<false, G>(RJ, RM, dv, MU, EPS, E2355, LOWMASK, l_); }    \
-    else { float l_ = 0.f; cones8<true, G>(RJ, RM, dv, MU, EPS, E2355, LOWMASK, l_); check(l_, 24, 56); }
+    else { float l_ = 0.f; cones8<true, G>(RJ, RM, dv, MU, EPS, E2355, LOWMASK, l_); check(l_); }
             // non-contact rows: list = [limits..., motors 0..15], walked forwards on odd
-            // iterations and backwards on even ones; motors 0..7 live in the lower halves
+            // iterations and backwards on even ones
             if (it & 1) {
                 limit_rows(true);
-                SNK_ROWS8(0, kSlotMotor, false, NMI, PMI, E23, 24)
-                sync_from_lower();
-                SNK_ROWS8(1, kSlotMotor, false, NMI, PMI, E55, 56)
-                sync_from_upper();
+                SNK_DUOS4(0, kSlotMotor, NMI, PMI)
+                SNK_DUOS4(0, kSlotMotor + 4, NMI, PMI)
             } else {
-                SNK_ROWS8(1, kSlotMotor, true, NMI, PMI, E55, 56)
-                sync_from_upper();
-                SNK_ROWS8(0, kSlotMotor, true, NMI, PMI, E23, 24)
-                sync_from_lower();
+                SNK_DUOS4(1, kSlotMotor + 4, NMI, PMI)
+                SNK_DUOS4(1, kSlotMotor, NMI, PMI)
                 limit_rows(false);
             }
-            // contact normals in contact order: 0..31 live in the lower halves, 32..63 in the
-            // upper; one scalar branch per group of 8, rows past the active count are inert
-            if (ncl > 0) { SNK_ROWS8(0, kSlotNormal + 0, false, ZERO, BIG, E23, 24) }
-            if (ncl > 8) { SNK_ROWS8(0, kSlotNormal + 8, false, ZERO, BIG, E23, 24) }
-            if (ncl > 16) { SNK_ROWS8(0, kSlotNormal + 16, false, ZERO, BIG, E23, 24) }
-            if (ncl > 24) { SNK_ROWS8(0, kSlotNormal + 24, false, ZERO, BIG, E23, 24) }
-            sync_from_lower();
-            if (ncl > 32) {
-                SNK_ROWS8(1, kSlotNormal + 0, false, ZERO, BIG, E55, 56)
-                if (ncl > 40) { SNK_ROWS8(1, kSlotNormal + 8, false, ZERO, BIG, E55, 56) }
-                if (ncl > 48) { SNK_ROWS8(1, kSlotNormal + 16, false, ZERO, BIG, E55, 56) }
-                if (ncl > 56) { SNK_ROWS8(1, kSlotNormal + 24, false, ZERO, BIG, E55, 56) }
-                sync_from_upper();
-            }
+            // contact normals in contact order, one scalar branch per 8 contacts; rows past the
+            // active count are inert zeros
+            if (ncl > 0) { SNK_DUOS4(0, kSlotNormal + 0, ZERO, BIG) }
+            if (ncl > 8) { SNK_DUOS4(0, kSlotNormal + 4, ZERO, BIG) }
+            if (ncl > 16) { SNK_DUOS4(0, kSlotNormal + 8, ZERO, BIG) }
+            if (ncl > 24) { SNK_DUOS4(0, kSlotNormal + 12, ZERO, BIG) }
+            if (ncl > 32) { SNK_DUOS4(0, kSlotNormal + 16, ZERO, BIG) }
+            if (ncl > 40) { SNK_DUOS4(0, kSlotNormal + 20, ZERO, BIG) }
+            if (ncl > 48) { SNK_DUOS4(0, kSlotNormal + 24, ZERO, BIG) }
+            if (ncl > 56) { SNK_DUOS4(0, kSlotNormal + 28, ZERO, BIG) }
             // friction pairs in contact order
             if (cone) {
                 if (ncl > 0) { SNK_CONES8(0) }
@@ -617,25 +661,24 @@ __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane, f
                 if (ncl > 48) { SNK_CONES8(6) }
                 if (ncl > 56) { SNK_CONES8(7) }
             } else {
-                // pyramid friction (not Bullet's default here): the two directions as single rows
+                // pyramid friction (not Bullet's default here): a duo whose rows do not see each
+                // other... they DO in Bullet's pyramid (sequential rows), so use the duo step with
+                // its coupling scalar, bounds +-mu*lambda_n
 #pragma unroll
                 for (int g = 0; g < 8; g++) {
                     if (ncl > 8 * g) {
 #pragma unroll
                         for (int ci = 8 * g; ci < 8 * g + 8; ci++) {
-                            float lim = rdlane(RJ[kSlotNormal + (ci & 31)], (ci & 32) ? 55 : 23) * MU;
+                            float lim = rdlane(RJ[kSlotNormal + (ci >> 1)], (ci & 1) ? 55 : 23) * MU;
                             float nlim_ = -lim, lsq = 0.f;
                             // lim == 0 clamps both impulses to 0 (Bullet skips the rows: same result)
-                            row_step<0, true>(RJ[kSlotFric + ci], RM[kSlotFric + ci], dv, nlim_, lim, E23, lsq);
-                            sync_from_lower();
-                            row_step<1, true>(RJ[kSlotFric + ci], RM[kSlotFric + ci], dv, nlim_, lim, E55, lsq);
-                            sync_from_upper();
-                            if (!exceeded) exceeded = __builtin_amdgcn_readfirstlane(fmaxf(rdlane(lsq, 24), rdlane(lsq, 56)) > thr ? 1 : 0);
+                            duo_step<0, true>(RJ[kSlotFric + ci], RM[kSlotFric + ci], dv, nlim_, lim, E2355, LOWMASK, lsq);
+                            if (!exceeded) check(lsq);
                         }
                     }
                 }
             }
-#undef SNK_ROWS8
+#undef SNK_DUOS4
 #undef SNK_CONES8
             if (!exceeded || it >= n_iter - 1) { it++; break; }
         }
@@ -654,7 +697,7 @@ __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane, f
         f3 eN = mk3(0, 0, 0), eF = mk3(0, 0, 0);
         for (int ci = 0; ci < nc; ci++) {
             if (L.ccbody[ci] == b) {
-                f3 F = (mk3(0.f, 0.f, 1.f) * L.app[2 * (kSlotNormal + (ci & 31)) + (ci >> 5)] +
+                f3 F = (mk3(0.f, 0.f, 1.f) * L.app[2 * kSlotNormal + ci] +
                         ld3(L.ccdir[ci][0]) * L.app[2 * (kSlotFric + ci)] +
                         ld3(L.ccdir[ci][1]) * L.app[2 * (kSlotFric + ci) + 1]) * M.inv_dt;
                 eF = eF + F;
@@ -664,7 +707,7 @@ __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane, f
         st3(&L.ext[b][0], eN);
         st3(&L.ext[b][3], eF);
     }
-    if (lane < N) L.tauj[lane] = -M.joint_damp * L.qd_old[lane] + L.app[2 * (lane & 7) + (lane >> 3)] * M.inv_dt;
+    if (lane < N) L.tauj[lane] = -M.joint_damp * L.qd_old[lane] + L.app[lane] * M.inv_dt;
     lds_sync();
     if (lane == 0) {
         for (int i = 0; i < nlim; i++) L.tauj[L.nc_joint[i]] += L.nc_sign[i] * L.nc_app[i] * M.inv_dt;
@@ -704,7 +747,7 @@ __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane, f
         L.qd()[lane - 6] = x;
         L.q()[lane - 6] += dt * x;
     }
-    if (lane < N) L.taum()[lane] = L.app[2 * (lane & 7) + (lane >> 3)] * M.inv_dt;
+    if (lane < N) L.taum()[lane] = L.app[lane] * M.inv_dt;
     lds_sync();
     {
         float* bs = L.base();

@@ -247,3 +247,33 @@ def test_device_vec_env_torch(pkg):
     assert np.array_equal(done.cpu().numpy().astype(bool), hd)
     assert float(ta.abs().max()) <= 1.0
     env.close()
+
+
+def test_sharded_env_over_rccl_world1(pkg):
+    """The RCCL (backend 'nccl') scatter/gather path of ShardedVecEnv with a single rank:
+    same calls the N-GPU bench makes, results equal the unsharded device env."""
+    import os
+    import socket
+    import torch
+    import torch.distributed as dist
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        B = 64
+        local = pkg.DeviceVecEnv(B, device_index=0)
+        ref = pkg.DeviceVecEnv(B, device_index=0)
+        env = pkg.ShardedVecEnv(local, root=0, device=torch.device("cuda", 0))
+        o0 = env.reset(); r0 = ref.reset()
+        torch.cuda.synchronize()
+        assert torch.equal(o0, r0)
+        for j in range(3):
+            a = torch.from_numpy(gait(range(B), j)).cuda()
+            obs, rew, done, infos = env.step(a.clone())
+            o2, r2, d2 = ref.step(a.clone())
+            torch.cuda.synchronize()
+            assert len(infos) == B
+            assert torch.equal(obs, o2) and torch.equal(rew, r2) and torch.equal(done, d2.bool())
+    finally:
+        dist.destroy_process_group()
