@@ -661,19 +661,20 @@ __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane, f
                 if (ncl > 48) { SNK_CONES8(6) }
                 if (ncl > 56) { SNK_CONES8(7) }
             } else {
-                // pyramid friction (not Bullet's default here): a duo whose rows do not see each
-                // other... they DO in Bullet's pyramid (sequential rows), so use the duo step with
-                // its coupling scalar, bounds +-mu*lambda_n
+                // pyramid friction (not Bullet's default here): the two directions are resolved one
+                // after the other (a duo with its coupling scalar), bounds +-mu*lambda_n, and -- as
+                // in Bullet -- skipped altogether while the normal impulse is zero
 #pragma unroll
                 for (int g = 0; g < 8; g++) {
                     if (ncl > 8 * g) {
 #pragma unroll
                         for (int ci = 8 * g; ci < 8 * g + 8; ci++) {
                             float lim = rdlane(RJ[kSlotNormal + (ci >> 1)], (ci & 1) ? 55 : 23) * MU;
-                            float nlim_ = -lim, lsq = 0.f;
-                            // lim == 0 clamps both impulses to 0 (Bullet skips the rows: same result)
-                            duo_step<0, true>(RJ[kSlotFric + ci], RM[kSlotFric + ci], dv, nlim_, lim, E2355, LOWMASK, lsq);
-                            if (!exceeded) check(lsq);
+                            if (__builtin_amdgcn_readfirstlane(lim > 0.f ? 1 : 0)) {
+                                float nlim_ = -lim, lsq = 0.f;
+                                duo_step<0, true>(RJ[kSlotFric + ci], RM[kSlotFric + ci], dv, nlim_, lim, E2355, LOWMASK, lsq);
+                                if (!exceeded) check(lsq);
+                            }
                         }
                     }
                 }

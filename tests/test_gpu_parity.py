@@ -96,3 +96,89 @@ def test_single_substep_parity(pkg, oracle_mod, case):
     assert err_q < tol_q
     assert err_v < tol_v
     assert err_q < 2 * cq + 1e-6 and err_v < 2 * cv + 1e-5
+
+
+def _substep_compare(pkg, oracle_mod, S, T, k=1, n=16, **over):
+    B = S.shape[0]
+    st = pkg.Stepper(B, n_modules=n, **over)
+    S32 = S.astype(np.float32)
+    st.set_state(S32)
+    info = st.substep(T.astype(np.float32), k)
+    G, Gaux = st.get_state()
+    refs, its, ncs = [], [], []
+    for i in range(B):
+        o = oracle_mod.OracleEnv(n_modules=n, **over)
+        o.set_state(S32[i].astype(np.float64))
+        for _ in range(k):
+            o.substep(T[i].astype(np.float32).astype(np.float64))
+        refs.append(o.get_state()); its.append(o.last_iterations); ncs.append(o.last_num_contacts)
+    return G, Gaux, info, np.array(refs), np.array(its), np.array(ncs)
+
+
+def test_rare_branch_pyramid_friction(pkg, oracle_mod):
+    """cone_friction=0: the two friction directions are resolved one after the other."""
+    n, B = 16, 16
+    rng = np.random.default_rng(77)
+    S = np.array([random_state(rng, n, z=0.026, qamp=0.3, vamp=0.3, flat=True) for _ in range(B)])
+    S[:, 7:9] *= 0.1; S[:, 9] *= 0.1
+    T = rng.uniform(-0.5, 0.5, (B, n))
+    G, _, info, R, its, ncs = _substep_compare(pkg, oracle_mod, S, T, cone_friction=0, residual_threshold=0.0)
+    assert np.array_equal(info[:, 1], ncs) and np.array_equal(info[:, 0], its)
+    # the box-clamped rows switch on/off with the normal impulse: a little more sensitive to
+    # float32 round-off than the cone (measured 3e-4)
+    assert np.abs(G[:, :7] - R[:, :7]).max() < 2e-4 and np.abs(G[:, 13:29] - R[:, 13:29]).max() < 1e-3
+    assert (np.abs(G[:, 29:] - R[:, 29:]) / (1 + np.abs(R[:, 29:]))).max() < 5e-2
+
+
+def test_rare_branch_joint_limits(pkg, oracle_mod):
+    """Joints beyond +-1.57 create limit rows (kept in LDS, generic path)."""
+    n, B = 16, 8
+    rng = np.random.default_rng(78)
+    S = np.array([random_state(rng, n, z=2.0, qamp=0.3, vamp=0.3) for _ in range(B)])
+    for i in range(B):
+        S[i, 13 + (2 * i) % n] = 1.6 + 0.01 * i          # above the upper limit
+        S[i, 13 + (2 * i + 5) % n] = -1.62               # below the lower limit
+        S[i, 13 + n + (2 * i) % n] = 0.5
+    T = rng.uniform(-0.5, 0.5, (B, n))
+    # finite motor force so that the limit rows visibly act against the motors
+    G, _, info, R, its, ncs = _substep_compare(pkg, oracle_mod, S, T, max_motor_impulse=0.05, residual_threshold=0.0)
+    assert np.all(info[:, 1] == 0) and np.array_equal(info[:, 0], its)
+    assert np.abs(G[:, 13:29] - R[:, 13:29]).max() < 2e-5
+    assert (np.abs(G[:, 29:] - R[:, 29:]) / (1 + np.abs(R[:, 29:]))).max() < 2e-3
+
+
+def test_rare_branch_early_exit(pkg, oracle_mod):
+    """Bullet's residual early exit: at rest in the air with targets == q the first sweep already
+    has a zero residual; the GPU must leave after the same number of iterations."""
+    n, B = 16, 4
+    S = np.zeros((B, 13 + 2 * n)); S[:, 2] = 3.0; S[:, 6] = 1.0
+    rng = np.random.default_rng(79)
+    S[:, 13:13 + n] = rng.uniform(-0.3, 0.3, (B, n))
+    T = S[:, 13:13 + n].copy()
+    G, _, info, R, its, ncs = _substep_compare(pkg, oracle_mod, S, T, joint_damping=0.0, lin_damping=0.0, ang_damping=0.0,
+                                               gravity_z=0.0)
+    assert np.all(its < 50) and np.array_equal(info[:, 0], its), (info[:, 0], its)
+    assert np.abs(G - R).max() < 1e-5
+    # and with gravity the motors must hold the pose: many iterations, same count on both sides
+    G, _, info, R, its, ncs = _substep_compare(pkg, oracle_mod, S, T)
+    assert np.array_equal(info[:, 0], its)
+
+
+def test_partial_contact_sets(pkg, oracle_mod):
+    """Snake pitched so that only some cylinders are within the contact threshold: contact
+    counts that are not multiples of the group size (8) and in both halves."""
+    n = 16
+    states = []
+    for ang in (0.02, 0.04, 0.08, 0.15, 0.3):
+        s = np.zeros(13 + 2 * n)
+        # pitch about y lifts the tail (the chain extends along -x): nose stays near the ground
+        s[3:7] = [0, np.sin(ang / 2), 0, np.cos(ang / 2)]
+        s[2] = 0.002
+        states.append(s)
+    S = np.array(states)
+    T = np.zeros((len(states), n))
+    G, _, info, R, its, ncs = _substep_compare(pkg, oracle_mod, S, T, residual_threshold=0.0)
+    assert np.array_equal(info[:, 1], ncs), (info[:, 1], ncs)
+    assert len(set(ncs.tolist())) >= 3 and any(c % 8 for c in ncs)          # really partial sets
+    assert np.abs(G[:, :7] - R[:, :7]).max() < 2e-4 and np.abs(G[:, 13:29] - R[:, 13:29]).max() < 2e-4
+    assert (np.abs(G[:, 29:] - R[:, 29:]) / (1 + np.abs(R[:, 29:]))).max() < 2e-2
