@@ -509,6 +509,7 @@ __device__ void aba_main(LT& L, const DevModel& M, int lane) {
         }
     }
     lds_sync();
+    if (!FACTOR) return;   // the sensor pass only needs the base acceleration (acc0)
     // forward sweep: joint accelerations
     f3 al = ld3(&L.acc0[0]), a = ld3(&L.acc0[3]);
     for (int b = 1; b <= N; b++) {

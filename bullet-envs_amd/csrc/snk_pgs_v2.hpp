@@ -354,22 +354,22 @@ __device__ __forceinline__ void duo_step(float& RJ, const float RM, float& dv, f
 // Bullet's cone-friction pair (hand-written, 28 VALU): direction A in the lower half and B in
 // the upper half of one register, so one reduction yields both dots; the accumulated pair is
 // projected radially onto the disc of radius mu * lambda_n (the normal's accumulated impulse:
-// lane NL of RJnorm); the two contributions to delta-v cross halves with v_permlane32_swap.
+// kept pre-multiplied in lane NL+4 of RJnorm); the two contributions to delta-v cross halves with v_permlane32_swap.
 template <int NL, bool RES>
-__device__ __forceinline__ void cone_step(float& RJ, const float RM, const float RJnorm, float& dv, float MU, float EPS,
+__device__ __forceinline__ void cone_step(float& RJ, const float RM, const float RJnorm, float& dv, float EPS,
                                           float E2355, unsigned long long lowmask, float& lsq) {
-    float t, xA, xB, r2, c2, lim;
+    float t, xA, xB, r2, c2;
     float s0, s1, s2, s3, s4;
     asm volatile(
         "v_mul_f32 %[t], %[RJ], %[dv]\n\t"
-        "v_readlane_b32 %[s4], %[RJnorm], %[NLn]\n\t"
+        "v_readlane_b32 %[s4], %[RJnorm], %[NLn]\n\t"     // mu * lambda_n, kept in lane 27 / 59 of the normal
         "v_readlane_b32 %[s0], %[RJ], 23\n\t"
         "v_add_f32_dpp %[t], %[t], %[t] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
         "v_readlane_b32 %[s2], %[RJ], 55\n\t"
-        "v_mul_f32 %[lim], %[s4], %[MU]\n\t"
-        "v_add_f32_dpp %[t], %[t], %[t] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
         "v_mov_b32 %[xA], %[s0]\n\t"
+        "v_add_f32_dpp %[t], %[t], %[t] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
         "v_mov_b32 %[xB], %[s2]\n\t"
+        "s_nop 0\n\t"
         "v_add_f32_dpp %[t], %[t], %[t] row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
         "s_nop 1\n\t"
         "v_add_f32_dpp %[t], %[t], %[t] row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
@@ -383,7 +383,7 @@ __device__ __forceinline__ void cone_step(float& RJ, const float RM, const float
         "v_fma_f32 %[r2], %[s3], %[s3], %[r2]\n\t"
         "v_rsq_f32 %[r2], %[r2]\n\t"
         "s_nop 1\n\t"
-        "v_mul_f32_e64 %[r2], %[lim], %[r2] clamp\n\t"
+        "v_mul_f32_e64 %[r2], %[s4], %[r2] clamp\n\t"
         "v_fma_f32 %[xA], %[r2], -%[s1], -%[xA]\n\t"
         "v_fma_f32 %[xB], %[r2], -%[s3], -%[xB]\n\t"
         "v_cndmask_b32_e64 %[t], %[xB], %[xA], %[lowmask]\n\t"
@@ -395,10 +395,10 @@ __device__ __forceinline__ void cone_step(float& RJ, const float RM, const float
         "s_nop 1\n\t"
         "v_add_f32 %[dv], %[dv], %[r2]\n\t"
         "v_add_f32 %[dv], %[dv], %[c2]\n\t"
-        : [t] "=&v"(t), [xA] "=&v"(xA), [xB] "=&v"(xB), [r2] "=&v"(r2), [c2] "=&v"(c2), [lim] "=&v"(lim),
+        : [t] "=&v"(t), [xA] "=&v"(xA), [xB] "=&v"(xB), [r2] "=&v"(r2), [c2] "=&v"(c2),
           [s0] "=&s"(s0), [s1] "=&s"(s1), [s2] "=&s"(s2), [s3] "=&s"(s3), [s4] "=&s"(s4), [RJ] "+v"(RJ), [dv] "+v"(dv)
-        : [RM] "v"(RM), [RJnorm] "v"(RJnorm), [MU] "v"(MU), [EPS] "v"(EPS), [E] "v"(E2355), [lowmask] "s"(lowmask),
-          [NLn] "n"(NL));
+        : [RM] "v"(RM), [RJnorm] "v"(RJnorm), [EPS] "v"(EPS), [E] "v"(E2355), [lowmask] "s"(lowmask),
+          [NLn] "n"(NL + 4));
     if (RES) {
         asm volatile("v_mul_f32 %[x], %[dI], %[RJ]\n\t"
                      "v_max_f32 %[lsq], %[lsq], |%[x]|\n\t"
@@ -429,13 +429,13 @@ __device__ __forceinline__ void duos4(float (&RJ)[kSlots], float (&RM)[kSlots], 
 // eight consecutive friction pairs (contacts 8G..8G+7); the normal impulse of contact ci sits
 // in slot kSlotNormal + ci/2, lane 23 (even ci) or 55 (odd ci)
 template <bool RES, int G>
-__device__ __forceinline__ void cones8(float (&RJ)[kSlots], float (&RM)[kSlots], float& dv, float MU, float EPS,
-                                       float E2355, unsigned long long lowmask, float& lsq) {
+__device__ __forceinline__ void cones8(float (&RJ)[kSlots], float (&RM)[kSlots], float& dv, float EPS, float E2355,
+                                       unsigned long long lowmask, float& lsq) {
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const int c0 = 8 * G + 2 * i;
-        cone_step<23, RES>(RJ[kSlotFric + c0], RM[kSlotFric + c0], RJ[kSlotNormal + (c0 >> 1)], dv, MU, EPS, E2355, lowmask, lsq);
-        cone_step<55, RES>(RJ[kSlotFric + c0 + 1], RM[kSlotFric + c0 + 1], RJ[kSlotNormal + (c0 >> 1)], dv, MU, EPS, E2355, lowmask, lsq);
+        cone_step<23, RES>(RJ[kSlotFric + c0], RM[kSlotFric + c0], RJ[kSlotNormal + (c0 >> 1)], dv, EPS, E2355, lowmask, lsq);
+        cone_step<55, RES>(RJ[kSlotFric + c0 + 1], RM[kSlotFric + c0 + 1], RJ[kSlotNormal + (c0 >> 1)], dv, EPS, E2355, lowmask, lsq);
     }
 }
 
@@ -588,6 +588,7 @@ __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane, f
         dv = d == 22 ? 1.0f : (d == 23 ? -1.0f : 0.0f);
         const float E2355 = d == 23 ? 1.0f : 0.0f;
         const float MU = mu;
+        const float ENORM = d == 23 ? 1.0f : (d == 27 ? mu : 0.0f);   // normals also keep mu*lambda_n (lane 27/59)
         const float EPS = 1e-30f;
         const float mi = M.max_motor_imp;
         const float NMI = -mi, PMI = mi, ZERO = 0.f, BIG = 1e10f;
@@ -626,9 +627,12 @@ __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane, f
 #define SNK_DUOS4(ORDER, BASE, LO, HI)                                                              \
     if (exceeded) { float l_ = 0.f; duos4<ORDER, false, BASE>(RJ, RM, dv, LO, HI, E2355, LOWMASK, l_); } \
     else { float l_ = 0.f; duos4<ORDER, true, BASE>(RJ, RM, dv, LO, HI, E2355, LOWMASK, l_); check(l_); }
+#define SNK_DUOS4N(BASE)                                                                            \
+    if (exceeded) { float l_ = 0.f; duos4<0, false, BASE>(RJ, RM, dv, ZERO, BIG, ENORM, LOWMASK, l_); }  \
+    else { float l_ = 0.f; duos4<0, true, BASE>(RJ, RM, dv, ZERO, BIG, ENORM, LOWMASK, l_); check(l_); }
 #define SNK_CONES8(G)                                                                              \
-    if (exceeded) { float l_ = 0.f; cones8<false, G>(RJ, RM, dv, MU, EPS, E2355, LOWMASK, l_); }    \
-    else { float l_ = 0.f; cones8<true, G>(RJ, RM, dv, MU, EPS, E2355, LOWMASK, l_); check(l_); }
+    if (exceeded) { float l_ = 0.f; cones8<false, G>(RJ, RM, dv, EPS, E2355, LOWMASK, l_); }    \
+    else { float l_ = 0.f; cones8<true, G>(RJ, RM, dv, EPS, E2355, LOWMASK, l_); check(l_); }
             // non-contact rows: list = [limits..., motors 0..15], walked forwards on odd
             // iterations and backwards on even ones
             if (it & 1) {
@@ -642,14 +646,14 @@ __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane, f
             }
             // contact normals in contact order, one scalar branch per 8 contacts; rows past the
             // active count are inert zeros
-            if (ncl > 0) { SNK_DUOS4(0, kSlotNormal + 0, ZERO, BIG) }
-            if (ncl > 8) { SNK_DUOS4(0, kSlotNormal + 4, ZERO, BIG) }
-            if (ncl > 16) { SNK_DUOS4(0, kSlotNormal + 8, ZERO, BIG) }
-            if (ncl > 24) { SNK_DUOS4(0, kSlotNormal + 12, ZERO, BIG) }
-            if (ncl > 32) { SNK_DUOS4(0, kSlotNormal + 16, ZERO, BIG) }
-            if (ncl > 40) { SNK_DUOS4(0, kSlotNormal + 20, ZERO, BIG) }
-            if (ncl > 48) { SNK_DUOS4(0, kSlotNormal + 24, ZERO, BIG) }
-            if (ncl > 56) { SNK_DUOS4(0, kSlotNormal + 28, ZERO, BIG) }
+            if (ncl > 0) { SNK_DUOS4N(kSlotNormal + 0) }
+            if (ncl > 8) { SNK_DUOS4N(kSlotNormal + 4) }
+            if (ncl > 16) { SNK_DUOS4N(kSlotNormal + 8) }
+            if (ncl > 24) { SNK_DUOS4N(kSlotNormal + 12) }
+            if (ncl > 32) { SNK_DUOS4N(kSlotNormal + 16) }
+            if (ncl > 40) { SNK_DUOS4N(kSlotNormal + 20) }
+            if (ncl > 48) { SNK_DUOS4N(kSlotNormal + 24) }
+            if (ncl > 56) { SNK_DUOS4N(kSlotNormal + 28) }
             // friction pairs in contact order
             if (cone) {
                 if (ncl > 0) { SNK_CONES8(0) }
@@ -680,6 +684,7 @@ __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane, f
                 }
             }
 #undef SNK_DUOS4
+#undef SNK_DUOS4N
 #undef SNK_CONES8
             if (!exceeded || it >= n_iter - 1) { it++; break; }
         }
