@@ -157,7 +157,7 @@ struct Lds<N, true> : LdsCommon<N> {
     float ccP[NC][3], ccdist[NC], ccdir[NC][2][3];        // indexed by COMPACT contact index
     int ccbody[NC];
     float stM[64][25];           // staging of one 64-row batch: M^-1 J^T [22], rhs, den, 1/den
-    float MmS[N][3];             // the motors' rhs, den, 1/den (their M^-1 rows are Mm)
+    float MmS[N][4];             // the motors' rhs, den, 1/den, target velocity change (their M^-1 rows are Mm)
     float fz_park;               // first-pass part of the joint-0 force, parked across the solve
     float app[2 * (N / 2 + NC / 2 + NC)];   // accumulated impulses by (register slot, half)
 };

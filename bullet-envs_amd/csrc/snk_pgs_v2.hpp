@@ -226,6 +226,7 @@ __device__ void build_batch_v2(LT& L, const DevModel& M, int lane, int nc) {
         S[0] = target * dinv;
         S[1] = den;
         S[2] = dinv;
+        if (motor) S[3] = target;
     }
     lds_sync();
 }
@@ -241,24 +242,26 @@ struct LaneK {
 };
 
 // Fill the halves of one register slot from the rows staged by the last batch.
-// KIND 0 motor (row = 2s + h, from L.Mm), 1 normal (contact 2s + h; both halves),
-// 2 friction A (contact s -> lower half only), 3 friction B (contact s -> upper half only).
+// KIND 1 normal (contact 2s + h; both halves), 2 friction A (contact s -> lower half only),
+// 3 friction B (contact s -> upper half only).
+//   RJ: d < 22  J[d] / den * sJ,   d == 22  -rhs * sJ,   d == 31  accumulated impulse (0)
+//   RM: d < 22  (M^-1 J^T)[d] * sM, d == 24  den * sM
+// Friction rows are built in units of mu (sJ = 1/mu, sM = mu): the impulse variable is
+// f / mu, so the cone radius is lambda_n itself and mu never appears in the solve loop;
+// dI * den (the residual) is unchanged.  mu == 0 gives inert zero rows.
 template <class LT, int KIND>
-__device__ __forceinline__ void load_slot(LT& L, const LaneK& K, int s, int count, float& RJ, float& RM) {
-    const int row = (KIND == 0 || KIND == 1) ? 2 * s + K.h : s;
+__device__ __forceinline__ void load_slot(LT& L, const LaneK& K, int s, int count, float sJ, float sM, float& RJ, float& RM) {
+    const int row = KIND == 1 ? 2 * s + K.h : s;
     const bool valid = row < count;
     const int rs = valid ? row : 0;
-    // staged normals: rows 0..31 of the batch sit in staging rows 0..31, rows 32..63 after them
-    const float* st = KIND == 0 ? L.Mm[rs] : L.stM[rs];
-    const float* sc = KIND == 0 ? L.MmS[rs] : &L.stM[rs][22];
+    const float* st = L.stM[rs];
+    const float* sc = &L.stM[rs][22];
     const int dd = K.isdof ? K.d : 0;
     float mval = st[dd];
     float dinv = sc[2];
     float sp = sc[K.spoff];
     float jd;
-    if (KIND == 0) {
-        jd = (K.d == 6 + rs) ? 1.0f : 0.0f;
-    } else {
+    {
         f3 P = ld3(L.ccP[rs]);
         f3 dir = KIND == 1 ? mk3(0.f, 0.f, 1.f) : ld3(L.ccdir[rs][KIND == 2 ? 0 : 1]);
         const int k = L.ccbody[rs];
@@ -266,8 +269,8 @@ __device__ __forceinline__ void load_slot(LT& L, const LaneK& K, int s, int coun
         v = K.d == 3 ? dir.x : (K.d == 4 ? dir.y : (K.d == 5 ? dir.z : v));
         jd = (K.bL <= k) ? v : 0.0f;
     }
-    float rj = K.isdof ? jd * dinv : sp * K.m22 + sp * K.m24;
-    float rm = K.isdof ? mval : 0.0f;
+    float rj = (K.isdof ? jd * dinv : sp * K.m22) * sJ;
+    float rm = (K.isdof ? mval : sp * K.m24) * sM;
     if (!valid) { rj = 0.f; rm = 0.f; }
     const bool mine = KIND == 2 ? (K.h == 0) : (KIND == 3 ? (K.h == 1) : true);
     RJ = mine ? rj : RJ;
@@ -279,103 +282,116 @@ __device__ __forceinline__ float wrlane(float old, float v_uniform, int l) {
     return ((int)threadIdx.x == l) ? v_uniform : old;
 }
 
-// Two consecutive single rows living in the two halves of one slot (hand-written, 25 VALU).
-// ORDER 0: lower-half row first, then the upper-half row (coupling scalar in lane 57);
-// ORDER 1: upper first, then lower (coupling in lane 25) -- motors are walked backwards on
-// even iterations.  For each row:  a' = med3(-dot, LO, HI), dI = a' - a; the second row's dot
-// first receives  c * dI_first.  Both contributions are exchanged between the halves, and the
-// accumulated impulses (lane 23 / 55) are updated through E2355.
-// RES: also accumulate max |dI * den| (lane 24 / 56) into lsq.
-#define SNK_DUO_ASM(SEL)                                                                          \
-    "v_mul_f32 %[t], %[RJ], %[dv]\n\t"                                                             \
-    "v_readlane_b32 %[s2], %[RJ], %[AF]\n\t"                                                       \
-    "v_readlane_b32 %[s3], %[RJ], %[AS]\n\t"                                                       \
-    "v_add_f32_dpp %[t], %[t], %[t] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
-    "v_readlane_b32 %[s4], %[RJ], %[CL]\n\t"                                                       \
-    "s_nop 0\n\t"                                                                                  \
-    "v_add_f32_dpp %[t], %[t], %[t] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
-    "s_nop 1\n\t"                                                                                  \
+// DPP sum over each 32-lane half of %[t]; results in lane 31 / 63.  A dependent DPP read needs
+// 2 wait states after the VALU write (s_nop 1); the other wave of the SIMD issues into them.
+// Measured on MI355X (tools/ubench_lat.hip): a dependent v_add_f32_dpp step costs 12.6 clocks,
+// a plain dependent VALU 5, v_readlane -> VALU use ~20, so the five reduction steps are the
+// longest part of a row step; the scalar v_readlanes are placed in their shadow.
+#define SNK_REDUCE_12 \
+    "v_add_f32_dpp %[t], %[t], %[t] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+#define SNK_REDUCE_22 \
+    "v_add_f32_dpp %[t], %[t], %[t] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+#define SNK_REDUCE_345                                                                            \
     "v_add_f32_dpp %[t], %[t], %[t] row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"         \
     "s_nop 1\n\t"                                                                                  \
     "v_add_f32_dpp %[t], %[t], %[t] row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"         \
     "s_nop 1\n\t"                                                                                  \
     "v_add_f32_dpp %[t], %[t], %[t] row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"                   \
-    "s_nop 1\n\t"                                                                                  \
-    "v_readlane_b32 %[s0], %[t], %[DF]\n\t"                                                        \
-    "v_readlane_b32 %[s1], %[t], %[DS]\n\t"                                                        \
-    "s_nop 0\n\t"                                                                                  \
-    "v_med3_f32 %[dF], -%[s0], %[LO], %[HI]\n\t"                                                   \
-    "v_mov_b32 %[x], %[s1]\n\t"                                                                    \
-    "v_subrev_f32 %[dF], %[s2], %[dF]\n\t"                                                         \
-    "v_fmac_f32 %[x], %[s4], %[dF]\n\t"                                                            \
-    "v_med3_f32 %[x], -%[x], %[LO], %[HI]\n\t"                                                     \
-    "v_subrev_f32 %[dS], %[s3], %[x]\n\t"                                                          \
-    SEL                                                                                            \
-    "v_mul_f32 %[x], %[RM], %[t]\n\t"                                                              \
-    "v_mul_f32 %[c2], %[RM], %[t]\n\t"                                                             \
-    "v_fmac_f32 %[RJ], %[E], %[t]\n\t"                                                             \
-    "s_nop 0\n\t"                                                                                  \
-    "v_permlane32_swap_b32 %[x], %[c2]\n\t"                                                        \
-    "s_nop 1\n\t"                                                                                  \
-    "v_add_f32 %[dv], %[dv], %[x]\n\t"                                                             \
+    "s_nop 1\n\t"
+
+// Two consecutive single rows living in the two halves of one slot (hand-written, 25 VALU):
+// lower-half row first, then the upper-half row.  One multiply and one reduction give both
+// sums  -(rhs - J.dv/den + a)  in lanes 31 / 63; they, the accumulated impulses (lanes 31 / 63
+// of RJ) and the coupling scalar c (lane 57 of RJ; delta-v is 0 there) are read into SGPRs and the clamps run on
+// wave-uniform values:  a' = med3(-sum, LO, HI), dI = a' - a;  the upper row's sum first
+// receives c * dI_lower.  v_cndmask gives every lane its own half's dI; the two contributions
+// to delta-v cross halves with v_permlane32_swap.  RES: also max |dI * den| (den: lane 24 / 56
+// of RM) into lsq.
+#define SNK_DUO_HEAD                                     \
+    "v_mul_f32 %[t], %[RJ], %[dv]\n\t"                    \
+    "v_readlane_b32 %[s2], %[RJ], 31\n\t"                 \
+    "v_readlane_b32 %[s3], %[RJ], 63\n\t"                 \
+    SNK_REDUCE_12                                          \
+    "v_readlane_b32 %[s4], %[RJ], 57\n\t"                 \
+    "s_nop 0\n\t"                                         \
+    SNK_REDUCE_22                                          \
+    "s_nop 1\n\t"                                         \
+    SNK_REDUCE_345                                         \
+    "v_readlane_b32 %[s0], %[t], 31\n\t"                  \
+    "v_readlane_b32 %[s1], %[t], 63\n\t"                  \
+    "s_nop 0\n\t"
+#define SNK_DUO_TAIL                                     \
+    "v_cndmask_b32_e64 %[t], %[dS], %[dF], %[lowmask]\n\t" \
+    "v_mul_f32 %[x], %[RM], %[t]\n\t"                     \
+    "v_mul_f32 %[c2], %[RM], %[t]\n\t"                    \
+    "v_fmac_f32 %[RJ], %[E], %[t]\n\t"                    \
+    "s_nop 0\n\t"                                         \
+    "v_permlane32_swap_b32 %[x], %[c2]\n\t"               \
+    "s_nop 1\n\t"                                         \
+    "v_add_f32 %[dv], %[dv], %[x]\n\t"                    \
     "v_add_f32 %[dv], %[dv], %[c2]\n\t"
-template <int ORDER, bool RES>
-__device__ __forceinline__ void duo_step(float& RJ, const float RM, float& dv, float LO, float HI, float E2355,
+// BOX = false: contact normals, bounds [0, inf) -> a single v_max; BOX = true: [-HI, HI]
+template <bool RES, bool BOX>
+__device__ __forceinline__ void duo_step(float& RJ, const float RM, float& dv, float HI, float E3163,
                                          unsigned long long lowmask, float& lsq) {
     float t, x, dF, dS, c2;
     float s0, s1, s2, s3, s4;
-    // F = first row, S = second row.  Dots land in lane 31 (lower row) / 63 (upper row), the
-    // accumulated impulses sit in lanes 23 / 55; v_cndmask gives every lane its own half's dI
-    // (mask = lower half -> takes the lower row's value).
-    if (ORDER == 0) {
-        asm volatile(SNK_DUO_ASM("v_cndmask_b32_e64 %[t], %[dS], %[dF], %[lowmask]\n\t")
-                     : [t] "=&v"(t), [x] "=&v"(x), [dF] "=&v"(dF), [dS] "=&v"(dS), [c2] "=&v"(c2), [s0] "=&s"(s0),
-                       [s1] "=&s"(s1), [s2] "=&s"(s2), [s3] "=&s"(s3), [s4] "=&s"(s4), [RJ] "+v"(RJ), [dv] "+v"(dv)
-                     : [RM] "v"(RM), [LO] "v"(LO), [HI] "v"(HI), [E] "v"(E2355), [lowmask] "s"(lowmask), [AF] "n"(23),
-                       [AS] "n"(55), [CL] "n"(57), [DF] "n"(31), [DS] "n"(63));
-    } else {
-        asm volatile(SNK_DUO_ASM("v_cndmask_b32_e64 %[t], %[dF], %[dS], %[lowmask]\n\t")
-                     : [t] "=&v"(t), [x] "=&v"(x), [dF] "=&v"(dF), [dS] "=&v"(dS), [c2] "=&v"(c2), [s0] "=&s"(s0),
-                       [s1] "=&s"(s1), [s2] "=&s"(s2), [s3] "=&s"(s3), [s4] "=&s"(s4), [RJ] "+v"(RJ), [dv] "+v"(dv)
-                     : [RM] "v"(RM), [LO] "v"(LO), [HI] "v"(HI), [E] "v"(E2355), [lowmask] "s"(lowmask), [AF] "n"(55),
-                       [AS] "n"(23), [CL] "n"(25), [DF] "n"(63), [DS] "n"(31));
-    }
+    if (!BOX) {
+        asm volatile(
+            SNK_DUO_HEAD
+            "v_max_f32_e64 %[dF], -%[s0], 0\n\t"
+            "v_mov_b32 %[x], %[s1]\n\t"
+            "v_subrev_f32 %[dF], %[s2], %[dF]\n\t"
+            "v_fmac_f32 %[x], %[s4], %[dF]\n\t"
+            "v_max_f32_e64 %[x], -%[x], 0\n\t"
+            "v_subrev_f32 %[dS], %[s3], %[x]\n\t"
+            SNK_DUO_TAIL
+            : [t] "=&v"(t), [x] "=&v"(x), [dF] "=&v"(dF), [dS] "=&v"(dS), [c2] "=&v"(c2), [s0] "=&s"(s0), [s1] "=&s"(s1),
+              [s2] "=&s"(s2), [s3] "=&s"(s3), [s4] "=&s"(s4), [RJ] "+v"(RJ), [dv] "+v"(dv)
+            : [RM] "v"(RM), [E] "v"(E3163), [lowmask] "s"(lowmask));
+    } else
+    asm volatile(
+        SNK_DUO_HEAD
+        "v_med3_f32 %[dF], -%[s0], -%[HI], %[HI]\n\t"
+        "v_mov_b32 %[x], %[s1]\n\t"
+        "v_subrev_f32 %[dF], %[s2], %[dF]\n\t"
+        "v_fmac_f32 %[x], %[s4], %[dF]\n\t"
+        "v_med3_f32 %[x], -%[x], -%[HI], %[HI]\n\t"
+        "v_subrev_f32 %[dS], %[s3], %[x]\n\t"
+        SNK_DUO_TAIL
+        : [t] "=&v"(t), [x] "=&v"(x), [dF] "=&v"(dF), [dS] "=&v"(dS), [c2] "=&v"(c2), [s0] "=&s"(s0), [s1] "=&s"(s1),
+          [s2] "=&s"(s2), [s3] "=&s"(s3), [s4] "=&s"(s4), [RJ] "+v"(RJ), [dv] "+v"(dv)
+        : [RM] "v"(RM), [HI] "v"(HI), [E] "v"(E3163), [lowmask] "s"(lowmask));
     if (RES) {
-        asm volatile("v_mul_f32 %[x], %[dI], %[RJ]\n\t"
-                     "v_max_f32 %[lsq], %[lsq], |%[x]|\n\t"
+        asm volatile("v_max3_f32 %[lsq], %[lsq], |%[x]|, |%[c2]|\n\t"
                      "s_nop 1"
-                     : [x] "=&v"(x), [lsq] "+v"(lsq)
-                     : [dI] "v"(t), [RJ] "v"(RJ));
+                     : [lsq] "+v"(lsq)
+                     : [x] "v"(x), [c2] "v"(c2));
     } else {
         asm volatile("s_nop 1");
     }
 }
 
-// Bullet's cone-friction pair (hand-written, 28 VALU): direction A in the lower half and B in
-// the upper half of one register, so one reduction yields both dots; the accumulated pair is
-// projected radially onto the disc of radius mu * lambda_n (the normal's accumulated impulse:
-// kept pre-multiplied in lane NL+4 of RJnorm); the two contributions to delta-v cross halves with v_permlane32_swap.
+// Bullet's cone-friction pair (hand-written, 27 VALU): direction A in the lower half and B in
+// the upper half of one register, so one reduction yields both sums; the pair of new
+// accumulated impulses is projected radially onto the disc of radius lambda_n (the friction
+// rows are built in units of mu, see load_slot), read from lane NL of the normal's RJ.
 template <int NL, bool RES>
 __device__ __forceinline__ void cone_step(float& RJ, const float RM, const float RJnorm, float& dv, float EPS,
-                                          float E2355, unsigned long long lowmask, float& lsq) {
+                                          float E3163, unsigned long long lowmask, float& lsq) {
     float t, xA, xB, r2, c2;
     float s0, s1, s2, s3, s4;
     asm volatile(
         "v_mul_f32 %[t], %[RJ], %[dv]\n\t"
-        "v_readlane_b32 %[s4], %[RJnorm], %[NLn]\n\t"     // mu * lambda_n, kept in lane 27 / 59 of the normal
-        "v_readlane_b32 %[s0], %[RJ], 23\n\t"
-        "v_add_f32_dpp %[t], %[t], %[t] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_readlane_b32 %[s2], %[RJ], 55\n\t"
+        "v_readlane_b32 %[s4], %[RJnorm], %[NLn]\n\t"
+        "v_readlane_b32 %[s0], %[RJ], 31\n\t"
+        SNK_REDUCE_12
+        "v_readlane_b32 %[s2], %[RJ], 63\n\t"
         "v_mov_b32 %[xA], %[s0]\n\t"
-        "v_add_f32_dpp %[t], %[t], %[t] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        SNK_REDUCE_22
         "v_mov_b32 %[xB], %[s2]\n\t"
         "s_nop 0\n\t"
-        "v_add_f32_dpp %[t], %[t], %[t] row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "s_nop 1\n\t"
-        "v_add_f32_dpp %[t], %[t], %[t] row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "s_nop 1\n\t"
-        "v_add_f32_dpp %[t], %[t], %[t] row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
+        SNK_REDUCE_345
         "v_readlane_b32 %[s1], %[t], 31\n\t"
         "v_readlane_b32 %[s3], %[t], 63\n\t"
         "s_nop 1\n\t"
@@ -397,45 +413,148 @@ __device__ __forceinline__ void cone_step(float& RJ, const float RM, const float
         "v_add_f32 %[dv], %[dv], %[c2]\n\t"
         : [t] "=&v"(t), [xA] "=&v"(xA), [xB] "=&v"(xB), [r2] "=&v"(r2), [c2] "=&v"(c2),
           [s0] "=&s"(s0), [s1] "=&s"(s1), [s2] "=&s"(s2), [s3] "=&s"(s3), [s4] "=&s"(s4), [RJ] "+v"(RJ), [dv] "+v"(dv)
-        : [RM] "v"(RM), [RJnorm] "v"(RJnorm), [EPS] "v"(EPS), [E] "v"(E2355), [lowmask] "s"(lowmask),
-          [NLn] "n"(NL + 4));
+        : [RM] "v"(RM), [RJnorm] "v"(RJnorm), [EPS] "v"(EPS), [E] "v"(E3163), [lowmask] "s"(lowmask),
+          [NLn] "n"(NL));
     if (RES) {
-        asm volatile("v_mul_f32 %[x], %[dI], %[RJ]\n\t"
-                     "v_max_f32 %[lsq], %[lsq], |%[x]|\n\t"
+        asm volatile("v_max3_f32 %[lsq], %[lsq], |%[r2]|, |%[c2]|\n\t"
                      "s_nop 1"
-                     : [x] "=&v"(xA), [lsq] "+v"(lsq)
-                     : [dI] "v"(t), [RJ] "v"(RJ));
+                     : [lsq] "+v"(lsq)
+                     : [r2] "v"(r2), [c2] "v"(c2));
     } else {
         asm volatile("s_nop 1");
     }
 }
 
-// slot map
-constexpr int kSlotMotor = 0;     // 8 slots
-constexpr int kSlotNormal = 8;    // 32 slots
-constexpr int kSlotFric = 40;     // 64 slots
-constexpr int kSlots = 104;
-
-// four consecutive duo slots (8 rows): slots BASE..BASE+3, backwards if ORDER == 1
-template <int ORDER, bool RES, int BASE>
-__device__ __forceinline__ void duos4(float (&RJ)[kSlots], float (&RM)[kSlots], float& dv, float LO, float HI, float E2355,
-                                      unsigned long long lowmask, float& lsq) {
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int s = BASE + (ORDER ? 3 - i : i);
-        duo_step<ORDER, RES>(RJ[s], RM[s], dv, LO, HI, E2355, lowmask, lsq);
+// A motor row has a unit Jacobian (J = e_{6+j}), so its dot is just delta-v of that joint, and
+// with the row written in units of 1/den (impulse variable y = dI * den; RMm = M^-1[:, 6+j] / den)
+// every lane 6+j evaluates its own motor's candidate  y = target - dv  (Bullet's
+// deltaImpulse = rhs - dv/den with cfm = 0, times den) lane-locally; the row being resolved
+// is picked with one v_readlane and delta-v += RMm * y is one FMA with that scalar.  4 VALU
+// (7 with a finite impulse clamp, bound max_impulse * den per lane in PMIV) instead of half a
+// duo (12.5).  The accumulated y lives in lane 6+j of ACCV (updated under a one-lane exec
+// mask).  Returns y (wave-uniform).
+template <int J, bool CLAMP>
+__device__ __forceinline__ float motor_step(const float RMj, float& dv, const float TARGV, float& ACCV, float PMIV) {
+    float u, xs, s;
+    if (CLAMP) {
+        asm volatile(
+            "v_sub_f32 %[u], %[TARGV], %[dv]\n\t"
+            "v_add_f32 %[xs], %[ACCV], %[u]\n\t"
+            "v_med3_f32 %[xs], %[xs], -%[PMIV], %[PMIV]\n\t"
+            "v_sub_f32 %[u], %[xs], %[ACCV]\n\t"
+            "s_nop 0\n\t"
+            "v_readlane_b32 %[s], %[u], %[LN]\n\t"
+            "s_mov_b64 exec, %[MASK]\n\t"
+            "v_add_f32 %[ACCV], %[ACCV], %[u]\n\t"
+            "s_mov_b64 exec, -1\n\t"
+            "v_fmac_f32 %[dv], %[s], %[RMj]\n\t"
+            : [u] "=&v"(u), [xs] "=&v"(xs), [s] "=&s"(s), [ACCV] "+v"(ACCV), [dv] "+v"(dv)
+            : [RMj] "v"(RMj), [TARGV] "v"(TARGV), [PMIV] "v"(PMIV), [LN] "n"(6 + J), [MASK] "n"(1 << (6 + J)));
+    } else {
+        asm volatile(
+            "v_sub_f32 %[u], %[TARGV], %[dv]\n\t"
+            "s_nop 0\n\t"
+            "v_readlane_b32 %[s], %[u], %[LN]\n\t"
+            "s_mov_b64 exec, %[MASK]\n\t"
+            "v_add_f32 %[ACCV], %[ACCV], %[u]\n\t"
+            "s_mov_b64 exec, -1\n\t"
+            "v_fmac_f32 %[dv], %[s], %[RMj]\n\t"
+            : [u] "=&v"(u), [s] "=&s"(s), [ACCV] "+v"(ACCV), [dv] "+v"(dv)
+            : [RMj] "v"(RMj), [TARGV] "v"(TARGV), [LN] "n"(6 + J), [MASK] "n"(1 << (6 + J)));
+        (void)xs;
     }
+    return s;
 }
+
+// slot map (two rows per slot) and the layout of the accumulated impulses handed back in L.app
+constexpr int kSlotNormal = 0;    // 32 slots: contacts 2s (lower half), 2s+1 (upper half)
+constexpr int kSlotFric = 32;     // 64 slots: contact s, direction A lower / B upper
+constexpr int kSlots = 96;
+constexpr int kAppMotor = 0;      // app[j]                motor j
+constexpr int kAppNormal = 16;    // app[16 + ci]          normal of contact ci
+constexpr int kAppFric = 80;      // app[80 + 2 ci + {0,1}] friction A / B of contact ci
+constexpr unsigned long long kLowMask = 0x00000000FFFFFFFFull;
+
+template <bool RES, int BASE>
+__device__ __forceinline__ void duos4(float (&RJ)[kSlots], float (&RM)[kSlots], float& dv, float E3163, float& lsq) {
+#pragma unroll
+    for (int s = BASE; s < BASE + 4; s++) duo_step<RES, false>(RJ[s], RM[s], dv, 0.f, E3163, kLowMask, lsq);
+}
+
 // eight consecutive friction pairs (contacts 8G..8G+7); the normal impulse of contact ci sits
-// in slot kSlotNormal + ci/2, lane 23 (even ci) or 55 (odd ci)
+// in slot kSlotNormal + ci/2, lane 31 (even ci) or 63 (odd ci)
 template <bool RES, int G>
-__device__ __forceinline__ void cones8(float (&RJ)[kSlots], float (&RM)[kSlots], float& dv, float EPS, float E2355,
-                                       unsigned long long lowmask, float& lsq) {
+__device__ __forceinline__ void cones8(float (&RJ)[kSlots], float (&RM)[kSlots], float& dv, float EPS,
+                                       float E3163, float& lsq) {
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const int c0 = 8 * G + 2 * i;
-        cone_step<23, RES>(RJ[kSlotFric + c0], RM[kSlotFric + c0], RJ[kSlotNormal + (c0 >> 1)], dv, EPS, E2355, lowmask, lsq);
-        cone_step<55, RES>(RJ[kSlotFric + c0 + 1], RM[kSlotFric + c0 + 1], RJ[kSlotNormal + (c0 >> 1)], dv, EPS, E2355, lowmask, lsq);
+        cone_step<31, RES>(RJ[kSlotFric + c0], RM[kSlotFric + c0], RJ[kSlotNormal + (c0 >> 1)], dv, EPS, E3163, kLowMask, lsq);
+        cone_step<63, RES>(RJ[kSlotFric + c0 + 1], RM[kSlotFric + c0 + 1], RJ[kSlotNormal + (c0 >> 1)], dv, EPS, E3163, kLowMask, lsq);
+    }
+}
+
+// the 16 motor rows, forwards or backwards; returns max |dI * den| = max |y| of the sweep
+// (ALIVE: every motor row has a usable denominator -- always, unless a joint has no inertia;
+// otherwise dead rows are masked out of the residual through LDS)
+template <bool FWD, bool CLAMP, bool ALIVE, class LT>
+__device__ __forceinline__ float motors16(LT& L, const float (&RMm)[16], float& dv, const float TARGV, float& ACCV,
+                                          float PMIV) {
+    float res = 0.f;
+#define SNK_MOTOR(J)                                                                              \
+    {                                                                                              \
+        float s_ = motor_step<J, CLAMP>(RMm[J], dv, TARGV, ACCV, PMIV);                            \
+        res = fmaxf(res, fabsf(ALIVE ? s_ : s_ * (L.MmS[J][1] * L.MmS[J][2])));                    \
+    }
+    if (FWD) {
+        SNK_MOTOR(0) SNK_MOTOR(1) SNK_MOTOR(2) SNK_MOTOR(3) SNK_MOTOR(4) SNK_MOTOR(5) SNK_MOTOR(6) SNK_MOTOR(7)
+        SNK_MOTOR(8) SNK_MOTOR(9) SNK_MOTOR(10) SNK_MOTOR(11) SNK_MOTOR(12) SNK_MOTOR(13) SNK_MOTOR(14) SNK_MOTOR(15)
+    } else {
+        SNK_MOTOR(15) SNK_MOTOR(14) SNK_MOTOR(13) SNK_MOTOR(12) SNK_MOTOR(11) SNK_MOTOR(10) SNK_MOTOR(9) SNK_MOTOR(8)
+        SNK_MOTOR(7) SNK_MOTOR(6) SNK_MOTOR(5) SNK_MOTOR(4) SNK_MOTOR(3) SNK_MOTOR(2) SNK_MOTOR(1) SNK_MOTOR(0)
+    }
+#undef SNK_MOTOR
+    return res;
+}
+
+// all contact rows of one iteration: normals in contact order (one scalar branch per 8
+// contacts; rows past the active count are inert zeros), then the friction pairs.
+// RES: lsq collects max |dI * den| in lanes 24 / 56.
+template <bool RES>
+__device__ __forceinline__ void contact_rows(float (&RJ)[kSlots], float (&RM)[kSlots], float& dv, int ncl, bool cone,
+                                             float EPS, float E3163, float& lsq) {
+    if (ncl > 0) duos4<RES, kSlotNormal + 0>(RJ, RM, dv, E3163, lsq);
+    if (ncl > 8) duos4<RES, kSlotNormal + 4>(RJ, RM, dv, E3163, lsq);
+    if (ncl > 16) duos4<RES, kSlotNormal + 8>(RJ, RM, dv, E3163, lsq);
+    if (ncl > 24) duos4<RES, kSlotNormal + 12>(RJ, RM, dv, E3163, lsq);
+    if (ncl > 32) duos4<RES, kSlotNormal + 16>(RJ, RM, dv, E3163, lsq);
+    if (ncl > 40) duos4<RES, kSlotNormal + 20>(RJ, RM, dv, E3163, lsq);
+    if (ncl > 48) duos4<RES, kSlotNormal + 24>(RJ, RM, dv, E3163, lsq);
+    if (ncl > 56) duos4<RES, kSlotNormal + 28>(RJ, RM, dv, E3163, lsq);
+    if (cone) {
+        if (ncl > 0) cones8<RES, 0>(RJ, RM, dv, EPS, E3163, lsq);
+        if (ncl > 8) cones8<RES, 1>(RJ, RM, dv, EPS, E3163, lsq);
+        if (ncl > 16) cones8<RES, 2>(RJ, RM, dv, EPS, E3163, lsq);
+        if (ncl > 24) cones8<RES, 3>(RJ, RM, dv, EPS, E3163, lsq);
+        if (ncl > 32) cones8<RES, 4>(RJ, RM, dv, EPS, E3163, lsq);
+        if (ncl > 40) cones8<RES, 5>(RJ, RM, dv, EPS, E3163, lsq);
+        if (ncl > 48) cones8<RES, 6>(RJ, RM, dv, EPS, E3163, lsq);
+        if (ncl > 56) cones8<RES, 7>(RJ, RM, dv, EPS, E3163, lsq);
+    } else {
+        // pyramid friction (not Bullet's default here): the two directions are resolved one
+        // after the other (a duo with its coupling scalar), bounds +-lambda_n (rows are in
+        // units of mu), and -- as in Bullet -- skipped altogether while the normal impulse is zero
+#pragma unroll
+        for (int g = 0; g < 8; g++) {
+            if (ncl > 8 * g) {
+#pragma unroll
+                for (int ci = 8 * g; ci < 8 * g + 8; ci++) {
+                    float lim = rdlane(RJ[kSlotNormal + (ci >> 1)], (ci & 1) ? 63 : 31);
+                    if (__builtin_amdgcn_readfirstlane(lim > 0.f ? 1 : 0))
+                        duo_step<RES, true>(RJ[kSlotFric + ci], RM[kSlotFric + ci], dv, lim, E3163, kLowMask, lsq);
+                }
+            }
+        }
     }
 }
 
@@ -479,6 +598,8 @@ __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane, f
     // runs while at most the 128 friction-row registers are live: motors go to LDS first,
     // then friction A, friction B, normals through the 64-row staging, motors are loaded last.
     float RJ[kSlots], RM[kSlots];
+    float RMm[16], TARGV, PMIV;   // PMIV: per-lane bound on y = dI * den (clamped motors only)
+    bool malive;                  // every motor row has a positive denominator
     {
         LaneK K;
         K.h = lane >> 5;
@@ -491,6 +612,7 @@ __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane, f
         K.oL = ld3(L.o[K.bL]);
         K.aL = (K.d >= 6 && K.isdof) ? ld3(L.ax[K.bL])
                                      : mk3(K.d == 0 ? 1.f : 0.f, K.d == 1 ? 1.f : 0.f, K.d == 2 ? 1.f : 0.f);
+        const float fJ = mu > 0.f ? 1.0f / mu : 0.f, fM = mu > 0.f ? mu : 0.f;
         build_batch_v2<LT, 0>(L, M, lane, nc);
         build_batch_v2<LT, 2>(L, M, lane, nc);
 #pragma unroll
@@ -499,7 +621,7 @@ __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane, f
 #pragma unroll
                 for (int s = 8 * g; s < 8 * g + 8; s++) {
                     RJ[kSlotFric + s] = 0.f; RM[kSlotFric + s] = 0.f;
-                    load_slot<LT, 2>(L, K, s, nc, RJ[kSlotFric + s], RM[kSlotFric + s]);
+                    load_slot<LT, 2>(L, K, s, nc, fJ, fM, RJ[kSlotFric + s], RM[kSlotFric + s]);
                 }
             } else {
 #pragma unroll
@@ -512,7 +634,7 @@ __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane, f
         for (int g = 0; g < 8; g++) {
             if (nc > 8 * g) {
 #pragma unroll
-                for (int s = 8 * g; s < 8 * g + 8; s++) load_slot<LT, 3>(L, K, s, nc, RJ[kSlotFric + s], RM[kSlotFric + s]);
+                for (int s = 8 * g; s < 8 * g + 8; s++) load_slot<LT, 3>(L, K, s, nc, fJ, fM, RJ[kSlotFric + s], RM[kSlotFric + s]);
             }
         }
         lds_sync();
@@ -521,36 +643,43 @@ __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane, f
         for (int g = 0; g < 4; g++) {
             if (nc > 16 * g) {
 #pragma unroll
-                for (int s = 8 * g; s < 8 * g + 8; s++) load_slot<LT, 1>(L, K, s, nc, RJ[kSlotNormal + s], RM[kSlotNormal + s]);
+                for (int s = 8 * g; s < 8 * g + 8; s++) load_slot<LT, 1>(L, K, s, nc, 1.0f, 1.0f, RJ[kSlotNormal + s], RM[kSlotNormal + s]);
             } else {
 #pragma unroll
                 for (int s = 8 * g; s < 8 * g + 8; s++) { RJ[kSlotNormal + s] = 0.f; RM[kSlotNormal + s] = 0.f; }
             }
         }
+        // motors: column 6+j of M^-1 (divided by the row's denominator) in both halves;
+        // target velocity change of motor j in lane 6+j
 #pragma unroll
-        for (int s = 0; s < 8; s++) load_slot<LT, 0>(L, K, s, N, RJ[kSlotMotor + s], RM[kSlotMotor + s]);
+        for (int j = 0; j < 16; j++) RMm[j] = K.isdof ? L.Mm[j][K.d] * L.MmS[j][2] : 0.f;
+        {
+            const bool mot = K.d >= 6 && K.isdof;
+            const int jm = mot ? K.d - 6 : 0;
+            const float dinv_m = mot ? L.MmS[jm][2] : 0.f;
+            TARGV = (mot && dinv_m > 0.f) ? L.MmS[jm][3] : 0.f;
+            PMIV = (M.max_motor_imp < 1e30f && dinv_m > 0.f) ? M.max_motor_imp / dinv_m : 1e30f;
+            malive = __all(!mot || dinv_m > 0.f) != 0;
+        }
         lds_sync();
     }
 
-    // coupling scalars of the duos (motors and normals), once per substep:
-    //   lower lane 25 <- RJ_lower . RM_upper  (used when the upper row goes first),
-    //   upper lane 57 <- RJ_upper . RM_lower  (used when the lower row goes first)
+    // coupling scalar of each duo, once per substep:  lane 57 of RJ <- RJ_upper . RM_lower
+    // (the upper row is resolved after the lower one).  Pyramid friction resolves the two
+    // directions of a contact one after the other, so its slots are duos as well.
     {
-        const bool lo_ = lane < 32;
 #pragma unroll
         for (int s = 0; s < kSlotFric; s++) {
             swap2 sw = half_swap(RM[s], RM[s]);             // a = [RM_lower, RM_lower], b = [RM_upper, RM_upper]
-            float t = half_reduce(RJ[s] * (lo_ ? sw.b : sw.a));
-            float c_lo = rdlane(t, 31), c_up = rdlane(t, 63);
-            RJ[s] = wrlane(wrlane(RJ[s], c_lo, 25), c_up, 57);
+            float t = half_reduce(RJ[s] * sw.a);
+            RJ[s] = wrlane(RJ[s], rdlane(t, 63), 57);
         }
-        if (M.cone == 0) {   // pyramid friction resolves the two directions one after the other
+        if (M.cone == 0) {
 #pragma unroll
             for (int s = kSlotFric; s < kSlots; s++) {
                 swap2 sw = half_swap(RM[s], RM[s]);
-                float t = half_reduce(RJ[s] * (lo_ ? sw.b : sw.a));
-                float c_lo = rdlane(t, 31), c_up = rdlane(t, 63);
-                RJ[s] = wrlane(wrlane(RJ[s], c_lo, 25), c_up, 57);
+                float t = half_reduce(RJ[s] * sw.a);
+                RJ[s] = wrlane(RJ[s], rdlane(t, 63), 57);
             }
         }
     }
@@ -585,14 +714,12 @@ __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane, f
     float dv;
     {
         const int d = lane & 31;
-        dv = d == 22 ? 1.0f : (d == 23 ? -1.0f : 0.0f);
-        const float E2355 = d == 23 ? 1.0f : 0.0f;
-        const float MU = mu;
-        const float ENORM = d == 23 ? 1.0f : (d == 27 ? mu : 0.0f);   // normals also keep mu*lambda_n (lane 27/59)
+        dv = d == 22 ? 1.0f : (d == 31 ? -1.0f : 0.0f);
+        const float E3163 = d == 31 ? 1.0f : 0.0f;
         const float EPS = 1e-30f;
         const float mi = M.max_motor_imp;
-        const float NMI = -mi, PMI = mi, ZERO = 0.f, BIG = 1e10f;
-        const unsigned long long LOWMASK = 0x00000000FFFFFFFFull;
+        const bool mclamp = mi < 1e30f;
+        float ACCV = 0.f;     // accumulated motor impulses, motor j in lane 6+j
         const float thr = sqrtf(M.resid_thr);
         const int n_iter = M.n_iter;
         const bool cone = M.cone != 0;
@@ -604,10 +731,6 @@ __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane, f
             int exceeded = 0;
             int ncl = nc;
             asm volatile("" : "+s"(ncl));   // keeps the group-active compares from being hoisted and spilled
-            auto check = [&](float lsq) {
-                float m = fmaxf(rdlane(lsq, 24), rdlane(lsq, 56));
-                exceeded = __builtin_amdgcn_readfirstlane(m > thr ? 1 : 0);
-            };
             auto limit_rows = [&](bool fwd) {
                 for (int jj = 0; jj < nlim; jj++) {
                     const int idx = fwd ? jj : nlim - 1 - jj;
@@ -624,76 +747,45 @@ __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane, f
                     if (__builtin_amdgcn_readfirstlane(fabsf(dI * L.nc_den[idx]) > thr ? 1 : 0)) exceeded = 1;
                 }
             };
-#define SNK_DUOS4(ORDER, BASE, LO, HI)                                                              \
-    if (exceeded) { float l_ = 0.f; duos4<ORDER, false, BASE>(RJ, RM, dv, LO, HI, E2355, LOWMASK, l_); } \
-    else { float l_ = 0.f; duos4<ORDER, true, BASE>(RJ, RM, dv, LO, HI, E2355, LOWMASK, l_); check(l_); }
-#define SNK_DUOS4N(BASE)                                                                            \
-    if (exceeded) { float l_ = 0.f; duos4<0, false, BASE>(RJ, RM, dv, ZERO, BIG, ENORM, LOWMASK, l_); }  \
-    else { float l_ = 0.f; duos4<0, true, BASE>(RJ, RM, dv, ZERO, BIG, ENORM, LOWMASK, l_); check(l_); }
-#define SNK_CONES8(G)                                                                              \
-    if (exceeded) { float l_ = 0.f; cones8<false, G>(RJ, RM, dv, EPS, E2355, LOWMASK, l_); }    \
-    else { float l_ = 0.f; cones8<true, G>(RJ, RM, dv, EPS, E2355, LOWMASK, l_); check(l_); }
             // non-contact rows: list = [limits..., motors 0..15], walked forwards on odd
-            // iterations and backwards on even ones
+            // iterations and backwards on even ones.  The motors' residual is always tracked
+            // (one v_max per row); it decides which body runs for the ~190 contact rows.
+            float mres;
+#define SNK_MOTORS(FWD)                                                                             \
+    mres = malive ? (mclamp ? motors16<FWD, true, true>(L, RMm, dv, TARGV, ACCV, PMIV)               \
+                            : motors16<FWD, false, true>(L, RMm, dv, TARGV, ACCV, PMIV))             \
+                  : (mclamp ? motors16<FWD, true, false>(L, RMm, dv, TARGV, ACCV, PMIV)              \
+                            : motors16<FWD, false, false>(L, RMm, dv, TARGV, ACCV, PMIV));
             if (it & 1) {
                 limit_rows(true);
-                SNK_DUOS4(0, kSlotMotor, NMI, PMI)
-                SNK_DUOS4(0, kSlotMotor + 4, NMI, PMI)
+                SNK_MOTORS(true)
             } else {
-                SNK_DUOS4(1, kSlotMotor + 4, NMI, PMI)
-                SNK_DUOS4(1, kSlotMotor, NMI, PMI)
+                SNK_MOTORS(false)
                 limit_rows(false);
             }
-            // contact normals in contact order, one scalar branch per 8 contacts; rows past the
-            // active count are inert zeros
-            if (ncl > 0) { SNK_DUOS4N(kSlotNormal + 0) }
-            if (ncl > 8) { SNK_DUOS4N(kSlotNormal + 4) }
-            if (ncl > 16) { SNK_DUOS4N(kSlotNormal + 8) }
-            if (ncl > 24) { SNK_DUOS4N(kSlotNormal + 12) }
-            if (ncl > 32) { SNK_DUOS4N(kSlotNormal + 16) }
-            if (ncl > 40) { SNK_DUOS4N(kSlotNormal + 20) }
-            if (ncl > 48) { SNK_DUOS4N(kSlotNormal + 24) }
-            if (ncl > 56) { SNK_DUOS4N(kSlotNormal + 28) }
-            // friction pairs in contact order
-            if (cone) {
-                if (ncl > 0) { SNK_CONES8(0) }
-                if (ncl > 8) { SNK_CONES8(1) }
-                if (ncl > 16) { SNK_CONES8(2) }
-                if (ncl > 24) { SNK_CONES8(3) }
-                if (ncl > 32) { SNK_CONES8(4) }
-                if (ncl > 40) { SNK_CONES8(5) }
-                if (ncl > 48) { SNK_CONES8(6) }
-                if (ncl > 56) { SNK_CONES8(7) }
-            } else {
-                // pyramid friction (not Bullet's default here): the two directions are resolved one
-                // after the other (a duo with its coupling scalar), bounds +-mu*lambda_n, and -- as
-                // in Bullet -- skipped altogether while the normal impulse is zero
-#pragma unroll
-                for (int g = 0; g < 8; g++) {
-                    if (ncl > 8 * g) {
-#pragma unroll
-                        for (int ci = 8 * g; ci < 8 * g + 8; ci++) {
-                            float lim = rdlane(RJ[kSlotNormal + (ci >> 1)], (ci & 1) ? 55 : 23) * MU;
-                            if (__builtin_amdgcn_readfirstlane(lim > 0.f ? 1 : 0)) {
-                                float nlim_ = -lim, lsq = 0.f;
-                                duo_step<0, true>(RJ[kSlotFric + ci], RM[kSlotFric + ci], dv, nlim_, lim, E2355, LOWMASK, lsq);
-                                if (!exceeded) check(lsq);
-                            }
-                        }
-                    }
-                }
+#undef SNK_MOTORS
+            if (__builtin_amdgcn_readfirstlane(mres > thr ? 1 : 0)) exceeded = 1;
+            // contact rows: the residual is tracked in every step (one v_max3; a second,
+            // residual-free copy of the ~190 row steps costs more in register copies at the
+            // join and in instruction cache than it saves)
+            {
+                float l_ = 0.f;
+                contact_rows<true>(RJ, RM, dv, ncl, cone, EPS, E3163, l_);
+                float m = fmaxf(rdlane(l_, 24), rdlane(l_, 56));
+                if (__builtin_amdgcn_readfirstlane(m > thr ? 1 : 0)) exceeded = 1;
             }
-#undef SNK_DUOS4
-#undef SNK_DUOS4N
-#undef SNK_CONES8
             if (!exceeded || it >= n_iter - 1) { it++; break; }
         }
         iters = it;
-        // accumulated impulses -> LDS, by (slot, half)
-        if (d == 23) {
+        // accumulated impulses -> LDS (friction back from units of mu)
+        if (d == 31) {
+            const int h = lane >> 5;
 #pragma unroll
-            for (int s = 0; s < kSlots; s++) L.app[2 * s + (lane >> 5)] = RJ[s];
+            for (int s = 0; s < kSlotFric; s++) L.app[kAppNormal + 2 * s + h] = RJ[kSlotNormal + s];
+#pragma unroll
+            for (int s = 0; s < kSlots - kSlotFric; s++) L.app[kAppFric + 2 * s + h] = RJ[kSlotFric + s] * mu;
         }
+        if (lane >= 6 && lane < ND) L.app[kAppMotor + lane - 6] = ACCV * L.MmS[lane - 6][2];   // y / den = impulse
     }
     lds_sync();
 
@@ -703,9 +795,9 @@ __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane, f
         f3 eN = mk3(0, 0, 0), eF = mk3(0, 0, 0);
         for (int ci = 0; ci < nc; ci++) {
             if (L.ccbody[ci] == b) {
-                f3 F = (mk3(0.f, 0.f, 1.f) * L.app[2 * kSlotNormal + ci] +
-                        ld3(L.ccdir[ci][0]) * L.app[2 * (kSlotFric + ci)] +
-                        ld3(L.ccdir[ci][1]) * L.app[2 * (kSlotFric + ci) + 1]) * M.inv_dt;
+                f3 F = (mk3(0.f, 0.f, 1.f) * L.app[kAppNormal + ci] +
+                        ld3(L.ccdir[ci][0]) * L.app[kAppFric + 2 * ci] +
+                        ld3(L.ccdir[ci][1]) * L.app[kAppFric + 2 * ci + 1]) * M.inv_dt;
                 eF = eF + F;
                 eN = eN + cross(ld3(L.ccP[ci]) - ld3(L.o[b]), F);
             }

@@ -5,7 +5,7 @@ per-env-friction configs, and size-independent properties at BASELINE's full 409
 Tolerances for one env-step (<= 41 substeps with ~64 contacts, 50 unconverged Gauss-Seidel
 sweeps each; float32 GPU vs float64 oracle, re-synchronised before every step):
 joint angles / base pose 5e-3 (1e-2 for the 32-link chain), reward 5e-3, joint velocities:
-90th percentile of |dqd|/(1+|qd|) below 5e-2 (0.4: only 24 samples) and maximum below 0.5 (1.0).  These are the sensitivity of the system
+90th percentile of |dqd|/(1+|qd|) below 5e-2 (0.4: only 24 samples) and maximum below 0.75 (1.0).  These are the sensitivity of the system
 to float32 round-off, not kernel error: the oracle itself built in float32 differs from the
 float64 oracle by 2.5e-3 / 0.24 (max) on the same steps, and the test requires the GPU to
 be no worse than twice (32-link: three times) that calibration, measured in the same run.  Substep counts and done
@@ -75,7 +75,7 @@ def test_env_step_parity_resynced(pkg, oracle_mod, n):
     print("n", n, "GPU-f32 vs oracle-f64 worst", worst, "qd p90", p90, "| oracle-f32 vs oracle-f64", cal,
           "| boundary mismatches", mism, "of", B * J)
     # the 32-link chain is twice as long and correspondingly more sensitive to round-off
-    tq, tp90, tmax, kcal = (5e-3, 5e-2, 0.5, 2.0) if n == 16 else (1e-2, 0.4, 1.0, 3.0)
+    tq, tp90, tmax, kcal = (5e-3, 5e-2, 0.75, 2.0) if n == 16 else (1e-2, 0.4, 1.0, 3.0)
     assert worst["q"] < tq and worst["r"] < 5e-3
     assert p90 < tp90 and worst["qd"] < tmax
     assert worst["q"] < kcal * cal["q"] + 1e-4 and worst["qd"] < kcal * cal["qd"] + 1e-3
