@@ -297,7 +297,11 @@ __device__ __forceinline__ float wrlane(float old, float v_uniform, int l) {
     "v_add_f32_dpp %[t], %[t], %[t] row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"         \
     "s_nop 1\n\t"                                                                                  \
     "v_add_f32_dpp %[t], %[t], %[t] row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"                   \
-    "s_nop 1\n\t"
+    "s_nop 0\n\t"
+// Wait states used below are the ones hipcc itself inserts on gfx950: VALU write -> DPP read 2,
+// VALU write -> v_readlane 1, v_readlane (SGPR) -> VALU read 2, v_rsq -> VALU use 1,
+// VALU write -> v_permlane32_swap 2, v_permlane32_swap -> VALU use 0.  Every s_nop is an issue
+// slot of the wave, so none is spent beyond those (measured: -15 % per step).
 
 // Two consecutive single rows living in the two halves of one slot (hand-written, 25 VALU):
 // lower-half row first, then the upper-half row.  One multiply and one reduction give both
@@ -327,7 +331,6 @@ __device__ __forceinline__ float wrlane(float old, float v_uniform, int l) {
     "v_fmac_f32 %[RJ], %[E], %[t]\n\t"                    \
     "s_nop 0\n\t"                                         \
     "v_permlane32_swap_b32 %[x], %[c2]\n\t"               \
-    "s_nop 1\n\t"                                         \
     "v_add_f32 %[dv], %[dv], %[x]\n\t"                    \
     "v_add_f32 %[dv], %[dv], %[c2]\n\t"
 // BOX = false: contact normals, bounds [0, inf) -> a single v_max; BOX = true: [-HI, HI]
@@ -362,14 +365,7 @@ __device__ __forceinline__ void duo_step(float& RJ, const float RM, float& dv, f
         : [t] "=&v"(t), [x] "=&v"(x), [dF] "=&v"(dF), [dS] "=&v"(dS), [c2] "=&v"(c2), [s0] "=&s"(s0), [s1] "=&s"(s1),
           [s2] "=&s"(s2), [s3] "=&s"(s3), [s4] "=&s"(s4), [RJ] "+v"(RJ), [dv] "+v"(dv)
         : [RM] "v"(RM), [HI] "v"(HI), [E] "v"(E3163), [lowmask] "s"(lowmask));
-    if (RES) {
-        asm volatile("v_max3_f32 %[lsq], %[lsq], |%[x]|, |%[c2]|\n\t"
-                     "s_nop 1"
-                     : [lsq] "+v"(lsq)
-                     : [x] "v"(x), [c2] "v"(c2));
-    } else {
-        asm volatile("s_nop 1");
-    }
+    if (RES) asm volatile("v_max3_f32 %[lsq], %[lsq], |%[x]|, |%[c2]|" : [lsq] "+v"(lsq) : [x] "v"(x), [c2] "v"(c2));
 }
 
 // Bullet's cone-friction pair (hand-written, 27 VALU): direction A in the lower half and B in
@@ -394,11 +390,11 @@ __device__ __forceinline__ void cone_step(float& RJ, const float RM, const float
         SNK_REDUCE_345
         "v_readlane_b32 %[s1], %[t], 31\n\t"
         "v_readlane_b32 %[s3], %[t], 63\n\t"
-        "s_nop 1\n\t"
+        "s_nop 0\n\t"
         "v_fma_f32 %[r2], %[s1], %[s1], %[EPS]\n\t"
         "v_fma_f32 %[r2], %[s3], %[s3], %[r2]\n\t"
         "v_rsq_f32 %[r2], %[r2]\n\t"
-        "s_nop 1\n\t"
+        "s_nop 0\n\t"
         "v_mul_f32_e64 %[r2], %[s4], %[r2] clamp\n\t"
         "v_fma_f32 %[xA], %[r2], -%[s1], -%[xA]\n\t"
         "v_fma_f32 %[xB], %[r2], -%[s3], -%[xB]\n\t"
@@ -408,21 +404,13 @@ __device__ __forceinline__ void cone_step(float& RJ, const float RM, const float
         "v_fmac_f32 %[RJ], %[E], %[t]\n\t"
         "s_nop 0\n\t"
         "v_permlane32_swap_b32 %[r2], %[c2]\n\t"
-        "s_nop 1\n\t"
         "v_add_f32 %[dv], %[dv], %[r2]\n\t"
         "v_add_f32 %[dv], %[dv], %[c2]\n\t"
         : [t] "=&v"(t), [xA] "=&v"(xA), [xB] "=&v"(xB), [r2] "=&v"(r2), [c2] "=&v"(c2),
           [s0] "=&s"(s0), [s1] "=&s"(s1), [s2] "=&s"(s2), [s3] "=&s"(s3), [s4] "=&s"(s4), [RJ] "+v"(RJ), [dv] "+v"(dv)
         : [RM] "v"(RM), [RJnorm] "v"(RJnorm), [EPS] "v"(EPS), [E] "v"(E3163), [lowmask] "s"(lowmask),
           [NLn] "n"(NL));
-    if (RES) {
-        asm volatile("v_max3_f32 %[lsq], %[lsq], |%[r2]|, |%[c2]|\n\t"
-                     "s_nop 1"
-                     : [lsq] "+v"(lsq)
-                     : [r2] "v"(r2), [c2] "v"(c2));
-    } else {
-        asm volatile("s_nop 1");
-    }
+    if (RES) asm volatile("v_max3_f32 %[lsq], %[lsq], |%[r2]|, |%[c2]|" : [lsq] "+v"(lsq) : [r2] "v"(r2), [c2] "v"(c2));
 }
 
 // A motor row has a unit Jacobian (J = e_{6+j}), so its dot is just delta-v of that joint, and
