@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsnk.so")
+# SNK_LIB selects an instrumented build of the same ABI (tools/profile_phases.py); default: libsnk.so
+LIB_PATH = os.environ.get("SNK_LIB") or os.path.join(_HERE, "libsnk.so")
 
 
 class SnkParams(C.Structure):

@@ -22,21 +22,25 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
-    if not force and not needs_build():
+def build(force=False, verbose=False, defines=(), out=None):
+    """defines/out: instrumented variants (e.g. -DSNK_PROFILE -> libsnk_prof.so, tools/profile_phases.py)."""
+    if out is None and not defines and not force and not needs_build():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-shared", "-fPIC",
-           os.path.join(CSRC, "snk_api.hip"), "-o", LIB]
+           os.path.join(CSRC, "snk_api.hip"), "-o", out or LIB] + ["-D" + d for d in defines]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    return LIB
+    return out or LIB
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, verbose="-v" in sys.argv)
-    print(LIB)
+    if "--profile" in sys.argv:
+        print(build(force=True, defines=("SNK_PROFILE",), out=os.path.join(HERE, "libsnk_prof.so")))
+    else:
+        build(force="--force" in sys.argv, verbose="-v" in sys.argv)
+        print(LIB)

@@ -41,6 +41,14 @@
 
 namespace snk {
 
+// -DSNK_PROFILE: s_memtime stamps between the phases of substep_v2; the phase durations (ticks)
+// overwrite the motor-torque outputs of the substep (tools/profile_phases.py reads them).
+#ifdef SNK_PROFILE
+#define SNK_STAMP(i) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); prof_t[i] = t_; }
+#else
+#define SNK_STAMP(i)
+#endif
+
 struct swap2 {
     float a, b;
 };
@@ -100,7 +108,7 @@ __device__ __forceinline__ void half_dot2(float x, float& sA, float& sB) {
 // contacts of the current pose, written at their COMPACT index (same geometry as v1)
 // ------------------------------------------------------------------------------------
 template <class LT>
-__device__ int find_contacts_v2(LT& L, const DevModel& M, int lane) {
+__device__ int find_contacts_v2(LT& L, const DevModel& M, int lane, unsigned long long& active_slots) {
     constexpr int N = LT::kN;
     static_assert(4 * N == 64, "one contact slot per lane");
     const int slot = lane;
@@ -135,6 +143,7 @@ __device__ int find_contacts_v2(LT& L, const DevModel& M, int lane) {
         st3(L.ccdir[idx][0], mulRv(Rw, mk3(l1.x * a.x, l1.y * a.y, l1.z * a.z)));
         st3(L.ccdir[idx][1], mulRv(Rw, mk3(l2.x * a.x, l2.y * a.y, l2.z * a.z)));
     }
+    active_slots = bal;
     return __popcll(bal);
 }
 
@@ -231,6 +240,15 @@ __device__ void build_batch_v2(LT& L, const DevModel& M, int lane, int nc) {
     lds_sync();
 }
 
+// slot map (two rows per slot) and the layout of the accumulated impulses handed back in L.app
+constexpr int kSlotNormal = 0;    // 32 slots: contacts 2s (lower half), 2s+1 (upper half)
+constexpr int kSlotFric = 32;     // 64 slots: contact s, direction A lower / B upper
+constexpr int kSlots = 96;
+constexpr int kAppMotor = 0;      // app[j]                motor j
+constexpr int kAppNormal = 16;    // app[16 + ci]          normal of contact ci
+constexpr int kAppFric = 80;      // app[80 + 2 ci + {0,1}] friction A / B of contact ci
+constexpr unsigned long long kLowMask = 0x00000000FFFFFFFFull;
+
 // per-lane constants of the (half, d) layout
 struct LaneK {
     int h, d;
@@ -249,32 +267,54 @@ struct LaneK {
 // Friction rows are built in units of mu (sJ = 1/mu, sM = mu): the impulse variable is
 // f / mu, so the cone radius is lambda_n itself and mu never appears in the solve loop;
 // dI * den (the residual) is unchanged.  mu == 0 gives inert zero rows.
+// The LDS reads of a slot (issued one slot ahead of the arithmetic that consumes them: a
+// dependent ds_read round trip costs ~200 clocks, as much as the whole slot's arithmetic).
+struct SlotRaw {
+    float mval, dinv, sp;
+    f3 P, dir;
+    int k;
+    bool valid;
+};
 template <class LT, int KIND>
-__device__ __forceinline__ void load_slot(LT& L, const LaneK& K, int s, int count, float sJ, float sM, float& RJ, float& RM) {
+__device__ __forceinline__ SlotRaw fetch_slot(LT& L, const LaneK& K, int s, int count) {
+    SlotRaw r;
     const int row = KIND == 1 ? 2 * s + K.h : s;
-    const bool valid = row < count;
-    const int rs = valid ? row : 0;
+    r.valid = row < count;
+    const int rs = r.valid ? row : 0;
     const float* st = L.stM[rs];
-    const float* sc = &L.stM[rs][22];
     const int dd = K.isdof ? K.d : 0;
-    float mval = st[dd];
-    float dinv = sc[2];
-    float sp = sc[K.spoff];
-    float jd;
-    {
-        f3 P = ld3(L.ccP[rs]);
-        f3 dir = KIND == 1 ? mk3(0.f, 0.f, 1.f) : ld3(L.ccdir[rs][KIND == 2 ? 0 : 1]);
-        const int k = L.ccbody[rs];
-        float v = dot(K.aL, cross(P - K.oL, dir));
-        v = K.d == 3 ? dir.x : (K.d == 4 ? dir.y : (K.d == 5 ? dir.z : v));
-        jd = (K.bL <= k) ? v : 0.0f;
-    }
-    float rj = (K.isdof ? jd * dinv : sp * K.m22) * sJ;
-    float rm = (K.isdof ? mval : sp * K.m24) * sM;
-    if (!valid) { rj = 0.f; rm = 0.f; }
+    r.mval = st[dd];
+    r.dinv = st[24];
+    r.sp = st[22 + K.spoff];
+    r.P = ld3(L.ccP[rs]);
+    r.dir = KIND == 1 ? mk3(0.f, 0.f, 1.f) : ld3(L.ccdir[rs][KIND == 2 ? 0 : 1]);
+    r.k = L.ccbody[rs];
+    return r;
+}
+template <int KIND>
+__device__ __forceinline__ void finish_slot(const SlotRaw& r, const LaneK& K, float sJ, float sM, float& RJ, float& RM) {
+    float v = dot(K.aL, cross(r.P - K.oL, r.dir));
+    v = K.d == 3 ? r.dir.x : (K.d == 4 ? r.dir.y : (K.d == 5 ? r.dir.z : v));
+    const float jd = (K.bL <= r.k) ? v : 0.0f;
+    float rj = (K.isdof ? jd * r.dinv : r.sp * K.m22) * sJ;
+    float rm = (K.isdof ? r.mval : r.sp * K.m24) * sM;
+    if (!r.valid) { rj = 0.f; rm = 0.f; }
     const bool mine = KIND == 2 ? (K.h == 0) : (KIND == 3 ? (K.h == 1) : true);
     RJ = mine ? rj : RJ;
     RM = mine ? rm : RM;
+}
+// eight consecutive slots BASE .. BASE+7 of one kind, software-pipelined by one slot
+template <class LT, int KIND, int BASE, int DST>
+__device__ __forceinline__ void load_slots8(LT& L, const LaneK& K, int count, float sJ, float sM, float (&RJ)[kSlots],
+                                            float (&RM)[kSlots]) {
+    SlotRaw cur = fetch_slot<LT, KIND>(L, K, BASE, count);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        SlotRaw nxt = cur;
+        if (i < 7) nxt = fetch_slot<LT, KIND>(L, K, BASE + i + 1, count);
+        finish_slot<KIND>(cur, K, sJ, sM, RJ[DST + BASE + i], RM[DST + BASE + i]);
+        cur = nxt;
+    }
 }
 
 // old with lane l replaced by a wave-uniform value (once per substep: a select is fine)
@@ -454,14 +494,6 @@ __device__ __forceinline__ float motor_step(const float RMj, float& dv, const fl
     return s;
 }
 
-// slot map (two rows per slot) and the layout of the accumulated impulses handed back in L.app
-constexpr int kSlotNormal = 0;    // 32 slots: contacts 2s (lower half), 2s+1 (upper half)
-constexpr int kSlotFric = 32;     // 64 slots: contact s, direction A lower / B upper
-constexpr int kSlots = 96;
-constexpr int kAppMotor = 0;      // app[j]                motor j
-constexpr int kAppNormal = 16;    // app[16 + ci]          normal of contact ci
-constexpr int kAppFric = 80;      // app[80 + 2 ci + {0,1}] friction A / B of contact ci
-constexpr unsigned long long kLowMask = 0x00000000FFFFFFFFull;
 
 template <bool RES, int BASE>
 __device__ __forceinline__ void duos4(float (&RJ)[kSlots], float (&RM)[kSlots], float& dv, float E3163, float& lsq) {
@@ -552,9 +584,15 @@ __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane, f
     constexpr int ND = N + 6;
     static_assert(N == 16, "v2 is laid out for the 16-link chain");
     const float dt = M.dt;
+#ifdef SNK_PROFILE
+    unsigned long long prof_t[17];
+#endif
+    SNK_STAMP(0)
     // (1) contacts of the current pose, (2) bias forces with gravity, joint damping torque
-    const int nc = __builtin_amdgcn_readfirstlane(find_contacts_v2(L, M, lane));
+    unsigned long long cslots;   // bit s: contact slot s (cylinder s/2, end cap s&1) is active
+    const int nc = __builtin_amdgcn_readfirstlane(find_contacts_v2(L, M, lane, cslots));
     ncontacts = nc;
+    SNK_STAMP(1)
     if (lane < N) {
         float qd = L.qd()[lane];
         L.qd_old[lane] = qd;
@@ -563,6 +601,7 @@ __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane, f
     body_bias<LT, true>(L, M, lane);
     lds_sync();
     aba_main<LT, true>(L, M, lane);
+    SNK_STAMP(2)
     // joint-0 force sensor, first pass [U] (parked in LDS: nothing but rows may live across the solve)
     {
         f3 zb = mulRv(L.R[0], ld3(M.zbase));
@@ -582,6 +621,7 @@ __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane, f
     }
     lds_sync();
 
+    SNK_STAMP(3)
     // (4) rows -> registers.  The lane=row builder needs ~60 registers of its own, so it only
     // runs while at most the 128 friction-row registers are live: motors go to LDS first,
     // then friction A, friction B, normals through the 64-row staging, motors are loaded last.
@@ -602,41 +642,35 @@ __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane, f
                                      : mk3(K.d == 0 ? 1.f : 0.f, K.d == 1 ? 1.f : 0.f, K.d == 2 ? 1.f : 0.f);
         const float fJ = mu > 0.f ? 1.0f / mu : 0.f, fM = mu > 0.f ? mu : 0.f;
         build_batch_v2<LT, 0>(L, M, lane, nc);
+        SNK_STAMP(4)
         build_batch_v2<LT, 2>(L, M, lane, nc);
+        SNK_STAMP(5)
+#define SNK_LOAD8(KIND, G, DST, SJ, SM)                                                            \
+    if (nc > 8 * G) load_slots8<LT, KIND, 8 * G, DST>(L, K, nc, SJ, SM, RJ, RM);
 #pragma unroll
-        for (int g = 0; g < 8; g++) {
-            if (nc > 8 * g) {
-#pragma unroll
-                for (int s = 8 * g; s < 8 * g + 8; s++) {
-                    RJ[kSlotFric + s] = 0.f; RM[kSlotFric + s] = 0.f;
-                    load_slot<LT, 2>(L, K, s, nc, fJ, fM, RJ[kSlotFric + s], RM[kSlotFric + s]);
-                }
-            } else {
-#pragma unroll
-                for (int s = 8 * g; s < 8 * g + 8; s++) { RJ[kSlotFric + s] = 0.f; RM[kSlotFric + s] = 0.f; }
-            }
-        }
+        for (int s = 0; s < kSlots - kSlotFric; s++) { RJ[kSlotFric + s] = 0.f; RM[kSlotFric + s] = 0.f; }
+        SNK_LOAD8(2, 0, kSlotFric, fJ, fM) SNK_LOAD8(2, 1, kSlotFric, fJ, fM) SNK_LOAD8(2, 2, kSlotFric, fJ, fM)
+        SNK_LOAD8(2, 3, kSlotFric, fJ, fM) SNK_LOAD8(2, 4, kSlotFric, fJ, fM) SNK_LOAD8(2, 5, kSlotFric, fJ, fM)
+        SNK_LOAD8(2, 6, kSlotFric, fJ, fM) SNK_LOAD8(2, 7, kSlotFric, fJ, fM)
         lds_sync();
+        SNK_STAMP(6)
         build_batch_v2<LT, 3>(L, M, lane, nc);
-#pragma unroll
-        for (int g = 0; g < 8; g++) {
-            if (nc > 8 * g) {
-#pragma unroll
-                for (int s = 8 * g; s < 8 * g + 8; s++) load_slot<LT, 3>(L, K, s, nc, fJ, fM, RJ[kSlotFric + s], RM[kSlotFric + s]);
-            }
-        }
+        SNK_STAMP(7)
+        SNK_LOAD8(3, 0, kSlotFric, fJ, fM) SNK_LOAD8(3, 1, kSlotFric, fJ, fM) SNK_LOAD8(3, 2, kSlotFric, fJ, fM)
+        SNK_LOAD8(3, 3, kSlotFric, fJ, fM) SNK_LOAD8(3, 4, kSlotFric, fJ, fM) SNK_LOAD8(3, 5, kSlotFric, fJ, fM)
+        SNK_LOAD8(3, 6, kSlotFric, fJ, fM) SNK_LOAD8(3, 7, kSlotFric, fJ, fM)
         lds_sync();
+        SNK_STAMP(8)
         build_batch_v2<LT, 1>(L, M, lane, nc);
+        SNK_STAMP(9)
 #pragma unroll
-        for (int g = 0; g < 4; g++) {
-            if (nc > 16 * g) {
-#pragma unroll
-                for (int s = 8 * g; s < 8 * g + 8; s++) load_slot<LT, 1>(L, K, s, nc, 1.0f, 1.0f, RJ[kSlotNormal + s], RM[kSlotNormal + s]);
-            } else {
-#pragma unroll
-                for (int s = 8 * g; s < 8 * g + 8; s++) { RJ[kSlotNormal + s] = 0.f; RM[kSlotNormal + s] = 0.f; }
-            }
-        }
+        for (int s = 0; s < kSlotFric; s++) { RJ[kSlotNormal + s] = 0.f; RM[kSlotNormal + s] = 0.f; }
+        // a normal slot holds contacts 2s, 2s+1: 8 slots per 16 contacts
+        if (nc > 0) load_slots8<LT, 1, 0, kSlotNormal>(L, K, nc, 1.0f, 1.0f, RJ, RM);
+        if (nc > 16) load_slots8<LT, 1, 8, kSlotNormal>(L, K, nc, 1.0f, 1.0f, RJ, RM);
+        if (nc > 32) load_slots8<LT, 1, 16, kSlotNormal>(L, K, nc, 1.0f, 1.0f, RJ, RM);
+        if (nc > 48) load_slots8<LT, 1, 24, kSlotNormal>(L, K, nc, 1.0f, 1.0f, RJ, RM);
+#undef SNK_LOAD8
         // motors: column 6+j of M^-1 (divided by the row's denominator) in both halves;
         // target velocity change of motor j in lane 6+j
 #pragma unroll
@@ -652,6 +686,7 @@ __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane, f
         lds_sync();
     }
 
+    SNK_STAMP(10)
     // coupling scalar of each duo, once per substep:  lane 57 of RJ <- RJ_upper . RM_lower
     // (the upper row is resolved after the lower one).  Pyramid friction resolves the two
     // directions of a contact one after the other, so its slots are duos as well.
@@ -672,6 +707,7 @@ __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane, f
         }
     }
 
+    SNK_STAMP(11)
     // violated joint limits (rare): kept as LDS rows, processed by a generic path
     int nlim = 0;
     {
@@ -698,6 +734,7 @@ __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane, f
         if (nlim) lds_sync();
     }
 
+    SNK_STAMP(12)
     // (5) projected Gauss-Seidel on the register-resident rows
     float dv;
     {
@@ -777,17 +814,29 @@ __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane, f
     }
     lds_sync();
 
+    SNK_STAMP(13)
     // (6) constraint pass for the joint-0 sensor [U]
+    // lane = contact: its force and its moment about the body's joint origin (staging rows are
+    // free now); then lane = body sums its <= 4 contacts (slots 4b-2 .. 4b+1) in contact order
+    if (lane < nc) {
+        const int ci = lane, k = L.ccbody[ci];
+        f3 F = (mk3(0.f, 0.f, 1.f) * L.app[kAppNormal + ci] +
+                ld3(L.ccdir[ci][0]) * L.app[kAppFric + 2 * ci] +
+                ld3(L.ccdir[ci][1]) * L.app[kAppFric + 2 * ci + 1]) * M.inv_dt;
+        st3(&L.stM[ci][0], cross(ld3(L.ccP[ci]) - ld3(L.o[k]), F));
+        st3(&L.stM[ci][3], F);
+    }
+    lds_sync();
     if (lane <= N) {
         const int b = lane;
         f3 eN = mk3(0, 0, 0), eF = mk3(0, 0, 0);
-        for (int ci = 0; ci < nc; ci++) {
-            if (L.ccbody[ci] == b) {
-                f3 F = (mk3(0.f, 0.f, 1.f) * L.app[kAppNormal + ci] +
-                        ld3(L.ccdir[ci][0]) * L.app[kAppFric + 2 * ci] +
-                        ld3(L.ccdir[ci][1]) * L.app[kAppFric + 2 * ci + 1]) * M.inv_dt;
-                eF = eF + F;
-                eN = eN + cross(ld3(L.ccP[ci]) - ld3(L.o[b]), F);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int sl = 4 * b - 2 + j;
+            if (sl >= 0 && sl < 64 && ((cslots >> sl) & 1ull)) {
+                const int ci = __popcll(cslots & ((1ull << sl) - 1ull));
+                eN = eN + ld3(&L.stM[ci][0]);
+                eF = eF + ld3(&L.stM[ci][3]);
             }
         }
         st3(&L.ext[b][0], eN);
@@ -812,6 +861,7 @@ __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane, f
         }
     }
     lds_sync();
+    SNK_STAMP(14)
     body_bias<LT, false>(L, M, lane);
     lds_sync();
     aba_main<LT, false>(L, M, lane);
@@ -823,6 +873,7 @@ __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane, f
         f3 a2 = ld3(&L.acc0[3]);
         fz = L.fz_park - dot(zb, a2 * M.m_root + v1 * (M.m_root * (M.lin_damp + M.lin_damp * nv1)));
     }
+    SNK_STAMP(15)
     // (7) apply the solver's delta-v (lower half's copy), motor torques, integrate positions
     if (lane < 6) {
         float x = L.base()[7 + lane] + dv;
@@ -860,6 +911,12 @@ __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane, f
     }
     lds_sync();
     fk_vel(L, M, lane);
+#ifdef SNK_PROFILE
+    SNK_STAMP(16)
+    lds_sync();
+    if (lane < 16) L.taum()[lane] = (float)(prof_t[lane + 1] - prof_t[lane]);
+    lds_sync();
+#endif
 }
 
 }  // namespace snk
