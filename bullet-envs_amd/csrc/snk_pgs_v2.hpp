@@ -303,17 +303,19 @@ __device__ __forceinline__ void finish_slot(const SlotRaw& r, const LaneK& K, fl
     RJ = mine ? rj : RJ;
     RM = mine ? rm : RM;
 }
-// eight consecutive slots BASE .. BASE+7 of one kind, software-pipelined by one slot
+// eight consecutive slots BASE .. BASE+7 of one kind, reads issued two slots ahead
 template <class LT, int KIND, int BASE, int DST>
 __device__ __forceinline__ void load_slots8(LT& L, const LaneK& K, int count, float sJ, float sM, float (&RJ)[kSlots],
                                             float (&RM)[kSlots]) {
-    SlotRaw cur = fetch_slot<LT, KIND>(L, K, BASE, count);
+    SlotRaw r0 = fetch_slot<LT, KIND>(L, K, BASE, count);
+    SlotRaw r1 = fetch_slot<LT, KIND>(L, K, BASE + 1, count);
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-        SlotRaw nxt = cur;
-        if (i < 7) nxt = fetch_slot<LT, KIND>(L, K, BASE + i + 1, count);
-        finish_slot<KIND>(cur, K, sJ, sM, RJ[DST + BASE + i], RM[DST + BASE + i]);
-        cur = nxt;
+        SlotRaw r2 = r1;
+        if (i < 6) r2 = fetch_slot<LT, KIND>(L, K, BASE + i + 2, count);
+        finish_slot<KIND>(r0, K, sJ, sM, RJ[DST + BASE + i], RM[DST + BASE + i]);
+        r0 = r1;
+        r1 = r2;
     }
 }
 

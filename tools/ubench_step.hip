@@ -293,7 +293,7 @@ __device__ __forceinline__ void cone_x2(float& RJ, const float RM, const float R
 using namespace snk;
 constexpr unsigned long long kLowMask = 0x00000000FFFFFFFFull;
 template <int MODE>
-__global__ __launch_bounds__(64, 2) void k(float* out, unsigned long long* cyc, float seed, float accinit) {
+__global__ __launch_bounds__(64) void k(float* out, unsigned long long* cyc, float seed, float accinit) {
     const int lane = threadIdx.x, d = lane & 31;
     float RJ[8], RM[8];
 #pragma unroll
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(64, 2) void k(float* out, unsigned long long* cyc, 
 }
 template <int MODE>
 void run(const char* name, float accinit = 0.01f) {
-    for (int blocks : {1024, 2048}) {
+    for (int blocks : {1024, 2048, 3072, 4096, 8192}) {
         float* dd; unsigned long long* c;
         (void)hipMalloc(&dd, blocks * 64 * 4); (void)hipMalloc(&c, blocks * 8);
         hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(64), 0, 0, dd, c, 0.3f, accinit);
