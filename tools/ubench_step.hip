@@ -1,6 +1,7 @@
 // Isolated timing of the solve loop's row steps (ticks per step, 1 and 2 waves per SIMD).
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 #define N_IT 1000
 __device__ __forceinline__ unsigned long long now() { unsigned long long t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); return t; }
@@ -191,78 +192,60 @@ __device__ __forceinline__ float motor_step(const float RMj, float& dv, const fl
 
 
 // ---- experimental variants ----
-template <int NL>
-__device__ __forceinline__ void cone_x1(float& RJ, const float RM, const float RJnorm, float& dv, float EPS,
-                                          float E3163, unsigned long long lowmask, float& lsq) {
+// normal duo that also records "new accumulated impulse == 0" of its two rows in bit BIT / BIT+1 of z
+template <int BIT>
+__device__ __forceinline__ void duo_z(float& RJ, const float RM, float& dv, float E3163, unsigned long long lowmask, float& lsq,
+                                      unsigned& z) {
+    float t, x, dF, dS, c2;
+    float s0, s1, s2, s3, s4;
+    unsigned tz;
+    asm volatile(
+        SNK_DUO_HEAD
+        "v_max_f32_e64 %[dF], -%[s0], 0\n\t"
+        "v_mov_b32 %[x], %[s1]\n\t"
+        "v_cmp_eq_f32 vcc, 0, %[dF]\n\t"
+        "v_subrev_f32 %[dF], %[s2], %[dF]\n\t"
+        "v_fmac_f32 %[x], %[s4], %[dF]\n\t"
+        "s_and_b32 %[tz], vcc_lo, %[BL]\n\t"
+        "v_max_f32_e64 %[x], -%[x], 0\n\t"
+        "s_or_b32 %[z], %[z], %[tz]\n\t"
+        "v_cmp_eq_f32 vcc, 0, %[x]\n\t"
+        "v_subrev_f32 %[dS], %[s3], %[x]\n\t"
+        "v_cndmask_b32_e64 %[t], %[dS], %[dF], %[lowmask]\n\t"
+        "v_mul_f32 %[x], %[RM], %[t]\n\t"
+        "s_and_b32 %[tz], vcc_lo, %[BU]\n\t"
+        "v_mul_f32 %[c2], %[RM], %[t]\n\t"
+        "s_or_b32 %[z], %[z], %[tz]\n\t"
+        "v_fmac_f32 %[RJ], %[E], %[t]\n\t"
+        "s_nop 0\n\t"
+        "v_permlane32_swap_b32 %[x], %[c2]\n\t"
+        "v_add_f32 %[dv], %[dv], %[x]\n\t"
+        "v_add_f32 %[dv], %[dv], %[c2]\n\t"
+        "v_max3_f32 %[lsq], %[lsq], |%[x]|, |%[c2]|\n\t"
+        : [t] "=&v"(t), [x] "=&v"(x), [dF] "=&v"(dF), [dS] "=&v"(dS), [c2] "=&v"(c2), [s0] "=&s"(s0), [s1] "=&s"(s1),
+          [s2] "=&s"(s2), [s3] "=&s"(s3), [s4] "=&s"(s4), [tz] "=&s"(tz), [z] "+s"(z), [RJ] "+v"(RJ), [dv] "+v"(dv), [lsq] "+v"(lsq)
+        : [RM] "v"(RM), [E] "v"(E3163), [lowmask] "s"(lowmask), [BL] "n"(1u << BIT), [BU] "n"(1u << (BIT + 1))
+        : "vcc", "scc");
+}
+// cone that is skipped when bit BIT of zb is set
+template <int NL, int BIT>
+__device__ __forceinline__ void cone_z(float& RJ, const float RM, const float RJnorm, float& dv, float EPS,
+                                       float E3163, unsigned long long lowmask, float& lsq, unsigned zb) {
     float t, xA, xB, r2, c2;
     float s0, s1, s2, s3, s4;
     asm volatile(
-        "v_mul_f32 %[t], %[RJ], %[dv]\n\t"
-        "v_readlane_b32 %[s4], %[RJnorm], %[NLn]\n\t"
-        "v_readlane_b32 %[s0], %[RJ], 31\n\t"
-        SNK_REDUCE_12
-        "v_readlane_b32 %[s2], %[RJ], 63\n\t"
-        "v_mov_b32 %[xA], %[s0]\n\t"
-        SNK_REDUCE_22
-        "v_mov_b32 %[xB], %[s2]\n\t"
-        "s_nop 0\n\t"
-        "v_add_f32_dpp %[t], %[t], %[t] row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "s_nop 1\n\t"
-        "v_add_f32_dpp %[t], %[t], %[t] row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "s_nop 1\n\t"
-        "v_add_f32_dpp %[t], %[t], %[t] row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-        "s_nop 0\n\t"
-        "v_readlane_b32 %[s1], %[t], 31\n\t"
-        "v_readlane_b32 %[s3], %[t], 63\n\t"
-        "s_nop 0\n\t"
-        "v_fma_f32 %[r2], %[s1], %[s1], %[EPS]\n\t"
-        "v_fma_f32 %[r2], %[s3], %[s3], %[r2]\n\t"
-        "v_rsq_f32 %[r2], %[r2]\n\t"
-        "s_nop 0\n\t"
-        "v_mul_f32_e64 %[r2], %[s4], %[r2] clamp\n\t"
-        "v_fma_f32 %[xA], %[r2], -%[s1], -%[xA]\n\t"
-        "v_fma_f32 %[xB], %[r2], -%[s3], -%[xB]\n\t"
-        "v_cndmask_b32_e64 %[t], %[xB], %[xA], %[lowmask]\n\t"
-        "v_mul_f32 %[r2], %[RM], %[t]\n\t"
-        "v_mul_f32 %[c2], %[RM], %[t]\n\t"
-        "v_fmac_f32 %[RJ], %[E], %[t]\n\t"
-        "v_permlane32_swap_b32 %[r2], %[c2]\n\t"
-        "s_nop 0\n\t"
-        "v_add_f32 %[dv], %[dv], %[r2]\n\t"
-        "v_add_f32 %[dv], %[dv], %[c2]\n\t"
-        "v_max3_f32 %[lsq], %[lsq], |%[r2]|, |%[c2]|\n\t"
-        : [t] "=&v"(t), [xA] "=&v"(xA), [xB] "=&v"(xB), [r2] "=&v"(r2), [c2] "=&v"(c2),
-          [s0] "=&s"(s0), [s1] "=&s"(s1), [s2] "=&s"(s2), [s3] "=&s"(s3), [s4] "=&s"(s4), [RJ] "+v"(RJ), [dv] "+v"(dv), [lsq] "+v"(lsq)
-        : [RM] "v"(RM), [RJnorm] "v"(RJnorm), [EPS] "v"(EPS), [E] "v"(E3163), [lowmask] "s"(lowmask),
-          [NLn] "n"(NL));
-}
-// with the inert-contact skip
-template <int NL>
-__device__ __forceinline__ void cone_x2(float& RJ, const float RM, const float RJnorm, float& dv, float EPS,
-                                          float E3163, unsigned long long lowmask, float& lsq) {
-    float t, xA, xB, r2, c2;
-    float s0, s1, s2, s3, s4, s5;
-    asm volatile(
-        "v_readlane_b32 %[s4], %[RJnorm], %[NLn]\n\t"
-        "v_readlane_b32 %[s0], %[RJ], 31\n\t"
-        "v_readlane_b32 %[s2], %[RJ], 63\n\t"
-        "v_mul_f32 %[t], %[RJ], %[dv]\n\t"
-        "s_or_b32 %[s5], %[s4], %[s0]\n\t"
-        "s_or_b32 %[s5], %[s5], %[s2]\n\t"
-        "s_bitset0_b32 %[s5], 31\n\t"
-        "s_cmp_eq_u32 %[s5], 0\n\t"
+        "s_bitcmp1_b32 %[zb], %[BIT]\n\t"
         "s_cbranch_scc1 .Lskip%=\n\t"
+        "v_mul_f32 %[t], %[RJ], %[dv]\n\t"
+        "v_readlane_b32 %[s4], %[RJnorm], %[NLn]\n\t"
+        "v_readlane_b32 %[s0], %[RJ], 31\n\t"
         SNK_REDUCE_12
+        "v_readlane_b32 %[s2], %[RJ], 63\n\t"
         "v_mov_b32 %[xA], %[s0]\n\t"
-        "v_mov_b32 %[xB], %[s2]\n\t"
         SNK_REDUCE_22
-        "s_nop 1\n\t"
-        "v_add_f32_dpp %[t], %[t], %[t] row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "s_nop 1\n\t"
-        "v_add_f32_dpp %[t], %[t], %[t] row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "s_nop 1\n\t"
-        "v_add_f32_dpp %[t], %[t], %[t] row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "v_mov_b32 %[xB], %[s2]\n\t"
         "s_nop 0\n\t"
+        SNK_REDUCE_345
         "v_readlane_b32 %[s1], %[t], 31\n\t"
         "v_readlane_b32 %[s3], %[t], 63\n\t"
         "s_nop 0\n\t"
@@ -277,18 +260,18 @@ __device__ __forceinline__ void cone_x2(float& RJ, const float RM, const float R
         "v_mul_f32 %[r2], %[RM], %[t]\n\t"
         "v_mul_f32 %[c2], %[RM], %[t]\n\t"
         "v_fmac_f32 %[RJ], %[E], %[t]\n\t"
-        "v_permlane32_swap_b32 %[r2], %[c2]\n\t"
         "s_nop 0\n\t"
+        "v_permlane32_swap_b32 %[r2], %[c2]\n\t"
         "v_add_f32 %[dv], %[dv], %[r2]\n\t"
         "v_add_f32 %[dv], %[dv], %[c2]\n\t"
         "v_max3_f32 %[lsq], %[lsq], |%[r2]|, |%[c2]|\n\t"
         ".Lskip%=:\n\t"
         : [t] "=&v"(t), [xA] "=&v"(xA), [xB] "=&v"(xB), [r2] "=&v"(r2), [c2] "=&v"(c2),
-          [s0] "=&s"(s0), [s1] "=&s"(s1), [s2] "=&s"(s2), [s3] "=&s"(s3), [s4] "=&s"(s4), [s5] "=&s"(s5), [RJ] "+v"(RJ), [dv] "+v"(dv), [lsq] "+v"(lsq)
-        : [RM] "v"(RM), [RJnorm] "v"(RJnorm), [EPS] "v"(EPS), [E] "v"(E3163), [lowmask] "s"(lowmask),
-          [NLn] "n"(NL) : "scc");
+          [s0] "=&s"(s0), [s1] "=&s"(s1), [s2] "=&s"(s2), [s3] "=&s"(s3), [s4] "=&s"(s4), [RJ] "+v"(RJ), [dv] "+v"(dv), [lsq] "+v"(lsq)
+        : [RM] "v"(RM), [RJnorm] "v"(RJnorm), [EPS] "v"(EPS), [E] "v"(E3163), [lowmask] "s"(lowmask), [zb] "s"(zb),
+          [NLn] "n"(NL), [BIT] "n"(BIT)
+        : "scc");
 }
-
 }
 using namespace snk;
 constexpr unsigned long long kLowMask = 0x00000000FFFFFFFFull;
@@ -299,6 +282,7 @@ __global__ __launch_bounds__(64) void k(float* out, unsigned long long* cyc, flo
 #pragma unroll
     for (int s = 0; s < 8; s++) { RJ[s] = d < 22 ? seed * (s + 1) * 1e-3f * (d + 1) : (d == 31 ? accinit : 0.f); RM[s] = d < 22 ? 1e-4f * (d - s) : 0.f; }
     float dv = d == 22 ? 1.f : 0.f, lsq = 0.f, ACCV = 0.f;
+    unsigned zz = 0, zb = __builtin_amdgcn_readfirstlane(accinit == 0.f ? 0xffffffffu : 0u);
     const float E = (d == 31) ? 1.f : 0.f, EPS = 1e-30f;
     unsigned long long t0 = now();
     for (int i = 0; i < N_IT; i++) {
@@ -306,13 +290,13 @@ __global__ __launch_bounds__(64) void k(float* out, unsigned long long* cyc, flo
         for (int s = 0; s < 8; s++) {
             if (MODE == 0) duo_step<true, false>(RJ[s], RM[s], dv, 0.f, E, kLowMask, lsq);
             else if (MODE == 1) cone_step<31, true>(RJ[s], RM[s], RJ[(s + 1) & 7], dv, EPS, E, kLowMask, lsq);
-            else if (MODE == 2) cone_x1<31>(RJ[s], RM[s], RJ[(s + 1) & 7], dv, EPS, E, kLowMask, lsq);
-            else if (MODE == 3) cone_x2<31>(RJ[s], RM[s], RJ[(s + 1) & 7], dv, EPS, E, kLowMask, lsq);
+            else if (MODE == 2) duo_z<4>(RJ[s], RM[s], dv, E, kLowMask, lsq, zz);
+            else if (MODE == 3) cone_z<31, 5>(RJ[s], RM[s], RJ[(s + 1) & 7], dv, EPS, E, kLowMask, lsq, zb);
             else if (MODE == 4) { motor_step<3, false>(RM[s], dv, RJ[s], ACCV, 0.f); }
         }
     }
     unsigned long long t1 = now();
-    float acc = dv + lsq + ACCV;
+    float acc = dv + lsq + ACCV + (float)zz;
 #pragma unroll
     for (int s = 0; s < 8; s++) acc += RJ[s];
     out[blockIdx.x * 64 + threadIdx.x] = acc;
@@ -320,7 +304,7 @@ __global__ __launch_bounds__(64) void k(float* out, unsigned long long* cyc, flo
 }
 template <int MODE>
 void run(const char* name, float accinit = 0.01f) {
-    for (int blocks : {1024, 2048, 3072, 4096, 8192}) {
+    for (int blocks : {1024, 2048}) {
         float* dd; unsigned long long* c;
         (void)hipMalloc(&dd, blocks * 64 * 4); (void)hipMalloc(&c, blocks * 8);
         hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(64), 0, 0, dd, c, 0.3f, accinit);
@@ -333,8 +317,14 @@ void run(const char* name, float accinit = 0.01f) {
         (void)hipFree(dd); (void)hipFree(c);
     }
 }
-int main() {
-    run<0>("duo (normals)"); run<1>("cone"); run<2>("cone x1 (nops trimmed)"); run<3>("cone x2 (skip test, active)");
-    run<3>("cone x2 (skip test, all inert)", 0.0f); run<4>("motor direct");
+int main(int argc, char** argv) {
+    int m = argc > 1 ? atoi(argv[1]) : -1;
+    setvbuf(stdout, nullptr, _IONBF, 0);
+    if (m < 0 || m == 0) run<0>("duo (normals)");
+    if (m < 0 || m == 2) run<2>("duo + zero flags");
+    if (m < 0 || m == 1) run<1>("cone");
+    if (m < 0 || m == 3) run<3>("cone + skip bit (active)");
+    if (m < 0 || m == 5) run<3>("cone + skip bit (all inert)", 0.0f);
+    if (m < 0 || m == 4) run<4>("motor direct");
     return 0;
 }
