@@ -116,6 +116,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--policy", action="store_true",
+                    help="not the BASELINE metric: actions sampled from an on-device 2x256 actor-critic "
+                         "(bullet-envs_amd/rollout.py, SURVEY 8(f)-1) instead of the precomputed gait; 1 GPU")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -165,7 +168,24 @@ def main():
     else:
         local.reset()
 
+    net = None
+    if args.policy:
+        assert world == 1, "--policy measures one GPU"
+        torch.manual_seed(0)
+        net = pkg.rollout.ActorCritic(local.obs_dim, A, [256, 256]).to(dev)
+        pol_state = {"obs": local.obs}
+
     def one_step(j):
+        if net is not None:
+            with torch.no_grad():
+                mu, sigma, _value = net.heads(pol_state["obs"])
+                act = torch.normal(mu, sigma)
+            obs, rew, done = local.step(act)
+            sub_total.add_(local.substeps.sum())
+            h_obs.copy_(obs, non_blocking=True)
+            h_rew.copy_(rew, non_blocking=True)
+            h_done.copy_(done.to(torch.bool), non_blocking=True)
+            return
         if world > 1:
             obs, rew, done, _ = env.step(acts_all[j] if rank == 0 else None)
         else:
@@ -222,7 +242,8 @@ def main():
         except Exception:  # noqa: BLE001
             pass
         out = {
-            "metric": "env-steps/sec (whole node), 16-link snake, 4096 envs/GPU",
+            "metric": "env-steps/sec (whole node), 16-link snake, 4096 envs/GPU" + (
+                " -- with on-device policy inference (not the BASELINE metric)" if args.policy else ""),
             "value": n_env_steps / elapsed,
             "unit": "env-steps/s",
             "n_gpus": world, "steps": K, "warmup": W,
@@ -230,8 +251,9 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": ("%d envs/GPU x 16-link snake, flat ground plane, serpenoid gait actions "
-                             "(BASELINE configs[%d])" % (E, 1 if world == 1 else 2)),
+                "workload": ("%d envs/GPU x 16-link snake, flat ground plane, %s "
+                             "(BASELINE configs[%d])" % (E, "actions sampled from a random-init 2x256 actor-critic on the GPU"
+                                                         if args.policy else "serpenoid gait actions", 1 if world == 1 else 2)),
                 "envs_per_gpu": E, "n_links": N_LINKS,
                 "parallelism": "envs sharded over %d GPU(s), no data-path collective; "
                                "RCCL actions scatter + obs/reward/done gather to rank 0" % world

@@ -8,3 +8,4 @@ from ._lib import SnkParams, Stepper, default_params, load, LIB_PATH  # noqa: F4
 from .snake_env import (Snake, SnakeGymEnv, SnakeVecEnv, SubprocVecEnv, VecEnv,  # noqa: F401
                         params_from_args)
 from .device_env import DeviceVecEnv, ShardedVecEnv  # noqa: F401
+from . import rollout  # noqa: F401  (on-device policy inference / rollout buffer)
