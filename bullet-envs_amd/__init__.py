@@ -8,4 +8,10 @@ from ._lib import SnkParams, Stepper, default_params, load, LIB_PATH  # noqa: F4
 from .snake_env import (Snake, SnakeGymEnv, SnakeVecEnv, SubprocVecEnv, VecEnv,  # noqa: F401
                         params_from_args)
 from .device_env import DeviceVecEnv, ShardedVecEnv  # noqa: F401
-from . import rollout  # noqa: F401  (on-device policy inference / rollout buffer)
+from . import checkpoint  # noqa: F401  (simulator-state checkpoints)
+from .checkpoint import save_state, load_state  # noqa: F401
+try:        # the trainer-side pieces need torch; the env itself does not
+    from . import rollout  # noqa: F401  (on-device policy inference / rollout buffer)
+    from . import ars  # noqa: F401      (ARS normaliser + linear policies on device)
+except ImportError:  # pragma: no cover
+    rollout = ars = None

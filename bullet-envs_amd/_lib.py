@@ -217,6 +217,7 @@ class Stepper:
         m = np.ascontiguousarray(mu, dtype=np.float32)
         assert m.shape == (self.n_envs,)
         check(self.lib.snk_set_ground_friction(self.h, fptr(m)), "snk_set_ground_friction")
+        self.ground_friction = m.copy()      # kept for checkpoint.save_state
 
     def model_describe(self):
         bodies = np.zeros((self.n + 1, 10))

@@ -1,0 +1,107 @@
+"""the ARS observation normaliser / linear policies batched on the device
+(bullet-envs_amd/ars.py) against vectors produced by running the reference's own definitions
+(tests/golden/make_ars_vectors.py), and simulator-state checkpoints (bullet-envs_amd/checkpoint.py)."""
+import importlib
+import os
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden", "ars_vectors.npz")
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    return importlib.import_module("bullet-envs_amd")
+
+
+def test_batched_normalizer_reproduces_sequential_reference(pkg):
+    g = np.load(GOLD)
+    nz = pkg.ars.Normalizer([1, 56])
+    for step in range(3):
+        Y = nz.observe_normalize(g["X%d" % step])
+        assert np.allclose(Y.numpy(), g["Y%d" % step], rtol=1e-9, atol=1e-10)
+        for k in ("n", "mean", "mean_diff", "var"):
+            assert np.allclose(getattr(nz, k).numpy(), g["%s%d" % (k, step)], rtol=1e-9, atol=1e-11), (k, step)
+    act = pkg.ars.policy(torch.tensor(g["Y2"]), torch.tensor(g["W"]))
+    assert act.shape == (6, 8, 1) and np.allclose(act.numpy(), g["actions"], rtol=1e-10, atol=1e-12)
+    # eval mode: statistics frozen
+    before = nz.mean.clone()
+    Z = nz.observe_normalize(g["X0"], observe=False)
+    assert torch.equal(nz.mean, before) and np.allclose(Z.numpy(), (g["X0"] - g["mean2"]) / np.sqrt(g["var2"]))
+
+
+def test_single_observe_equals_batch_of_one(pkg):
+    g = np.load(GOLD)
+    a, b = pkg.ars.Normalizer(56), pkg.ars.Normalizer(56)
+    for r in range(6):
+        a.observe(g["X0"][r])
+        ya = a.normalize(g["X0"][r])
+        yb = b.observe_normalize(g["X0"][r:r + 1])[0]
+        assert torch.allclose(ya, yb, rtol=1e-12, atol=1e-13)
+    assert torch.allclose(a.var, b.var) and torch.equal(a.n, b.n)
+
+
+def test_store_restore_uses_reference_files(pkg, tmp_path):
+    g = np.load(GOLD)
+    nz = pkg.ars.Normalizer([1, 56])
+    nz.observe_normalize(g["X0"])
+    nz.store(str(tmp_path))
+    assert np.loadtxt(str(tmp_path / "mean.txt")).shape == (56,)      # what ars/test.py:108 reads back
+    other = pkg.ars.Normalizer([1, 56])
+    other.restore(str(tmp_path))
+    assert torch.allclose(other.mean, nz.mean) and torch.allclose(other.var, nz.var)
+
+
+def test_float32_on_device_dtype(pkg):
+    nz = pkg.ars.Normalizer(56, dtype=torch.float32)
+    X = torch.randn(4096, 56)
+    Y = nz.observe_normalize(X)
+    assert Y.dtype == torch.float32 and float(nz.n[0]) == 4096.0
+    assert torch.allclose(nz.mean, X.mean(dim=0), atol=1e-4)
+
+
+@pytest.mark.gpu
+def test_checkpoint_resumes_bit_for_bit(pkg, tmp_path):
+    from bench import gait_actions
+    n = 256
+    mu = np.random.default_rng(2).uniform(0.5, 1.5, n).astype(np.float32)
+    a_env = pkg.SnakeVecEnv(n)
+    a_env.set_ground_friction(mu)
+    a_env.reset()
+    for j in range(3):
+        a_env.step(gait_actions(np.arange(n), j).astype(np.float32))
+    path = str(tmp_path / "ck.npz")
+    pkg.save_state(a_env, path)
+    ref = [a_env.step(gait_actions(np.arange(n), j).astype(np.float32)) for j in range(3, 6)]
+    b_env = pkg.SnakeVecEnv(n)                # fresh handle, rest pose, default friction
+    pkg.load_state(b_env, path)
+    for j, (obs, rew, done, _) in zip(range(3, 6), ref):
+        o2, r2, d2, _ = b_env.step(gait_actions(np.arange(n), j).astype(np.float32))
+        assert np.array_equal(obs, o2) and np.array_equal(rew, r2) and np.array_equal(done, d2)
+    with pytest.raises(ValueError):
+        pkg.load_state(pkg.SnakeVecEnv(n // 2), path)
+    a_env.close(); b_env.close()
+
+
+@pytest.mark.gpu
+def test_ars_step_on_device(pkg):
+    """One ARS env-step for 64 directions with obs, normaliser, weights and actions on the GPU."""
+    n = 64
+    env = pkg.DeviceVecEnv(n)
+    dev = env.device
+    nz = pkg.ars.Normalizer([1, 56], device=dev, dtype=torch.float32)
+    gen = torch.Generator(device=dev).manual_seed(4)
+    W = torch.randn(n, 8, 56, device=dev, generator=gen) * 0.03
+    state = env.reset().clone()
+    tot = torch.zeros(n, device=dev)
+    for _ in range(3):
+        act = pkg.ars.policy(nz.observe_normalize(state), W)              # [n, 8, 1]
+        obs, rew, done = env.step(act.reshape(n, 8).contiguous())
+        tot += rew
+        state = obs.clone()
+    torch.cuda.synchronize()
+    assert float(nz.n[0]) == 3 * n and torch.isfinite(tot).all() and torch.isfinite(state).all()
+    env.close()
