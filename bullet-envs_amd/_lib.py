@@ -62,6 +62,7 @@ SYMBOLS = {
     "snk_set_state": (C.c_int, [_vp, _F, _F]),
     "snk_get_obs": (C.c_int, [_vp, _F]),
     "snk_mean_height": (C.c_int, [_vp, _F]),
+    "snk_link_positions": (C.c_int, [_vp, _F]),
     "snk_set_ground_friction": (C.c_int, [_vp, _F]),
     "snk_selftest": (C.c_int, [C.c_int32]),
     "snk_timing_enable": (C.c_int, [_vp, C.c_int32]),
@@ -211,6 +212,12 @@ class Stepper:
     def mean_height(self):
         o = np.zeros(self.n_envs, dtype=np.float32)
         check(self.lib.snk_mean_height(self.h, fptr(o)), "snk_mean_height")
+        return o
+
+    def link_positions(self):
+        """[n_envs, 3(n+1)]: getLinkPositions of every env ([x.., y.., z..] of links 0,3,...,3n)."""
+        o = np.zeros((self.n_envs, 3 * (self.n + 1)), dtype=np.float32)
+        check(self.lib.snk_link_positions(self.h, fptr(o)), "snk_link_positions")
         return o
 
     def set_ground_friction(self, mu):

@@ -48,6 +48,7 @@ struct snk_handle {
     float* d_tgt = nullptr;
     int32_t* d_info = nullptr;
     float* d_h = nullptr;
+    float* d_linkpos = nullptr;   // allocated on first snk_link_positions
     int32_t* d_order = nullptr;
     bool plan = true;
     size_t lds_bytes = 0;
@@ -81,9 +82,9 @@ int launch_reset(snk_handle* h, const uint8_t* mask, float* obs, int hard, hipSt
     return 0;
 }
 template <int N>
-int launch_obs(snk_handle* h, float* obs, float* height, hipStream_t st) {
+int launch_obs(snk_handle* h, float* obs, float* height, hipStream_t st, float* linkpos = nullptr) {
     hipLaunchKernelGGL((snk::obs_kernel<N>), dim3(h->n_envs), dim3(64), h->lds_bytes, st, h->d_model, h->d_recs, obs,
-                       height, h->n_envs);
+                       height, linkpos, h->n_envs);
     return 0;
 }
 template <int N>
@@ -365,6 +366,19 @@ int snk_mean_height(snk_handle* h, float* out) {
     if (check_launch()) return 1;
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(out, h->d_h, (size_t)h->n_envs * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int snk_link_positions(snk_handle* h, float* out) {
+    if (!h || !out) return fail("snk_link_positions: null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t bytes = (size_t)h->n_envs * 3 * (h->n + 1) * sizeof(float);
+    if (!h->d_linkpos) HIP_TRY(hipMalloc(&h->d_linkpos, bytes));
+    SNK_DISPATCH(h, launch_obs<16>(h, nullptr, nullptr, nullptr, h->d_linkpos),
+                 launch_obs<32>(h, nullptr, nullptr, nullptr, h->d_linkpos));
+    if (check_launch()) return 1;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, h->d_linkpos, bytes, hipMemcpyDeviceToHost));
     return 0;
 }
 

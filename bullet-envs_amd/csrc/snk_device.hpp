@@ -1058,7 +1058,8 @@ __global__ __launch_bounds__(64) void reset_kernel(float* __restrict__ recs, con
 
 template <int N>
 __global__ __launch_bounds__(64) void obs_kernel(const DevModel* __restrict__ Mp, const float* __restrict__ recs,
-                                                 float* __restrict__ obs, float* __restrict__ height, int n_envs) {
+                                                 float* __restrict__ obs, float* __restrict__ height,
+                                                 float* __restrict__ linkpos, int n_envs) {
     extern __shared__ float4 smem_raw[];
     using LT = Lds<N, (N == 16)>;
     LT& L = *reinterpret_cast<LT*>(smem_raw);
@@ -1068,10 +1069,20 @@ __global__ __launch_bounds__(64) void obs_kernel(const DevModel* __restrict__ Mp
     if (env >= n_envs) return;
     load_rec(L, recs + (size_t)env * LT::REC, lane);
     if (obs) write_obs(L, obs + (size_t)env * (3 * N + 8), lane);
-    if (height) {
+    if (height || linkpos) {
         fk_vel(L, M, lane);
-        float h = mean_height(L, M, lane);
-        if (lane == 0) height[env] = h;
+        if (height) {
+            float h = mean_height(L, M, lane);
+            if (lane == 0) height[env] = h;
+        }
+        if (linkpos && lane <= N) {
+            // getLinkPositions (snake.py:138-146): COM of Bullet links 0,3,...,3n -- the `base` link and
+            // the OUTPUT_BODY links (COM at their joint origin) -- as [x.., y.., z..]
+            f3 c = ld3(L.o[lane]);
+            if (lane == 0) c = c + mulRv(L.R[0], ld3(M.hbase));
+            float* out = linkpos + (size_t)env * 3 * (N + 1);
+            out[lane] = c.x; out[(N + 1) + lane] = c.y; out[2 * (N + 1) + lane] = c.z;
+        }
     }
 }
 

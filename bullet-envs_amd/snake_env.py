@@ -166,7 +166,11 @@ class SnakeGymEnv(object):
         a32 = np.ascontiguousarray(np.asarray(action, dtype=np.float32).reshape(1, -1))
         if a32.shape[1] != self._stepper.act_dim:
             raise SystemError("Action not executed!")
+        if self.mode == 'test':
+            before = self._stepper.get_state()
         obs, rew, done, sub = self._stepper.step(a32, vec_mode=False)
+        if self.mode == 'test':
+            self._record_telemetry(before, a32[0], int(sub[0]), obs[0])
         try:
             for idx in range(len(action)):
                 if action[idx] < -1 or action[idx] > 1:
@@ -183,11 +187,41 @@ class SnakeGymEnv(object):
             info = {}
         return observation, float(rew[0]), bool(done[0]), info
 
+    def _record_telemetry(self, before, clipped_action, n_substeps, final_obs):
+        """Test mode (snake.py:275-293, SnakeGymEnv.py:43-44): the observation and the link
+        positions after every physics substep of this env-step.  The fused step kernel stays the
+        authority for state, reward and termination; the substeps are replayed one at a time on a
+        scratch 1-env handle from the state the step started in (same device code, so the replay
+        ends on the observation the step returned)."""
+        r = self.robot
+        r.imgs, r.step_internal_observations, r.link_positions = [], [], []
+        if getattr(self, "_scratch", None) is None:
+            self._scratch = _lib.Stepper(1, device=self._stepper.device, params=self.params)
+        sc = self._scratch
+        sc.set_state(before[0], before[1])
+        n = r.numMotors
+        targets = np.zeros((1, n), dtype=np.float32)      # createAction + convertActionToJointCommand
+        if self._gaitSelection == 0:
+            targets[0, 0::2] = clipped_action
+        elif self._gaitSelection == 1:
+            targets[0, 1::2] = clipped_action
+        else:
+            targets[0, :] = clipped_action
+        targets *= np.float32(r.SCALING_FACTOR)
+        for _ in range(n_substeps):
+            sc.substep(targets, 1)
+            r.step_internal_observations.append(sc.get_obs()[0].astype(np.float64))
+            r.link_positions.append(sc.link_positions()[0].astype(np.float64))
+        if n_substeps and not np.array_equal(r.step_internal_observations[-1].astype(np.float32), final_obs):
+            raise SystemError("test-mode replay diverged from the step kernel")
+
     def render(self):
         return np.array([])
 
     def close(self):
         self._stepper.close()
+        if getattr(self, "_scratch", None) is not None:
+            self._scratch.close()
 
     def defObservationSpace(self):
         self.observation_space = make_box(self.robot.getObservationLowerBound(),

@@ -122,6 +122,10 @@ int snk_set_state(snk_handle* h, const float* state, const float* aux);
 int snk_get_obs(snk_handle* h, float* obs);
 /* checkSnakeHeight's mean z (snake.py:237-245), host buffer [n_envs]. */
 int snk_mean_height(snk_handle* h, float* out);
+/* Snake.getLinkPositions (snake.py:138-146), the test-mode telemetry of SnakeGymEnv.step's info
+ * (SnakeGymEnv.py:43-44): world COM of Bullet links 0,3,...,3n of every env, host buffer
+ * [n_envs x 3(n+1)] laid out [x_0..x_n, y_0..y_n, z_0..z_n]. */
+int snk_link_positions(snk_handle* h, float* out);
 
 /* BASELINE config 5: per-env lateral friction of the ground plane (reference: plane.urdf = 1). */
 int snk_set_ground_friction(snk_handle* h, const float* mu /* host [n_envs] */);

@@ -288,3 +288,55 @@ def test_sharded_env_over_rccl_world1(pkg):
             assert torch.equal(obs, o2) and torch.equal(rew, r2) and torch.equal(done, d2.bool())
     finally:
         dist.destroy_process_group()
+
+
+def test_link_positions_rest_pose_known_answers(pkg):
+    """snk_link_positions = getLinkPositions (snake.py:138-146) against the URDF-derived rest-pose
+    COM table (tests/golden/appendix_b.json)."""
+    import json
+    import os
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "appendix_b.json")))
+    st = pkg.Stepper(3)
+    st.reset()
+    lp = st.link_positions()
+    assert lp.shape == (3, 51)
+    ref = np.array([g["base_link_com_rest"]] + g["output_body_com_rest"])      # [17, 3]
+    for e in range(3):
+        got = lp[e].reshape(3, 17).T
+        assert np.abs(got - ref).max() < 1e-6
+
+
+def test_test_mode_telemetry(pkg, oracle_mod):
+    """mode='test': info carries the observation and the link positions after every substep
+    (SnakeGymEnv.py:43-44, snake.py:291-293); checked substep by substep against the oracle."""
+    import argparse
+    args = argparse.Namespace(alpha=1.0, beta=0.01, gamma=0.1, mode="test", gaitSelection=1, scaling_factor=6,
+                              motorVelocityLimit=np.inf, motorTorqueLimit=np.inf)
+    env = pkg.SnakeGymEnv(pkg.Snake(None, None, args=args), args=args)
+    ref = oracle_mod.OracleEnv()
+    env.reset()
+    ref.reset()
+    idx = 1 + np.arange(0, 49, 3)          # oracle rows: root + Bullet links 0..48
+    for j in range(3):
+        a = gait(range(1), j, 8)[0].astype(np.float64) * 1.3       # some components get clipped
+        S, X = env._stepper.get_state()
+        ref.set_state(S[0].astype(np.float64))
+        ref.set_aux(X[0, :16].astype(np.float64), float(X[0, 16]), float(X[0, 17]))
+        obs, rew, done, info = env.step(a.copy())
+        k = env.robot.counter
+        assert set(info) == {"frames", "internal_observations", "link_positions"} and info["frames"] == []
+        assert len(info["internal_observations"]) == k == len(info["link_positions"]) and k > 0
+        assert np.array_equal(info["internal_observations"][-1], obs)
+        targets = np.zeros(16)
+        targets[1::2] = np.clip(a, -1, 1) * (np.pi / 6)
+        for i in range(k):
+            ref.substep(targets)
+            o = ref.get_obs()
+            tol = 2e-4 * (i + 1)           # float32 drift over the substeps of one env-step
+            assert np.abs(info["internal_observations"][i][:16] - o[:16]).max() < tol
+            assert np.abs(info["internal_observations"][i][48:55] - o[48:55]).max() < tol
+            lp = info["link_positions"][i].reshape(3, 17).T
+            assert np.abs(lp - ref.link_com_world()[idx]).max() < tol
+        if done:
+            break
+    env.close()
