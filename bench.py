@@ -116,6 +116,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--links", type=int, default=N_LINKS, choices=(16, 32),
+                    help="32 = BASELINE configs[3] (a parity-test case, not the headline metric)")
     ap.add_argument("--policy", action="store_true",
                     help="not the BASELINE metric: actions sampled from an on-device 2x256 actor-critic "
                          "(bullet-envs_amd/rollout.py, SURVEY 8(f)-1) instead of the precomputed gait; 1 GPU")
@@ -138,7 +140,8 @@ def main():
     pkg = importlib.import_module("bullet-envs_amd")
 
     E, K, W = args.envs_per_gpu, args.steps, args.warmup
-    A = N_LINKS // 2
+    NL = args.links
+    A = NL // 2
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -147,7 +150,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
-    local = pkg.DeviceVecEnv(E, device_index=local_rank, n_modules=N_LINKS)
+    local = pkg.DeviceVecEnv(E, device_index=local_rank, n_modules=NL)
     env = pkg.ShardedVecEnv(local, root=0, device=dev) if world > 1 else None
 
     # actions for every step, resident in HBM on the trainer rank before timing
@@ -226,11 +229,13 @@ def main():
         n_env_steps = world * E * K
         # per-launch algorithmic bytes of the dominant kernel on this rank
         local_sub = float(sub_total.item())
-        alg_bytes_launch = (local_sub * BYTES_PER_SUBSTEP + E * K * BYTES_PER_ENVSTEP) / K
+        per_sub = BYTES_PER_SUBSTEP if NL == 16 else 744
+        per_env = BYTES_PER_ENVSTEP if NL == 16 else 64 + 416 + 4 + 1 + 4
+        alg_bytes_launch = (local_sub * per_sub + E * K * per_env) / K
         achieved = alg_bytes_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         # HBM traffic per launch comes from rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 +
         # WRITE_SIZE, calibrated on reset_kernel), run separately and committed under profiles/
-        traffic, traffic_src = None, None
+        traffic, traffic_src, valu = None, None, None
         try:
             import glob
             cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_summary.json")))
@@ -239,10 +244,20 @@ def main():
                     pm = json.load(f)
                 traffic = pm.get("hbm_bytes_per_launch")
                 traffic_src = os.path.relpath(cands[-1], ROOT)
+                sq = pm.get("sq_per_launch", {})
+                if sq.get("SQ_INSTS_VALU") and pm.get("kernel_trace_average_ms"):
+                    # the path is VALU/latency-bound -- wave-instructions per second of the
+                    # profiled launch against the rate measured with 8 waves/SIMD of the same
+                    # instruction mix (tools/ubench_step.hip: one 28-instruction step per 65 clocks per SIMD)
+                    rate = sq["SQ_INSTS_VALU"] / (pm["kernel_trace_average_ms"] * 1e-3) / 1e9
+                    peak = 1024 * 2.4 * 28.0 / 65.0
+                    valu = {"wave_insts_per_launch": sq["SQ_INSTS_VALU"], "achieved_G_wave_insts_per_s": rate,
+                            "measured_ceiling_G_wave_insts_per_s": peak, "frac": rate / peak,
+                            "valu_active_per_wave": pm.get("derived", {}).get("valu_active_fraction_of_wave_cycles")}
         except Exception:  # noqa: BLE001
             pass
         out = {
-            "metric": "env-steps/sec (whole node), 16-link snake, 4096 envs/GPU" + (
+            "metric": "env-steps/sec (whole node), %d-link snake, 4096 envs/GPU" % NL + (
                 " -- with on-device policy inference (not the BASELINE metric)" if args.policy else ""),
             "value": n_env_steps / elapsed,
             "unit": "env-steps/s",
@@ -251,10 +266,11 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": ("%d envs/GPU x 16-link snake, flat ground plane, %s "
-                             "(BASELINE configs[%d])" % (E, "actions sampled from a random-init 2x256 actor-critic on the GPU"
-                                                         if args.policy else "serpenoid gait actions", 1 if world == 1 else 2)),
-                "envs_per_gpu": E, "n_links": N_LINKS,
+                "workload": ("%d envs/GPU x %d-link snake, flat ground plane, %s "
+                             "(BASELINE configs[%d])" % (E, NL, "actions sampled from a random-init 2x256 actor-critic on the GPU"
+                                                         if args.policy else "serpenoid gait actions",
+                                                         (1 if world == 1 else 2) if NL == 16 else 3)),
+                "envs_per_gpu": E, "n_links": NL,
                 "parallelism": "envs sharded over %d GPU(s), no data-path collective; "
                                "RCCL actions scatter + obs/reward/done gather to rank 0" % world
                                if world > 1 else "1 GPU, one wavefront per env",
@@ -264,8 +280,9 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                "kernel": "env_step_kernel<16>", "kernel_ms": kernel_ms, "launches": kcount,
+                "kernel": "env_step_kernel<%d>" % NL, "kernel_ms": kernel_ms, "launches": kcount,
                 "algorithmic_bytes_per_launch": alg_bytes_launch,
+                "valu": valu,
                 "note": "recurrence-bound path: ~1e3 flop per algorithmic byte; the HBM fraction is "
                         "reported as the contract asks, it is not the limiter (DESIGN.md §5)",
             },
