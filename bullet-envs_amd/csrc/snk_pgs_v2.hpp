@@ -150,15 +150,16 @@ __device__ int find_contacts_v2(LT& L, const DevModel& M, int lane, unsigned lon
 // ------------------------------------------------------------------------------------
 // one batch of rows, lane = row: M^-1 J^T by the ABA delta sweeps
 // (btMultiBody::calcAccelerationDeltasMultiDof [U]) plus the row's denominator and
-// right-hand side.  KIND 0 motor (-> L.Mm, kept for the limit rows), 1 normal,
-// 2 friction A, 3 friction B (-> the 64-row staging buffer).
+// right-hand side.  KIND 0 motor (-> L.Mm, kept for the limit rows), 1 normal (contact = lane),
+// 4 friction pairs of 32 contacts: lane -> contact base + (lane & 31), direction lane >> 5
+// (A in staging rows 0..31, B in rows 32..63, so one pass over the slots fills both halves).
 // Staging row layout: [0..21] M^-1 J^T, [22] rhs impulse, [23] denominator, [24] 1/denominator.
 // ------------------------------------------------------------------------------------
 template <class LT, int KIND>
-__device__ void build_batch_v2(LT& L, const DevModel& M, int lane, int nc) {
+__device__ void build_batch_v2(LT& L, const DevModel& M, int lane, int nc, int base = 0) {
     constexpr int N = LT::kN;
-    const int count = KIND == 0 ? N : nc;
-    if (lane < count) {
+    const int ci = KIND == 4 ? base + (lane & 31) : lane;      // contact (or motor) of this lane
+    if (ci < (KIND == 0 ? N : nc)) {
         const bool motor = KIND == 0;
         int k;
         f3 P = mk3(0, 0, 0), d = mk3(0, 0, 0);
@@ -166,9 +167,9 @@ __device__ void build_batch_v2(LT& L, const DevModel& M, int lane, int nc) {
         if (motor) {
             k = lane + 1;
         } else {
-            k = L.ccbody[lane];
-            P = ld3(L.ccP[lane]);
-            d = KIND == 1 ? mk3(0.f, 0.f, 1.f) : ld3(L.ccdir[lane][KIND == 2 ? 0 : 1]);
+            k = L.ccbody[ci];
+            P = ld3(L.ccP[ci]);
+            d = KIND == 1 ? mk3(0.f, 0.f, 1.f) : ld3(L.ccdir[ci][lane >> 5]);
         }
         f3 pN = mk3(0, 0, 0), pF = mk3(0, 0, 0);
         for (int b = N; b >= 1; b--) {
@@ -276,18 +277,21 @@ struct SlotRaw {
     bool valid;
 };
 template <class LT, int KIND>
-__device__ __forceinline__ SlotRaw fetch_slot(LT& L, const LaneK& K, int s, int count) {
+__device__ __forceinline__ SlotRaw fetch_slot(LT& L, const LaneK& K, int s, int count, int base) {
     SlotRaw r;
-    const int row = KIND == 1 ? 2 * s + K.h : s;
-    r.valid = row < count;
-    const int rs = r.valid ? row : 0;
-    const float* st = L.stM[rs];
+    // KIND 1: slot s holds contacts 2s, 2s+1 (staging row = contact);  KIND 4: slot s = contact s,
+    // direction A / B in the lower / upper half, staged in rows (s - base) and 32 + (s - base)
+    const int ci = KIND == 1 ? 2 * s + K.h : s;
+    r.valid = ci < count;
+    const int rs = r.valid ? ci : 0;
+    const int row = KIND == 1 ? rs : (r.valid ? 32 * K.h + (s - base) : 0);
+    const float* st = L.stM[row];
     const int dd = K.isdof ? K.d : 0;
     r.mval = st[dd];
     r.dinv = st[24];
     r.sp = st[22 + K.spoff];
     r.P = ld3(L.ccP[rs]);
-    r.dir = KIND == 1 ? mk3(0.f, 0.f, 1.f) : ld3(L.ccdir[rs][KIND == 2 ? 0 : 1]);
+    r.dir = KIND == 1 ? mk3(0.f, 0.f, 1.f) : ld3(L.ccdir[rs][K.h]);
     r.k = L.ccbody[rs];
     return r;
 }
@@ -299,20 +303,19 @@ __device__ __forceinline__ void finish_slot(const SlotRaw& r, const LaneK& K, fl
     float rj = (K.isdof ? jd * r.dinv : r.sp * K.m22) * sJ;
     float rm = (K.isdof ? r.mval : r.sp * K.m24) * sM;
     if (!r.valid) { rj = 0.f; rm = 0.f; }
-    const bool mine = KIND == 2 ? (K.h == 0) : (KIND == 3 ? (K.h == 1) : true);
-    RJ = mine ? rj : RJ;
-    RM = mine ? rm : RM;
+    RJ = rj;
+    RM = rm;
 }
 // eight consecutive slots BASE .. BASE+7 of one kind, reads issued two slots ahead
 template <class LT, int KIND, int BASE, int DST>
-__device__ __forceinline__ void load_slots8(LT& L, const LaneK& K, int count, float sJ, float sM, float (&RJ)[kSlots],
-                                            float (&RM)[kSlots]) {
-    SlotRaw r0 = fetch_slot<LT, KIND>(L, K, BASE, count);
-    SlotRaw r1 = fetch_slot<LT, KIND>(L, K, BASE + 1, count);
+__device__ __forceinline__ void load_slots8(LT& L, const LaneK& K, int count, int base, float sJ, float sM,
+                                            float (&RJ)[kSlots], float (&RM)[kSlots]) {
+    SlotRaw r0 = fetch_slot<LT, KIND>(L, K, BASE, count, base);
+    SlotRaw r1 = fetch_slot<LT, KIND>(L, K, BASE + 1, count, base);
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         SlotRaw r2 = r1;
-        if (i < 6) r2 = fetch_slot<LT, KIND>(L, K, BASE + i + 2, count);
+        if (i < 6) r2 = fetch_slot<LT, KIND>(L, K, BASE + i + 2, count, base);
         finish_slot<KIND>(r0, K, sJ, sM, RJ[DST + BASE + i], RM[DST + BASE + i]);
         r0 = r1;
         r1 = r2;
@@ -645,34 +648,36 @@ __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane, f
         const float fJ = mu > 0.f ? 1.0f / mu : 0.f, fM = mu > 0.f ? mu : 0.f;
         build_batch_v2<LT, 0>(L, M, lane, nc);
         SNK_STAMP(4)
-        build_batch_v2<LT, 2>(L, M, lane, nc);
-        SNK_STAMP(5)
-#define SNK_LOAD8(KIND, G, DST, SJ, SM)                                                            \
-    if (nc > 8 * G) load_slots8<LT, KIND, 8 * G, DST>(L, K, nc, SJ, SM, RJ, RM);
+        // friction pairs: two batches of 32 contacts x {A, B}
 #pragma unroll
         for (int s = 0; s < kSlots - kSlotFric; s++) { RJ[kSlotFric + s] = 0.f; RM[kSlotFric + s] = 0.f; }
-        SNK_LOAD8(2, 0, kSlotFric, fJ, fM) SNK_LOAD8(2, 1, kSlotFric, fJ, fM) SNK_LOAD8(2, 2, kSlotFric, fJ, fM)
-        SNK_LOAD8(2, 3, kSlotFric, fJ, fM) SNK_LOAD8(2, 4, kSlotFric, fJ, fM) SNK_LOAD8(2, 5, kSlotFric, fJ, fM)
-        SNK_LOAD8(2, 6, kSlotFric, fJ, fM) SNK_LOAD8(2, 7, kSlotFric, fJ, fM)
+        build_batch_v2<LT, 4>(L, M, lane, nc, 0);
+        SNK_STAMP(5)
+        if (nc > 0) load_slots8<LT, 4, 0, kSlotFric>(L, K, nc, 0, fJ, fM, RJ, RM);
+        if (nc > 8) load_slots8<LT, 4, 8, kSlotFric>(L, K, nc, 0, fJ, fM, RJ, RM);
+        if (nc > 16) load_slots8<LT, 4, 16, kSlotFric>(L, K, nc, 0, fJ, fM, RJ, RM);
+        if (nc > 24) load_slots8<LT, 4, 24, kSlotFric>(L, K, nc, 0, fJ, fM, RJ, RM);
         lds_sync();
         SNK_STAMP(6)
-        build_batch_v2<LT, 3>(L, M, lane, nc);
-        SNK_STAMP(7)
-        SNK_LOAD8(3, 0, kSlotFric, fJ, fM) SNK_LOAD8(3, 1, kSlotFric, fJ, fM) SNK_LOAD8(3, 2, kSlotFric, fJ, fM)
-        SNK_LOAD8(3, 3, kSlotFric, fJ, fM) SNK_LOAD8(3, 4, kSlotFric, fJ, fM) SNK_LOAD8(3, 5, kSlotFric, fJ, fM)
-        SNK_LOAD8(3, 6, kSlotFric, fJ, fM) SNK_LOAD8(3, 7, kSlotFric, fJ, fM)
-        lds_sync();
+        if (nc > 32) {
+            build_batch_v2<LT, 4>(L, M, lane, nc, 32);
+            SNK_STAMP(7)
+            load_slots8<LT, 4, 32, kSlotFric>(L, K, nc, 32, fJ, fM, RJ, RM);
+            if (nc > 40) load_slots8<LT, 4, 40, kSlotFric>(L, K, nc, 32, fJ, fM, RJ, RM);
+            if (nc > 48) load_slots8<LT, 4, 48, kSlotFric>(L, K, nc, 32, fJ, fM, RJ, RM);
+            if (nc > 56) load_slots8<LT, 4, 56, kSlotFric>(L, K, nc, 32, fJ, fM, RJ, RM);
+            lds_sync();
+        }
         SNK_STAMP(8)
         build_batch_v2<LT, 1>(L, M, lane, nc);
         SNK_STAMP(9)
 #pragma unroll
         for (int s = 0; s < kSlotFric; s++) { RJ[kSlotNormal + s] = 0.f; RM[kSlotNormal + s] = 0.f; }
         // a normal slot holds contacts 2s, 2s+1: 8 slots per 16 contacts
-        if (nc > 0) load_slots8<LT, 1, 0, kSlotNormal>(L, K, nc, 1.0f, 1.0f, RJ, RM);
-        if (nc > 16) load_slots8<LT, 1, 8, kSlotNormal>(L, K, nc, 1.0f, 1.0f, RJ, RM);
-        if (nc > 32) load_slots8<LT, 1, 16, kSlotNormal>(L, K, nc, 1.0f, 1.0f, RJ, RM);
-        if (nc > 48) load_slots8<LT, 1, 24, kSlotNormal>(L, K, nc, 1.0f, 1.0f, RJ, RM);
-#undef SNK_LOAD8
+        if (nc > 0) load_slots8<LT, 1, 0, kSlotNormal>(L, K, nc, 0, 1.0f, 1.0f, RJ, RM);
+        if (nc > 16) load_slots8<LT, 1, 8, kSlotNormal>(L, K, nc, 0, 1.0f, 1.0f, RJ, RM);
+        if (nc > 32) load_slots8<LT, 1, 16, kSlotNormal>(L, K, nc, 0, 1.0f, 1.0f, RJ, RM);
+        if (nc > 48) load_slots8<LT, 1, 24, kSlotNormal>(L, K, nc, 0, 1.0f, 1.0f, RJ, RM);
         // motors: column 6+j of M^-1 (divided by the row's denominator) in both halves;
         // target velocity change of motor j in lane 6+j
 #pragma unroll
