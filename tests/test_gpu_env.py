@@ -345,3 +345,40 @@ def test_test_mode_telemetry(pkg, oracle_mod):
         if done:
             break
     env.close()
+
+
+@pytest.mark.parametrize("variant", ["gait0_weights", "gait2_identity"])
+def test_env_step_variants(pkg, oracle_mod, variant):
+    """createAction's other branches (snake.py:247-269: gait 0 -> even slots, else 16 actions
+    1:1), a different action scale and other reward weights: same parity as the default config."""
+    if variant == "gait0_weights":
+        over = dict(gait=0, scaling_factor=np.pi / 4, alpha=2.0, beta=0.05, gamma=0.2)
+        A = 8
+    else:
+        over = dict(gait=2, scaling_factor=np.pi / 8)
+        A = 16
+    B = 8
+    st = pkg.Stepper(B, **over)
+    assert st.act_dim == A
+    st.reset()
+    refs = [oracle_mod.OracleEnv(**over) for _ in range(B)]
+    rng = np.random.default_rng(12)
+    compared = 0
+    for j in range(3):
+        S, X = st.get_state()
+        a = rng.uniform(-1.2, 1.2, (B, A)).astype(np.float32)
+        a_in = a.copy()
+        obs, rew, done, sub = st.step(a, vec_mode=False)
+        assert np.array_equal(a, np.clip(a_in, -1, 1))                  # clipped in place
+        for i in range(B):
+            e = refs[i]
+            e.set_state(S[i].astype(np.float64))
+            e.set_aux(X[i, :16].astype(np.float64), float(X[i, 16]), float(X[i, 17]))
+            o, r, d, k, _ = e.env_step(a_in[i].astype(np.float64), vec_mode=False)
+            if k != sub[i] or d != bool(done[i]):
+                assert abs(k - sub[i]) <= 1 or _near_threshold(o, a[i], 16, e)
+                continue
+            compared += 1
+            assert np.abs(obs[i, :16] - o[:16]).max() < 5e-3 and np.abs(obs[i, 48:55] - o[48:55]).max() < 5e-3
+            assert abs(rew[i] - r) < 1e-2
+    assert compared >= 2 * B
