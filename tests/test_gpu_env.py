@@ -382,3 +382,35 @@ def test_env_step_variants(pkg, oracle_mod, variant):
             assert np.abs(obs[i, :16] - o[:16]).max() < 5e-3 and np.abs(obs[i, 48:55] - o[48:55]).max() < 5e-3
             assert abs(rew[i] - r) < 1e-2
     assert compared >= 2 * B
+
+
+def test_ragged_sizes_and_argument_errors(pkg):
+    """Batch sizes that are not multiples of anything (1, 3, 65, 1000): env i's trajectory does not
+    depend on the batch it is stepped in.  Bad arguments fail with a message, never a crash."""
+    def run(n):
+        st = pkg.Stepper(n)
+        st.reset()
+        outs = []
+        for j in range(2):
+            o, r, d, s = st.step(gait(range(n), j, 8))
+            outs.append((o, r, d, s))
+        st.close()
+        return outs
+    big = run(1000)
+    for n in (1, 3, 65):
+        small = run(n)
+        for (o, r, d, s), (O, R, D, S) in zip(small, big):
+            assert np.array_equal(o, O[:n]) and np.array_equal(r, R[:n]) and np.array_equal(d, D[:n]) and np.array_equal(s, S[:n])
+    with pytest.raises(RuntimeError, match="n_envs"):
+        pkg.Stepper(0)
+    with pytest.raises(RuntimeError):
+        pkg.Stepper(4, n_modules=12)             # kernels exist for the 16- and 32-link chains
+    st = pkg.Stepper(4)
+    lib = pkg.load()
+    assert lib.snk_step_host(st.h, None, None, None, None, None, 1) != 0 and b"null" in lib.snk_last_error()
+    assert lib.snk_get_obs(None, None) != 0
+    with pytest.raises(AssertionError):
+        st.step(np.zeros((4, 7), np.float32))    # wrong action width is caught before the C call
+    with pytest.raises(AssertionError):
+        st.set_ground_friction(np.ones(3, np.float32))
+    st.close()
