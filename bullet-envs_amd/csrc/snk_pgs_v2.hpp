@@ -172,6 +172,7 @@ __device__ void build_batch_v2(LT& L, const DevModel& M, int lane, int nc, int b
             d = KIND == 1 ? mk3(0.f, 0.f, 1.f) : ld3(L.ccdir[ci][lane >> 5]);
         }
         f3 pN = mk3(0, 0, 0), pF = mk3(0, 0, 0);
+#pragma unroll 4
         for (int b = N; b >= 1; b--) {
             f3 ax = ld3(L.ax[b]);
             if (!motor && b == k) {
@@ -205,6 +206,7 @@ __device__ void build_batch_v2(LT& L, const DevModel& M, int lane, int nc, int b
         const float* gb = L.base() + 7;
         float den = dot(J0, al) + dot(J1, a);
         float rv = dot(J0, ld3(gb)) + dot(J1, ld3(gb + 3));
+#pragma unroll 4
         for (int b = 1; b <= N; b++) {
             a = a + cross(al, ld3(L.r[b]));
             float u = Mrow[6 + b - 1];
@@ -306,19 +308,18 @@ __device__ __forceinline__ void finish_slot(const SlotRaw& r, const LaneK& K, fl
     RJ = rj;
     RM = rm;
 }
-// eight consecutive slots BASE .. BASE+7 of one kind, reads issued two slots ahead
+// eight consecutive slots BASE .. BASE+7 of one kind, reads issued one slot ahead (two ahead
+// measured the same and spills)
 template <class LT, int KIND, int BASE, int DST>
 __device__ __forceinline__ void load_slots8(LT& L, const LaneK& K, int count, int base, float sJ, float sM,
                                             float (&RJ)[kSlots], float (&RM)[kSlots]) {
-    SlotRaw r0 = fetch_slot<LT, KIND>(L, K, BASE, count, base);
-    SlotRaw r1 = fetch_slot<LT, KIND>(L, K, BASE + 1, count, base);
+    SlotRaw cur = fetch_slot<LT, KIND>(L, K, BASE, count, base);
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-        SlotRaw r2 = r1;
-        if (i < 6) r2 = fetch_slot<LT, KIND>(L, K, BASE + i + 2, count, base);
-        finish_slot<KIND>(r0, K, sJ, sM, RJ[DST + BASE + i], RM[DST + BASE + i]);
-        r0 = r1;
-        r1 = r2;
+        SlotRaw nxt = cur;
+        if (i < 7) nxt = fetch_slot<LT, KIND>(L, K, BASE + i + 1, count, base);
+        finish_slot<KIND>(cur, K, sJ, sM, RJ[DST + BASE + i], RM[DST + BASE + i]);
+        cur = nxt;
     }
 }
 
@@ -659,15 +660,13 @@ __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane, f
         if (nc > 24) load_slots8<LT, 4, 24, kSlotFric>(L, K, nc, 0, fJ, fM, RJ, RM);
         lds_sync();
         SNK_STAMP(6)
-        if (nc > 32) {
-            build_batch_v2<LT, 4>(L, M, lane, nc, 32);
-            SNK_STAMP(7)
-            load_slots8<LT, 4, 32, kSlotFric>(L, K, nc, 32, fJ, fM, RJ, RM);
-            if (nc > 40) load_slots8<LT, 4, 40, kSlotFric>(L, K, nc, 32, fJ, fM, RJ, RM);
-            if (nc > 48) load_slots8<LT, 4, 48, kSlotFric>(L, K, nc, 32, fJ, fM, RJ, RM);
-            if (nc > 56) load_slots8<LT, 4, 56, kSlotFric>(L, K, nc, 32, fJ, fM, RJ, RM);
-            lds_sync();
-        }
+        build_batch_v2<LT, 4>(L, M, lane, nc, 32);      // no active lanes when nc <= 32
+        SNK_STAMP(7)
+        if (nc > 32) load_slots8<LT, 4, 32, kSlotFric>(L, K, nc, 32, fJ, fM, RJ, RM);
+        if (nc > 40) load_slots8<LT, 4, 40, kSlotFric>(L, K, nc, 32, fJ, fM, RJ, RM);
+        if (nc > 48) load_slots8<LT, 4, 48, kSlotFric>(L, K, nc, 32, fJ, fM, RJ, RM);
+        if (nc > 56) load_slots8<LT, 4, 56, kSlotFric>(L, K, nc, 32, fJ, fM, RJ, RM);
+        lds_sync();
         SNK_STAMP(8)
         build_batch_v2<LT, 1>(L, M, lane, nc);
         SNK_STAMP(9)
