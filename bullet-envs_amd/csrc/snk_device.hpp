@@ -188,6 +188,11 @@ __device__ void fk_vel(LT& L, const DevModel& M, int lane) {
 #pragma unroll
         for (int i = 0; i < 6; i++) L.zeta[0][i] = 0.f;
     }
+    // sin/cos of all joint angles at once (lane = joint); the serial chain below picks them up
+    // with v_readlane instead of evaluating sincosf sixteen times one after the other
+    float snv = 0.f, csv = 1.f;
+    if (lane < N) sincosf(L.q()[lane], &snv, &csv);
+#pragma unroll 4
     for (int b = 1; b <= N; b++) {
         const float* Rf = M.Rfix[b];
         float T[9];
@@ -196,9 +201,9 @@ __device__ void fk_vel(LT& L, const DevModel& M, int lane) {
 #pragma unroll
             for (int j = 0; j < 3; j++)
                 T[3 * i + j] = Rp[3 * i] * Rf[j] + Rp[3 * i + 1] * Rf[3 + j] + Rp[3 * i + 2] * Rf[6 + j];
-        float qb = L.q()[b - 1], qdb = L.qd()[b - 1];
-        float sn, cs;
-        sincosf(qb, &sn, &cs);
+        float qdb = L.qd()[b - 1];
+        const float sn = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(snv), b - 1));
+        const float cs = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(csv), b - 1));
         float Rn[9];
 #pragma unroll
         for (int i = 0; i < 3; i++) {
