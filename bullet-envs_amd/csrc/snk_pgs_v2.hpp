@@ -6,34 +6,39 @@
 //
 //   * one 64-lane register holds TWO rows, one per 32-lane half; lane = (half, d), d = lane&31
 //       d <  22 : component d of the row vector
-//       d == 22 : -rhs impulse   (RJ only)          delta-v register holds +1 there
-//       d == 23 : accumulated impulse a (RJ only)   delta-v register holds -1 there
-//       d == 24 : row denominator J M^-1 J^T (RJ only, for the residual)
+//       d == 22 : -rhs impulse               (RJ)        delta-v register holds +1 there
+//       d == 31 : accumulated impulse a      (RJ)        delta-v register holds -1 there
+//       d == 24 : row denominator J M^-1 J^T (RM; delta-v collects dI*den there: the residual)
+//       lane 57 : coupling scalar of the slot's two rows (RJ of a duo; delta-v is 0 there)
 //     RJ = J / den (pre-scaled), RM = M^-1 J^T, both halves of `dv` carry the same delta-v.
 //     Then   sum_d RJ[d] dv[d] = (J.dv)/den - rhs - a   and the new accumulated impulse of
 //     the row is simply clamp(-sum): no per-row scalar is fetched from memory.
-//   * slots: 0..7 motors (motors 2s, 2s+1 in the lower/upper half), 8..39 contact normals
-//     (contacts 2s, 2s+1), 40..103 friction pairs (direction A lower, B upper)
+//   * 96 slots: 0..31 contact normals (contacts 2s, 2s+1 in the lower / upper half),
+//     32..95 friction pairs (contact s: direction A lower, B upper), built in units of mu
 //   * a half's dot: 4 DPP row steps + row_bcast:15 -> lane 31 / 63 -> v_readlane; one
 //     reduction therefore yields the dots of BOTH rows of a slot
-//   * friction pair: Bullet resolves both directions from the same velocity, so the two
-//     dots are used as they are.  Two consecutive single rows (a "duo"): the second row must
-//     see the first row's update; its dot is corrected exactly by  c * dI_first  with the
-//     coupling scalar c = RJ_second . RM_first, precomputed once per substep (lane 25 / 57).
-//     This halves the number of sequential steps of the Gauss-Seidel chain at equal work.
+//   * friction pair (cone_step): Bullet resolves both directions from the same velocity, so
+//     the two dots are used as they are.  Two consecutive normals (duo_step): the second row
+//     must see the first row's update; its dot is corrected exactly by  c * dI_first  with the
+//     coupling scalar c = RJ_second . RM_first, precomputed once per substep.  This halves the
+//     number of sequential steps of the Gauss-Seidel chain at equal work.
+//   * motor rows (motor_step) need no reduction at all: their Jacobian is a unit vector
 //   * contributions to delta-v cross halves with v_permlane32_swap, so both halves always
 //     hold the complete delta-v
-//   * the solve is VALU-issue-bound (PMC: VALU active 48 % of wave cycles per wave, two waves
-//     per SIMD; I-cache hit rate 99.95 %), so the row updates are hand-written with the fewest
-//     VALU instructions: 12 per single row, 28 per friction pair; s_nops for the DPP hazards
-//     cost nothing because the other wave of the SIMD issues into them.  (A software-
-//     pipelined variant with look-ahead reductions was measured: +25 % instructions, slower.)
-//   * the early-exit residual (max over rows of |dI * den|) is evaluated only until the first
-//     row exceeds the threshold in an iteration; after that the residual-free code runs
+//   * what the hardware charges for (tools/ubench_lat.hip, ubench_step.hip): a lone wave issues
+//     one VALU per ~5 clocks whatever the dependencies, a dependent DPP add costs 12.6, a
+//     v_readlane -> use round trip ~20, every s_nop is an issue slot.  The steps are therefore
+//     hand-written with the fewest instructions on the shortest chain: 26 VALU per duo, 28
+//     per friction pair, 4 per motor row, and only the wait states gfx950 requires.
+//     (Measured and rejected: software-pipelined look-ahead reductions, a lane-local variant
+//     with exec-masked scatter, skipping inert friction pairs -- DESIGN.md section 4.)
+//   * Bullet's early-exit residual (max over rows of |dI * den|) is folded into every step
+//     with one v_max3 and tested once per iteration
 //
 // Row construction (M^-1 J^T by ABA delta sweeps, one row per lane) goes through a 64-row
-// LDS staging buffer, one batch per row kind; J itself is evaluated directly in the
-// (half, d) layout from the contact point and the per-lane joint axis/origin.
+// LDS staging buffer: motors, friction (two batches of 32 contacts x {A, B}), normals; J
+// itself is evaluated directly in the (half, d) layout from the contact point and the
+// per-lane joint axis/origin.
 //
 // Restates the same Bullet steps as v1's build_rows_v1/pgs_v1 (snk_device.hpp); the order
 // of row updates is identical, so both versions track the oracle.
@@ -72,38 +77,6 @@ __device__ __forceinline__ float half_reduce(float t) {
 __device__ __forceinline__ float rdlane(float x, int l) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l));
 }
-// Hand-scheduled half reductions for the solve loop.  hipcc splits the first step (after a
-// multiply) and the masked row_bcast step into v_mov_dpp + v_add; written out, each is one
-// v_add_f32_dpp.  A dependent DPP read needs 2 wait states after the VALU write (s_nop 1);
-// with two waves per SIMD the other wave issues into those slots.
-#define SNK_HALF_REDUCE_ASM                                                                  \
-    "s_nop 1\n\t"                                                                            \
-    "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
-    "s_nop 1\n\t"                                                                            \
-    "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
-    "s_nop 1\n\t"                                                                            \
-    "v_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"         \
-    "s_nop 1\n\t"                                                                            \
-    "v_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"         \
-    "s_nop 1\n\t"                                                                            \
-    "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"                    \
-    "s_nop 1\n\t"
-// sum of the 32-lane half H of x, as a wave-uniform (SGPR) value
-template <int H>
-__device__ __forceinline__ float half_dot1(float x) {
-    float s;
-    if (H)
-        asm volatile(SNK_HALF_REDUCE_ASM "v_readlane_b32 %1, %0, 63" : "+v"(x), "=s"(s));
-    else
-        asm volatile(SNK_HALF_REDUCE_ASM "v_readlane_b32 %1, %0, 31" : "+v"(x), "=s"(s));
-    return s;
-}
-// both half sums at once
-__device__ __forceinline__ void half_dot2(float x, float& sA, float& sB) {
-    asm volatile(SNK_HALF_REDUCE_ASM "v_readlane_b32 %1, %0, 31\n\tv_readlane_b32 %2, %0, 63"
-                 : "+v"(x), "=s"(sA), "=s"(sB));
-}
-
 // ------------------------------------------------------------------------------------
 // contacts of the current pose, written at their COMPACT index (same geometry as v1)
 // ------------------------------------------------------------------------------------
