@@ -415,3 +415,47 @@ def test_ragged_sizes_and_argument_errors(pkg):
     with pytest.raises(AssertionError):
         st.set_ground_friction(np.ones(3, np.float32))
     st.close()
+
+
+def test_env_logic_branches(pkg, oracle_mod):
+    """The servo loop's and the reward's rare branches, constructed on purpose, GPU vs oracle:
+    0-substep step (snake.py:283 never enters the loop), the 41-substep cap (:303), height
+    termination after one substep (:299-301), and the -10 collision term (SnakeGymEnv.py:94)."""
+    n = 16
+
+    def both(over, state=None, aux=None, action=None):
+        st = pkg.Stepper(1, **over)
+        st.reset()
+        e = oracle_mod.OracleEnv(**over)
+        e.reset()
+        if state is not None:
+            S, X = st.get_state()
+            S[0, :len(state)] = state
+            if aux is not None:
+                X[0] = aux
+            st.set_state(S, X)
+            e.set_state(S[0].astype(np.float64))
+            e.set_aux(X[0, :n].astype(np.float64), float(X[0, n]), float(X[0, n + 1]))
+        a = np.zeros((1, 8), np.float32) if action is None else np.asarray(action, np.float32).reshape(1, 8)
+        obs, rew, done, sub = st.step(a.copy(), vec_mode=False)
+        o, r, d, k, _ = e.env_step(a[0].astype(np.float64), vec_mode=False)
+        st.close()
+        return (obs[0], float(rew[0]), bool(done[0]), int(sub[0])), (o, r, d, k)
+
+    # (1) targets already reached: no physics at all, observation is the old state
+    g, o = both({})
+    assert g[3] == 0 == o[3] and not g[2] and g[1] == 0.0 == o[1]
+    assert np.all(g[0][:51] == 0)
+    # (2) motors too weak to reach the target: the loop stops at the 41-substep cap
+    g, o = both(dict(max_motor_impulse=2e-5), action=[1.0] * 8)
+    assert g[3] == 41 == o[3] and g[2] == o[2]
+    # 41 substeps of saturated motors against sticking contacts: float32 round-off grows to a few 1e-2
+    assert np.abs(g[0][:16] - o[0][:16]).max() < 0.1
+    # (3) snake in the air: mean height > 0.1 ends the step after ONE substep, done, -5
+    g, o = both({}, state=[0.0, 0.0, 0.5], action=[0.5] * 8)
+    assert g[3] == 1 == o[3] and g[2] and o[2]
+    assert abs(g[1] - o[1]) < 1e-3 and g[1] < -4.0
+    # (4) stale joint-0 force above 10 with a 0-substep step: reward = -10 exactly (dx = dy = energy = 0)
+    aux = np.zeros(n + 2, np.float32); aux[n] = 15.0
+    g, o = both({}, state=[0.0, 0.0, 0.0], aux=aux)
+    assert g[3] == 0 == o[3] and g[1] == -10.0 == o[1] and g[0][55] == 15.0
