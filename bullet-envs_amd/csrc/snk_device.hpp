@@ -144,7 +144,8 @@ struct Lds<N, false> : LdsCommon<N> {
     static constexpr int NC = 4 * N, NR = 12 * N, ND = N + 6;
     float cP[NC][3], cdist[NC], cdA[NC][3], cdB[NC][3];   // indexed by contact slot
     int clist[NC];
-    float Jc[NR][ND], Mc[NR][ND];
+    // rows NR..NR+2 of both arrays are kept zero: lanes >= ND of the solve read them (see pgs_v1)
+    float Jc[NR + 3][ND], Mc[NR + 3][ND];
     float c_rhs[NR], c_dinv[NR], c_den[NR], c_app[NR];
 };
 
@@ -624,6 +625,7 @@ __device__ void build_rows_v1(LT& L, const DevModel& M, int lane, int nc, int& n
             L.c_dinv[row] = dinv;
             L.c_den[row] = den;
             L.c_app[row] = 0.f;
+            for (int d2 = 0; d2 < ND; d2++) Jrow[d2] *= dinv;   // the solve works on J / den (one multiply less per row step)
         }
     }
     lds_sync();
@@ -668,85 +670,230 @@ __device__ void build_rows_v1(LT& L, const DevModel& M, int lane, int nc, int& n
 }
 
 // ----------------------------------------------------------------------------------
-// S6: projected Gauss-Seidel, lane = generalized-velocity component
+// S6: projected Gauss-Seidel for chains too long for the register-resident solve (the 32-link
+// config: 38 velocity components, up to 384 contact rows kept in LDS), lane = velocity component
 // (btMultiBodyConstraintSolver::solveSingleIteration / resolveSingleConstraintRowGeneric /
 //  resolveConeFrictionConstraintRows [U]).  Returns delta-v of this lane.
+//
+// Same lessons as the 16-link solve (snk_pgs_v2.hpp): the row steps are hand-written with the
+// fewest VALU instructions (one multiply + a 6-step DPP reduction per dot, the clamp on
+// wave-uniform values, J rows pre-divided by their denominator), a row's operands are read
+// from LDS one row ahead of their use, and the motor rows -- unit Jacobians -- need no
+// reduction at all.
 // ----------------------------------------------------------------------------------
+#define SNK_RED64(T)                                                                                   \
+    "v_add_f32_dpp " T ", " T ", " T " quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"  \
+    "s_nop 1\n\t"                                                                                      \
+    "v_add_f32_dpp " T ", " T ", " T " quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"  \
+    "s_nop 1\n\t"                                                                                      \
+    "v_add_f32_dpp " T ", " T ", " T " row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"          \
+    "s_nop 1\n\t"                                                                                      \
+    "v_add_f32_dpp " T ", " T ", " T " row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"          \
+    "s_nop 1\n\t"                                                                                      \
+    "v_add_f32_dpp " T ", " T ", " T " row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"                    \
+    "s_nop 1\n\t"                                                                                      \
+    "v_add_f32_dpp " T ", " T ", " T " row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+// one DPP step of two independent reductions: each instruction is the other's wait state
+#define SNK_RED64x2_STEP(A, B, MODE)                    \
+    "v_add_f32_dpp " A ", " A ", " A " " MODE "\n\t"      \
+    "v_add_f32_dpp " B ", " B ", " B " " MODE "\n\t"      \
+    "s_nop 0\n\t"
+
+// a contact-normal row: a' = max(a + rhs - (J/den).dv, 0); dv += M^-1 J^T (a' - a).  Returns a'.
+__device__ __forceinline__ float row_step_normal(float jv, float mv, float rhs, float acc, float den, float& dv, float& lsq) {
+    float t, x, dI, P, s;
+    asm volatile(
+        "v_mul_f32 %[t], %[jv], %[dv]\n\t"
+        "v_add_f32 %[x], %[acc], %[rhs]\n\t"
+        "s_nop 0\n\t"
+        SNK_RED64("%[t]")
+        "s_nop 0\n\t"
+        "v_readlane_b32 %[s], %[t], 63\n\t"
+        "s_nop 1\n\t"
+        "v_subrev_f32 %[x], %[s], %[x]\n\t"
+        "v_max_f32 %[x], 0, %[x]\n\t"
+        "v_sub_f32 %[dI], %[x], %[acc]\n\t"
+        "v_mul_f32 %[P], %[dI], %[mv]\n\t"
+        "v_mul_f32 %[t], %[dI], %[den]\n\t"
+        "v_add_f32 %[dv], %[dv], %[P]\n\t"
+        "v_max_f32 %[lsq], %[lsq], |%[t]|\n\t"
+        : [t] "=&v"(t), [x] "=&v"(x), [dI] "=&v"(dI), [P] "=&v"(P), [s] "=&s"(s), [dv] "+v"(dv), [lsq] "+v"(lsq)
+        : [jv] "v"(jv), [mv] "v"(mv), [rhs] "v"(rhs), [acc] "v"(acc), [den] "v"(den));
+    return x;
+}
+
+// Bullet's cone-friction pair of one contact: both dots from the same delta-v, the new pair
+// (a + rhs - dot) projected radially onto the disc of radius lim.
+__device__ __forceinline__ void row_step_cone(float jA, float mA, float jB, float mB, float rhsA, float rhsB, float& accA,
+                                              float& accB, float denA, float denB, float lim, float EPS, float& dv,
+                                              float& lsq) {
+    float tA, tB, xA, xB, r2, P, sA, sB;
+    asm volatile(
+        "v_mul_f32 %[tA], %[jA], %[dv]\n\t"
+        "v_mul_f32 %[tB], %[jB], %[dv]\n\t"
+        "v_add_f32 %[xA], %[accA], %[rhsA]\n\t"
+        SNK_RED64x2_STEP("%[tA]", "%[tB]", "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1")
+        SNK_RED64x2_STEP("%[tA]", "%[tB]", "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1")
+        SNK_RED64x2_STEP("%[tA]", "%[tB]", "row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+        SNK_RED64x2_STEP("%[tA]", "%[tB]", "row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+        SNK_RED64x2_STEP("%[tA]", "%[tB]", "row_bcast:15 row_mask:0xa bank_mask:0xf")
+        "v_add_f32_dpp %[tA], %[tA], %[tA] row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "v_add_f32_dpp %[tB], %[tB], %[tB] row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "v_add_f32 %[xB], %[accB], %[rhsB]\n\t"
+        "v_readlane_b32 %[sA], %[tA], 63\n\t"
+        "v_readlane_b32 %[sB], %[tB], 63\n\t"
+        "s_nop 0\n\t"
+        "v_subrev_f32 %[xA], %[sA], %[xA]\n\t"
+        "v_subrev_f32 %[xB], %[sB], %[xB]\n\t"
+        "v_fma_f32 %[r2], %[xA], %[xA], %[EPS]\n\t"
+        "v_fma_f32 %[r2], %[xB], %[xB], %[r2]\n\t"
+        "v_rsq_f32 %[r2], %[r2]\n\t"
+        "s_nop 0\n\t"
+        "v_mul_f32_e64 %[r2], %[lim], %[r2] clamp\n\t"
+        "v_mul_f32 %[xA], %[xA], %[r2]\n\t"
+        "v_mul_f32 %[xB], %[xB], %[r2]\n\t"
+        "v_sub_f32 %[tA], %[xA], %[accA]\n\t"
+        "v_sub_f32 %[tB], %[xB], %[accB]\n\t"
+        "v_mul_f32 %[P], %[tA], %[mA]\n\t"
+        "v_mul_f32 %[r2], %[tA], %[denA]\n\t"
+        "v_fmac_f32 %[P], %[tB], %[mB]\n\t"
+        "v_mul_f32 %[tB], %[tB], %[denB]\n\t"
+        "v_add_f32 %[dv], %[dv], %[P]\n\t"
+        "v_max3_f32 %[lsq], %[lsq], |%[r2]|, |%[tB]|\n\t"
+        : [tA] "=&v"(tA), [tB] "=&v"(tB), [xA] "=&v"(xA), [xB] "=&v"(xB), [r2] "=&v"(r2), [P] "=&v"(P), [sA] "=&s"(sA),
+          [sB] "=&s"(sB), [dv] "+v"(dv), [lsq] "+v"(lsq)
+        : [jA] "v"(jA), [mA] "v"(mA), [jB] "v"(jB), [mB] "v"(mB), [rhsA] "v"(rhsA), [rhsB] "v"(rhsB), [accA] "v"(accA),
+          [accB] "v"(accB), [denA] "v"(denA), [denB] "v"(denB), [lim] "v"(lim), [EPS] "v"(EPS));
+    accA = xA;
+    accB = xB;
+}
+
 template <class LT>
 __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, float mu, int& iters) {
     constexpr int N = LT::kN;
     constexpr int ND = N + 6;
-    constexpr int W = (ND <= 32) ? 32 : 64;
+    static_assert(ND > 32 && ND <= 64, "this solve is laid out for one row per 64-lane register");
+    constexpr int NR = LT::NR;
     const bool act = lane < ND;
+    const int nlim = nn - N;                       // violated joint limits come first in the non-contact list
+    // model fields used inside the loops, read once (the model lives in global memory)
+    const int n_iter = M.n_iter;
+    const bool cone = M.cone != 0;
+    const float mi = M.max_motor_imp;
+    const float thr2 = M.resid_thr;
+    // motor rows: lane 6+j holds motor j's target velocity change and 1/den
+    const bool mot = lane >= 6 && act;
+    const int jm = mot ? lane - 6 : 0;
+    const float DINVV = mot ? L.nc_dinv[nlim + jm] : 0.f;
+    const float TARGV = (mot && DINVV > 0.f) ? L.nc_rhs[nlim + jm] * L.nc_den[nlim + jm] : 0.f;
+    float ACCV = 0.f;                               // accumulated motor impulses, motor j in lane 6+j
+    const float EPS = 1e-30f;
+    // One pointer per lane walks the rows: lane d < ND reads column d of rows 3ci, 3ci+1, 3ci+2
+    // (immediate offsets; the M^-1 J^T row sits sizeof(Jc) further); lanes >= ND stay on the
+    // three zero rows behind the last contact row, so no load needs a mask.
+    if (lane < ND) {
+#pragma unroll
+        for (int r = 0; r < 3; r++) { L.Jc[NR + r][lane] = 0.f; L.Mc[NR + r][lane] = 0.f; }
+    }
+    lds_sync();
+    const float* const row0 = act ? &L.Jc[0][lane] : &L.Jc[NR][0];
+    const int rstep = act ? 3 * ND : 0;
+    constexpr int kM = (NR + 3) * ND;               // floats from a J row to its M^-1 J^T row
     float dv = 0.f;
     int it = 0;
-    for (; it < M.n_iter; it++) {
-        float lsq = 0.f;
-        for (int jj = 0; jj < nn; jj++) {
-            const int idx = (it & 1) ? jj : nn - 1 - jj;
-            const int j = __builtin_amdgcn_readfirstlane(L.nc_joint[idx]);
-            const float sg = L.nc_sign[idx];
-            float un = sg * lane_bcast(dv, 6 + j);
-            float a0 = L.nc_app[idx];
-            float dI = L.nc_rhs[idx] - un * L.nc_dinv[idx];
-            float sum = fminf(fmaxf(a0 + dI, L.nc_lo[idx]), L.nc_hi[idx]);
-            dI = sum - a0;
-            L.nc_app[idx] = sum;   // uniform value, every lane stores it: no barrier needed
-            float mv = act ? L.Mm[j][lane] : 0.f;
-            dv += sg * mv * dI;
-            float rr = dI * L.nc_den[idx];
-            lsq = fmaxf(lsq, rr * rr);
-        }
-        for (int ci = 0; ci < nc; ci++) {
-            const int row = 3 * ci;
-            float jv = act ? L.Jc[row][lane] : 0.f;
-            float un = wave_sum<W>(jv * dv);
-            float a0 = L.c_app[row];
-            float dI = L.c_rhs[row] - un * L.c_dinv[row];
-            float sum = fminf(fmaxf(a0 + dI, 0.f), 1e10f);
-            dI = sum - a0;
-            L.c_app[row] = sum;
-            float mv = act ? L.Mc[row][lane] : 0.f;
-            dv += mv * dI;
-            float rr = dI * L.c_den[row];
-            lsq = fmaxf(lsq, rr * rr);
-        }
-        for (int ci = 0; ci < nc; ci++) {
-            const int rA = 3 * ci + 1, rB = 3 * ci + 2;
-            float lim = mu * L.c_app[3 * ci];
-            float jA = act ? L.Jc[rA][lane] : 0.f, jB = act ? L.Jc[rB][lane] : 0.f;
-            float mA = act ? L.Mc[rA][lane] : 0.f, mB = act ? L.Mc[rB][lane] : 0.f;
-            float aA = L.c_app[rA], aB = L.c_app[rB];
-            if (M.cone) {
-                float uA = wave_sum<W>(jA * dv), uB = wave_sum<W>(jB * dv);
-                float sA = aA + (L.c_rhs[rA] - uA * L.c_dinv[rA]);
-                float sB = aB + (L.c_rhs[rB] - uB * L.c_dinv[rB]);
-                float rr = sqrtf(sA * sA + sB * sB);
-                if (rr > lim) {
-                    float sc = rr > 0.f ? lim / rr : 0.f;
-                    sA *= sc; sB *= sc;
+    for (; it < n_iter; it++) {
+        float lsq = 0.f;       // max |dI * den| of the contact rows
+        float lsq_nc = 0.f;    // ... of the limit and motor rows
+        auto limit_rows = [&](bool fwd) {
+            for (int jj = 0; jj < nlim; jj++) {
+                const int idx = fwd ? jj : nlim - 1 - jj;
+                const int j = __builtin_amdgcn_readfirstlane(L.nc_joint[idx]);
+                const float sg = L.nc_sign[idx];
+                float un = sg * lane_bcast(dv, 6 + j);
+                float a0 = L.nc_app[idx];
+                float dI = L.nc_rhs[idx] - un * L.nc_dinv[idx];
+                float sum = fminf(fmaxf(a0 + dI, L.nc_lo[idx]), L.nc_hi[idx]);
+                dI = sum - a0;
+                L.nc_app[idx] = sum;   // uniform value, every lane stores it: no barrier needed
+                float mv = act ? L.Mm[j][lane] : 0.f;
+                dv += sg * mv * dI;
+                lsq_nc = fmaxf(lsq_nc, fabsf(dI * L.nc_den[idx]));
+            }
+        };
+        auto motor_rows = [&](bool fwd) {
+            const float* mrow = act ? &L.Mm[fwd ? 0 : N - 1][lane] : &L.Jc[NR][0];
+            const int mstep = act ? (fwd ? ND : -ND) : 0;
+            float mvn = mrow[0];
+            float denn = L.nc_den[nlim + (fwd ? 0 : N - 1)];
+            for (int jj = 0; jj < N; jj++) {
+                const int j = fwd ? jj : N - 1 - jj;
+                const float mv = mvn, den = denn;
+                if (jj + 1 < N) {
+                    mrow += mstep;
+                    mvn = mrow[0];
+                    denn = L.nc_den[nlim + (fwd ? j + 1 : j - 1)];
                 }
-                float dA = sA - aA, dB = sB - aB;
-                L.c_app[rA] = sA; L.c_app[rB] = sB;
-                dv += mA * dA + mB * dB;
-                float ra = dA * L.c_den[rA], rb = dB * L.c_den[rB];
-                lsq = fmaxf(lsq, fmaxf(ra * ra, rb * rb));
-            } else if (lim > 0.f) {
-                float uA = wave_sum<W>(jA * dv);
-                float sA = fminf(fmaxf(aA + (L.c_rhs[rA] - uA * L.c_dinv[rA]), -lim), lim);
-                float dA = sA - aA;
-                dv += mA * dA;
-                float uB = wave_sum<W>(jB * dv);
-                float sB = fminf(fmaxf(aB + (L.c_rhs[rB] - uB * L.c_dinv[rB]), -lim), lim);
-                float dB = sB - aB;
-                dv += mB * dB;
-                L.c_app[rA] = sA; L.c_app[rB] = sB;
-                float ra = dA * L.c_den[rA], rb = dB * L.c_den[rB];
-                lsq = fmaxf(lsq, fmaxf(ra * ra, rb * rb));
+                float u = (TARGV - dv) * DINVV;                          // every motor's candidate dI, lane-local
+                if (mi < 1e30f) u = fminf(fmaxf(ACCV + u, -mi), mi) - ACCV;
+                const float sdI = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(u), 6 + j));
+                ACCV = (lane == 6 + j) ? ACCV + u : ACCV;
+                dv += sdI * mv;
+                lsq_nc = fmaxf(lsq_nc, fabsf(sdI * den));
+            }
+        };
+        if (it & 1) { limit_rows(true); motor_rows(true); }
+        else { motor_rows(false); limit_rows(false); }
+        if (nc > 0) {
+            // normals, operands one row ahead
+            const float* p = row0;
+            float jn = p[0], mn = p[kM], rn = L.c_rhs[0], an = L.c_app[0], dn = L.c_den[0];
+            for (int ci = 0; ci < nc; ci++) {
+                const int row = 3 * ci;
+                const float jv = jn, mv = mn, rhs = rn, acc = an, den = dn;
+                if (ci + 1 < nc) {
+                    p += rstep;
+                    jn = p[0]; mn = p[kM]; rn = L.c_rhs[row + 3]; an = L.c_app[row + 3]; dn = L.c_den[row + 3];
+                }
+                L.c_app[row] = row_step_normal(jv, mv, rhs, acc, den, dv, lsq);
+            }
+            // friction pairs
+            p = row0;
+            float jA = p[ND], jB = p[2 * ND], mA = p[kM + ND], mB = p[kM + 2 * ND];
+            float rA = L.c_rhs[1], rB = L.c_rhs[2], aA = L.c_app[1], aB = L.c_app[2], dA = L.c_den[1], dB = L.c_den[2];
+            float ln = mu * L.c_app[0];
+            for (int ci = 0; ci < nc; ci++) {
+                const int row = 3 * ci;
+                const float cjA = jA, cjB = jB, cmA = mA, cmB = mB, crA = rA, crB = rB, cdA = dA, cdB = dB, lim = ln;
+                float accA = aA, accB = aB;
+                if (ci + 1 < nc) {
+                    p += rstep;
+                    jA = p[ND]; jB = p[2 * ND]; mA = p[kM + ND]; mB = p[kM + 2 * ND];
+                    rA = L.c_rhs[row + 4]; rB = L.c_rhs[row + 5]; aA = L.c_app[row + 4]; aB = L.c_app[row + 5];
+                    dA = L.c_den[row + 4]; dB = L.c_den[row + 5];
+                    ln = mu * L.c_app[row + 3];
+                }
+                if (cone) {
+                    row_step_cone(cjA, cmA, cjB, cmB, crA, crB, accA, accB, cdA, cdB, lim, EPS, dv, lsq);
+                    L.c_app[row + 1] = accA; L.c_app[row + 2] = accB;
+                } else if (lim > 0.f) {
+                    // pyramid friction (not Bullet's default here): box-clamped rows, one after the other
+                    float uA = wave_sum<64>(cjA * dv);
+                    float sA = fminf(fmaxf(accA + (crA - uA), -lim), lim);
+                    float eA = sA - accA;
+                    dv += cmA * eA;
+                    float uB = wave_sum<64>(cjB * dv);
+                    float sB = fminf(fmaxf(accB + (crB - uB), -lim), lim);
+                    float eB = sB - accB;
+                    dv += cmB * eB;
+                    L.c_app[row + 1] = sA; L.c_app[row + 2] = sB;
+                    lsq = fmaxf(lsq, fmaxf(fabsf(eA * cdA), fabsf(eB * cdB)));
+                }
             }
         }
-        if (lsq <= M.resid_thr || it >= M.n_iter - 1) { it++; break; }
+        const float res = fmaxf(lsq, lsq_nc);
+        if (res * res <= thr2 || it >= n_iter - 1) { it++; break; }
     }
+    if (lane >= 6 && lane < 6 + N) L.nc_app[nlim + lane - 6] = ACCV;
     lds_sync();
     iters = it;
     return dv;
