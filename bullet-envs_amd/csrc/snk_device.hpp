@@ -144,9 +144,16 @@ struct Lds<N, false> : LdsCommon<N> {
     static constexpr int NC = 4 * N, NR = 12 * N, ND = N + 6;
     float cP[NC][3], cdist[NC], cdA[NC][3], cdB[NC][3];   // indexed by contact slot
     int clist[NC];
-    // rows NR..NR+2 of both arrays are kept zero: lanes >= ND of the solve read them (see pgs_v1)
-    float Jc[NR + 3][ND], Mc[NR + 3][ND];
-    float c_rhs[NR], c_dinv[NR], c_den[NR], c_app[NR];
+    // kPad extra rows: the solve walks the rows four contacts per loop trip, so the rows of up to
+    // three contacts behind the last one are zeroed (inert), and lanes >= ND read the last 12
+    // rows, which are always zero (see pgs_v1)
+    static constexpr int kPad = 24;
+    float Jc[NR + kPad][ND], Mc[NR + kPad][ND];
+    // per-contact scalars of the rows, grouped the way the solve reads them (one ds_read_b128 each):
+    //   cN[ci] = {rhs, den, accumulated impulse, 1/den} of the normal row 3ci
+    //   cF[ci] = {rhsA, rhsB, denA, denB | accA, accB, 1/denA, 1/denB} of the friction rows 3ci+1, 3ci+2
+    alignas(16) float cN[NC + 4][4];
+    alignas(16) float cF[NC + 4][8];
 };
 
 // v2: rows live in VGPRs during the solve; LDS only stages one 64-row batch while they are built
@@ -621,10 +628,13 @@ __device__ void build_rows_v1(LT& L, const DevModel& M, int lane, int nc, int& n
             } else {
                 target = -rv;
             }
-            L.c_rhs[row] = target * dinv;
-            L.c_dinv[row] = dinv;
-            L.c_den[row] = den;
-            L.c_app[row] = 0.f;
+            const int cid = row / 3;
+            if (kind == 0) {
+                L.cN[cid][0] = target * dinv; L.cN[cid][1] = den; L.cN[cid][2] = 0.f; L.cN[cid][3] = dinv;
+            } else {
+                float* cf = L.cF[cid] + (kind - 1);
+                cf[0] = target * dinv; cf[2] = den; cf[4] = 0.f; cf[6] = dinv;
+            }
             for (int d2 = 0; d2 < ND; d2++) Jrow[d2] *= dinv;   // the solve works on J / den (one multiply less per row step)
         }
     }
@@ -777,10 +787,12 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
     const bool act = lane < ND;
     const int nlim = nn - N;                       // violated joint limits come first in the non-contact list
     // model fields used inside the loops, read once (the model lives in global memory)
-    const int n_iter = M.n_iter;
-    const bool cone = M.cone != 0;
-    const float mi = M.max_motor_imp;
-    const float thr2 = M.resid_thr;
+    // (v_readfirstlane: the loads go through vector memory, the values must be scalar for the
+    //  branches on them to be scalar branches instead of exec-mask regions)
+    const int n_iter = __builtin_amdgcn_readfirstlane(M.n_iter);
+    const bool cone = __builtin_amdgcn_readfirstlane(M.cone) != 0;
+    const float mi = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(M.max_motor_imp)));
+    const float thr2 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(M.resid_thr)));
     // motor rows: lane 6+j holds motor j's target velocity change and 1/den
     const bool mot = lane >= 6 && act;
     const int jm = mot ? lane - 6 : 0;
@@ -788,17 +800,26 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
     const float TARGV = (mot && DINVV > 0.f) ? L.nc_rhs[nlim + jm] * L.nc_den[nlim + jm] : 0.f;
     float ACCV = 0.f;                               // accumulated motor impulses, motor j in lane 6+j
     const float EPS = 1e-30f;
-    // One pointer per lane walks the rows: lane d < ND reads column d of rows 3ci, 3ci+1, 3ci+2
-    // (immediate offsets; the M^-1 J^T row sits sizeof(Jc) further); lanes >= ND stay on the
-    // three zero rows behind the last contact row, so no load needs a mask.
-    if (lane < ND) {
+    // One pointer per lane walks the rows, four contacts (12 rows) per loop trip: lane d < ND reads
+    // column d of its rows through immediate offsets (the M^-1 J^T row sits sizeof(Jc) further);
+    // lanes >= ND stay on the last 12 rows of the arrays, which are always zero, so no load needs
+    // a mask.  The rows and scalars of up to three contacts behind the last real one are zeroed
+    // too: a trip that runs past nc resolves inert rows (dI = 0 exactly).
+    constexpr int kPad = LT::kPad;
+    {
+        const int r0 = 3 * nc;
+        if (lane < ND) {
+            for (int r = 0; r < 9; r++) { L.Jc[r0 + r][lane] = 0.f; L.Mc[r0 + r][lane] = 0.f; }
 #pragma unroll
-        for (int r = 0; r < 3; r++) { L.Jc[NR + r][lane] = 0.f; L.Mc[NR + r][lane] = 0.f; }
+            for (int r = kPad - 12; r < kPad; r++) { L.Jc[NR + r][lane] = 0.f; L.Mc[NR + r][lane] = 0.f; }
+        }
+        if (lane < 12) L.cN[nc + lane / 4][lane & 3] = 0.f;
+        if (lane < 24) L.cF[nc + lane / 8][lane & 7] = 0.f;
     }
     lds_sync();
-    const float* const row0 = act ? &L.Jc[0][lane] : &L.Jc[NR][0];
-    const int rstep = act ? 3 * ND : 0;
-    constexpr int kM = (NR + 3) * ND;               // floats from a J row to its M^-1 J^T row
+    const float* const row0 = act ? &L.Jc[0][lane] : &L.Jc[NR + kPad - 12][0];
+    const int rstep4 = act ? 12 * ND : 0;
+    constexpr int kM = (NR + kPad) * ND;            // floats from a J row to its M^-1 J^T row
     float dv = 0.f;
     int it = 0;
     for (; it < n_iter; it++) {
@@ -821,7 +842,7 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
             }
         };
         auto motor_rows = [&](bool fwd) {
-            const float* mrow = act ? &L.Mm[fwd ? 0 : N - 1][lane] : &L.Jc[NR][0];
+            const float* mrow = act ? &L.Mm[fwd ? 0 : N - 1][lane] : &L.Jc[NR + kPad - 12][0];
             const int mstep = act ? (fwd ? ND : -ND) : 0;
             float mvn = mrow[0];
             float denn = L.nc_den[nlim + (fwd ? 0 : N - 1)];
@@ -844,49 +865,89 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
         if (it & 1) { limit_rows(true); motor_rows(true); }
         else { motor_rows(false); limit_rows(false); }
         if (nc > 0) {
-            // normals, operands one row ahead
-            const float* p = row0;
-            float jn = p[0], mn = p[kM], rn = L.c_rhs[0], an = L.c_app[0], dn = L.c_den[0];
-            for (int ci = 0; ci < nc; ci++) {
-                const int row = 3 * ci;
-                const float jv = jn, mv = mn, rhs = rn, acc = an, den = dn;
-                if (ci + 1 < nc) {
-                    p += rstep;
-                    jn = p[0]; mn = p[kM]; rn = L.c_rhs[row + 3]; an = L.c_app[row + 3]; dn = L.c_den[row + 3];
+            // Rows are walked two per loop trip with two operand sets (a, b): the reads of the
+            // next row are issued before the current row's step and nothing is copied.  The
+            // per-row scalars (rhs, den, accumulated impulse) are read through a VGPR address
+            // with immediate offsets (qoff is laundered so the compiler does not turn each of
+            // them into an SGPR address + v_mov).
+            int qoff = 0;
+            asm volatile("" : "+v"(qoff));
+            float* const qN0 = &L.cN[0][0] + qoff;
+            float* const qF0 = &L.cF[0][0] + qoff;
+            struct NOps { float jv, mv, rhs, acc, den; };
+            auto fetchN = [&](const float* pp, const float* qq, int k) {      // k-th contact of the trip
+                NOps o;
+                o.jv = pp[3 * ND * k]; o.mv = pp[kM + 3 * ND * k];
+                o.rhs = qq[4 * k]; o.den = qq[4 * k + 1]; o.acc = qq[4 * k + 2];
+                return o;
+            };
+            {
+                const float* p = row0;
+                float* q = qN0;
+                NOps a = fetchN(p, q, 0);
+                for (int ci = 0; ci < nc; ci += 4) {
+                    const NOps b = fetchN(p, q, 1);
+                    q[2] = row_step_normal(a.jv, a.mv, a.rhs, a.acc, a.den, dv, lsq);
+                    const NOps c = fetchN(p, q, 2);
+                    q[6] = row_step_normal(b.jv, b.mv, b.rhs, b.acc, b.den, dv, lsq);
+                    const NOps d4 = fetchN(p, q, 3);
+                    q[10] = row_step_normal(c.jv, c.mv, c.rhs, c.acc, c.den, dv, lsq);
+                    float* const qd = q;
+                    p += rstep4; q += 16;
+                    if (ci + 4 < nc) a = fetchN(p, q, 0);
+                    qd[14] = row_step_normal(d4.jv, d4.mv, d4.rhs, d4.acc, d4.den, dv, lsq);
                 }
-                L.c_app[row] = row_step_normal(jv, mv, rhs, acc, den, dv, lsq);
             }
             // friction pairs
-            p = row0;
-            float jA = p[ND], jB = p[2 * ND], mA = p[kM + ND], mB = p[kM + 2 * ND];
-            float rA = L.c_rhs[1], rB = L.c_rhs[2], aA = L.c_app[1], aB = L.c_app[2], dA = L.c_den[1], dB = L.c_den[2];
-            float ln = mu * L.c_app[0];
-            for (int ci = 0; ci < nc; ci++) {
-                const int row = 3 * ci;
-                const float cjA = jA, cjB = jB, cmA = mA, cmB = mB, crA = rA, crB = rB, cdA = dA, cdB = dB, lim = ln;
-                float accA = aA, accB = aB;
-                if (ci + 1 < nc) {
-                    p += rstep;
-                    jA = p[ND]; jB = p[2 * ND]; mA = p[kM + ND]; mB = p[kM + 2 * ND];
-                    rA = L.c_rhs[row + 4]; rB = L.c_rhs[row + 5]; aA = L.c_app[row + 4]; aB = L.c_app[row + 5];
-                    dA = L.c_den[row + 4]; dB = L.c_den[row + 5];
-                    ln = mu * L.c_app[row + 3];
+            struct COps { float jA, jB, mA, mB, rA, rB, aA, aB, dA, dB, lim; };
+            auto fetchC = [&](const float* pp, const float* qq, const float* qn, int k) {
+                COps o;
+                o.jA = pp[ND + 3 * ND * k]; o.jB = pp[2 * ND + 3 * ND * k];
+                o.mA = pp[kM + ND + 3 * ND * k]; o.mB = pp[kM + 2 * ND + 3 * ND * k];
+                const float* c = qq + 8 * k;
+                o.rA = c[0]; o.rB = c[1]; o.dA = c[2]; o.dB = c[3]; o.aA = c[4]; o.aB = c[5];
+                o.lim = mu * qn[4 * k + 2];
+                return o;
+            };
+#define SNK_CONE_ROW(O, QQ, K)                                                                          \
+    row_step_cone(O.jA, O.mA, O.jB, O.mB, O.rA, O.rB, O.aA, O.aB, O.dA, O.dB, O.lim, EPS, dv, lsq);       \
+    (QQ)[8 * (K) + 4] = O.aA; (QQ)[8 * (K) + 5] = O.aB;
+            if (cone) {
+                const float* p = row0;
+                float* q = qF0;
+                const float* qn = qN0;
+                COps a = fetchC(p, q, qn, 0);
+                for (int ci = 0; ci < nc; ci += 4) {
+                    COps b = fetchC(p, q, qn, 1);
+                    SNK_CONE_ROW(a, q, 0)
+                    COps c = fetchC(p, q, qn, 2);
+                    SNK_CONE_ROW(b, q, 1)
+                    COps d4 = fetchC(p, q, qn, 3);
+                    SNK_CONE_ROW(c, q, 2)
+                    float* const qd = q;
+                    p += rstep4; q += 32; qn += 16;
+                    if (ci + 4 < nc) a = fetchC(p, q, qn, 0);
+                    SNK_CONE_ROW(d4, qd, 3)
                 }
-                if (cone) {
-                    row_step_cone(cjA, cmA, cjB, cmB, crA, crB, accA, accB, cdA, cdB, lim, EPS, dv, lsq);
-                    L.c_app[row + 1] = accA; L.c_app[row + 2] = accB;
-                } else if (lim > 0.f) {
-                    // pyramid friction (not Bullet's default here): box-clamped rows, one after the other
-                    float uA = wave_sum<64>(cjA * dv);
-                    float sA = fminf(fmaxf(accA + (crA - uA), -lim), lim);
+#undef SNK_CONE_ROW
+            } else {
+                // pyramid friction (not Bullet's default here): box-clamped rows, one after the other
+                const float* p = row0;
+                for (int ci = 0; ci < nc; ci++, p += rstep4 / 4) {
+                    float* cf = L.cF[ci];
+                    const float lim = mu * L.cN[ci][2];
+                    if (!(lim > 0.f)) continue;
+                    const float accA = cf[4], accB = cf[5];
+                    float uA = wave_sum<64>(p[ND] * dv);
+                    float sA = fminf(fmaxf(accA + (cf[0] - uA), -lim), lim);
                     float eA = sA - accA;
-                    dv += cmA * eA;
-                    float uB = wave_sum<64>(cjB * dv);
-                    float sB = fminf(fmaxf(accB + (crB - uB), -lim), lim);
+                    dv += p[kM + ND] * eA;
+                    float uB = wave_sum<64>(p[2 * ND] * dv);
+                    float sB = fminf(fmaxf(accB + (cf[1] - uB), -lim), lim);
                     float eB = sB - accB;
-                    dv += cmB * eB;
-                    L.c_app[row + 1] = sA; L.c_app[row + 2] = sB;
-                    lsq = fmaxf(lsq, fmaxf(fabsf(eA * cdA), fabsf(eB * cdB)));
+                    dv += p[kM + 2 * ND] * eB;
+                    cf[4] = sA; cf[5] = sB;
+                    lsq = fmaxf(lsq, fmaxf(fabsf(eA * cf[2]), fabsf(eB * cf[3])));
                 }
             }
         }
@@ -946,8 +1007,8 @@ __device__ void substep_v1(LT& L, const DevModel& M, int lane, float mu, int& it
         for (int ci = 0; ci < nc; ci++) {
             const int slot = L.clist[ci];
             if ((((slot >> 1) + 1) >> 1) == b) {
-                f3 F = (mk3(0.f, 0.f, 1.f) * L.c_app[3 * ci] + ld3(L.cdA[slot]) * L.c_app[3 * ci + 1] +
-                        ld3(L.cdB[slot]) * L.c_app[3 * ci + 2]) * M.inv_dt;
+                f3 F = (mk3(0.f, 0.f, 1.f) * L.cN[ci][2] + ld3(L.cdA[slot]) * L.cF[ci][4] +
+                        ld3(L.cdB[slot]) * L.cF[ci][5]) * M.inv_dt;
                 eF = eF + F;
                 eN = eN + cross(ld3(L.cP[slot]) - ld3(L.o[b]), F);
             }

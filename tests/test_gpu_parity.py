@@ -188,12 +188,13 @@ def test_rare_branch_early_exit(pkg, oracle_mod):
     assert np.array_equal(info[:, 0], its)
 
 
-def test_partial_contact_sets(pkg, oracle_mod):
+@pytest.mark.parametrize("n", [16, 32])
+def test_partial_contact_sets(pkg, oracle_mod, n):
     """Snake pitched so that only some cylinders are within the contact threshold: contact
-    counts that are not multiples of the group size (8) and in both halves."""
-    n = 16
+    counts that are not multiples of the group sizes (8 rows per branch in the 16-link solve,
+    4 contacts per loop trip in the 32-link one) and in both halves."""
     states = []
-    for ang in (0.02, 0.04, 0.08, 0.15, 0.3):
+    for ang in (0.02, 0.04, 0.08, 0.15, 0.3) if n == 16 else (0.01, 0.02, 0.04, 0.08, 0.15):
         s = np.zeros(13 + 2 * n)
         # pitch about y lifts the tail (the chain extends along -x): nose stays near the ground
         s[3:7] = [0, np.sin(ang / 2), 0, np.cos(ang / 2)]
@@ -201,8 +202,8 @@ def test_partial_contact_sets(pkg, oracle_mod):
         states.append(s)
     S = np.array(states)
     T = np.zeros((len(states), n))
-    G, _, info, R, its, ncs = _substep_compare(pkg, oracle_mod, S, T, residual_threshold=0.0)
+    G, _, info, R, its, ncs = _substep_compare(pkg, oracle_mod, S, T, n=n, residual_threshold=0.0)
     assert np.array_equal(info[:, 1], ncs), (info[:, 1], ncs)
-    assert len(set(ncs.tolist())) >= 3 and any(c % 8 for c in ncs)          # really partial sets
-    assert np.abs(G[:, :7] - R[:, :7]).max() < 2e-4 and np.abs(G[:, 13:29] - R[:, 13:29]).max() < 2e-4
-    assert (np.abs(G[:, 29:] - R[:, 29:]) / (1 + np.abs(R[:, 29:]))).max() < 2e-2
+    assert len(set(ncs.tolist())) >= 3 and any(c % 8 for c in ncs) and any(c % 4 for c in ncs)   # really partial sets
+    assert np.abs(G[:, :7] - R[:, :7]).max() < 2e-4 and np.abs(G[:, 13:13 + n] - R[:, 13:13 + n]).max() < 2e-4
+    assert (np.abs(G[:, 13 + n:] - R[:, 13 + n:]) / (1 + np.abs(R[:, 13 + n:]))).max() < 2e-2

@@ -272,6 +272,94 @@ __device__ __forceinline__ void cone_z(float& RJ, const float RM, const float RJ
           [NLn] "n"(NL), [BIT] "n"(BIT)
         : "scc");
 }
+#define SNK_RED64(T)                                                                                   \
+    "v_add_f32_dpp " T ", " T ", " T " quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"  \
+    "s_nop 1\n\t"                                                                                      \
+    "v_add_f32_dpp " T ", " T ", " T " quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"  \
+    "s_nop 1\n\t"                                                                                      \
+    "v_add_f32_dpp " T ", " T ", " T " row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"          \
+    "s_nop 1\n\t"                                                                                      \
+    "v_add_f32_dpp " T ", " T ", " T " row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"          \
+    "s_nop 1\n\t"                                                                                      \
+    "v_add_f32_dpp " T ", " T ", " T " row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"                    \
+    "s_nop 1\n\t"                                                                                      \
+    "v_add_f32_dpp " T ", " T ", " T " row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+// one DPP step of two independent reductions: each instruction is the other's wait state
+#define SNK_RED64x2_STEP(A, B, MODE)                    \
+    "v_add_f32_dpp " A ", " A ", " A " " MODE "\n\t"      \
+    "v_add_f32_dpp " B ", " B ", " B " " MODE "\n\t"      \
+    "s_nop 0\n\t"
+
+// a contact-normal row: a' = max(a + rhs - (J/den).dv, 0); dv += M^-1 J^T (a' - a).  Returns a'.
+__device__ __forceinline__ float row_step_normal(float jv, float mv, float rhs, float acc, float den, float& dv, float& lsq) {
+    float t, x, dI, P, s;
+    asm volatile(
+        "v_mul_f32 %[t], %[jv], %[dv]\n\t"
+        "v_add_f32 %[x], %[acc], %[rhs]\n\t"
+        "s_nop 0\n\t"
+        SNK_RED64("%[t]")
+        "s_nop 0\n\t"
+        "v_readlane_b32 %[s], %[t], 63\n\t"
+        "s_nop 1\n\t"
+        "v_subrev_f32 %[x], %[s], %[x]\n\t"
+        "v_max_f32 %[x], 0, %[x]\n\t"
+        "v_sub_f32 %[dI], %[x], %[acc]\n\t"
+        "v_mul_f32 %[P], %[dI], %[mv]\n\t"
+        "v_mul_f32 %[t], %[dI], %[den]\n\t"
+        "v_add_f32 %[dv], %[dv], %[P]\n\t"
+        "v_max_f32 %[lsq], %[lsq], |%[t]|\n\t"
+        : [t] "=&v"(t), [x] "=&v"(x), [dI] "=&v"(dI), [P] "=&v"(P), [s] "=&s"(s), [dv] "+v"(dv), [lsq] "+v"(lsq)
+        : [jv] "v"(jv), [mv] "v"(mv), [rhs] "v"(rhs), [acc] "v"(acc), [den] "v"(den));
+    return x;
+}
+
+// Bullet's cone-friction pair of one contact: both dots from the same delta-v, the new pair
+// (a + rhs - dot) projected radially onto the disc of radius lim.
+__device__ __forceinline__ void row_step_cone(float jA, float mA, float jB, float mB, float rhsA, float rhsB, float& accA,
+                                              float& accB, float denA, float denB, float lim, float EPS, float& dv,
+                                              float& lsq) {
+    float tA, tB, xA, xB, r2, P, sA, sB;
+    asm volatile(
+        "v_mul_f32 %[tA], %[jA], %[dv]\n\t"
+        "v_mul_f32 %[tB], %[jB], %[dv]\n\t"
+        "v_add_f32 %[xA], %[accA], %[rhsA]\n\t"
+        SNK_RED64x2_STEP("%[tA]", "%[tB]", "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1")
+        SNK_RED64x2_STEP("%[tA]", "%[tB]", "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1")
+        SNK_RED64x2_STEP("%[tA]", "%[tB]", "row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+        SNK_RED64x2_STEP("%[tA]", "%[tB]", "row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+        SNK_RED64x2_STEP("%[tA]", "%[tB]", "row_bcast:15 row_mask:0xa bank_mask:0xf")
+        "v_add_f32_dpp %[tA], %[tA], %[tA] row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "v_add_f32_dpp %[tB], %[tB], %[tB] row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "v_add_f32 %[xB], %[accB], %[rhsB]\n\t"
+        "v_readlane_b32 %[sA], %[tA], 63\n\t"
+        "v_readlane_b32 %[sB], %[tB], 63\n\t"
+        "s_nop 0\n\t"
+        "v_subrev_f32 %[xA], %[sA], %[xA]\n\t"
+        "v_subrev_f32 %[xB], %[sB], %[xB]\n\t"
+        "v_fma_f32 %[r2], %[xA], %[xA], %[EPS]\n\t"
+        "v_fma_f32 %[r2], %[xB], %[xB], %[r2]\n\t"
+        "v_rsq_f32 %[r2], %[r2]\n\t"
+        "s_nop 0\n\t"
+        "v_mul_f32_e64 %[r2], %[lim], %[r2] clamp\n\t"
+        "v_mul_f32 %[xA], %[xA], %[r2]\n\t"
+        "v_mul_f32 %[xB], %[xB], %[r2]\n\t"
+        "v_sub_f32 %[tA], %[xA], %[accA]\n\t"
+        "v_sub_f32 %[tB], %[xB], %[accB]\n\t"
+        "v_mul_f32 %[P], %[tA], %[mA]\n\t"
+        "v_mul_f32 %[r2], %[tA], %[denA]\n\t"
+        "v_fmac_f32 %[P], %[tB], %[mB]\n\t"
+        "v_mul_f32 %[tB], %[tB], %[denB]\n\t"
+        "v_add_f32 %[dv], %[dv], %[P]\n\t"
+        "v_max3_f32 %[lsq], %[lsq], |%[r2]|, |%[tB]|\n\t"
+        : [tA] "=&v"(tA), [tB] "=&v"(tB), [xA] "=&v"(xA), [xB] "=&v"(xB), [r2] "=&v"(r2), [P] "=&v"(P), [sA] "=&s"(sA),
+          [sB] "=&s"(sB), [dv] "+v"(dv), [lsq] "+v"(lsq)
+        : [jA] "v"(jA), [mA] "v"(mA), [jB] "v"(jB), [mB] "v"(mB), [rhsA] "v"(rhsA), [rhsB] "v"(rhsB), [accA] "v"(accA),
+          [accB] "v"(accB), [denA] "v"(denA), [denB] "v"(denB), [lim] "v"(lim), [EPS] "v"(EPS));
+    accA = xA;
+    accB = xB;
+}
+
+
 }
 using namespace snk;
 constexpr unsigned long long kLowMask = 0x00000000FFFFFFFFull;
@@ -293,6 +381,8 @@ __global__ __launch_bounds__(64) void k(float* out, unsigned long long* cyc, flo
             else if (MODE == 2) duo_z<4>(RJ[s], RM[s], dv, E, kLowMask, lsq, zz);
             else if (MODE == 3) cone_z<31, 5>(RJ[s], RM[s], RJ[(s + 1) & 7], dv, EPS, E, kLowMask, lsq, zb);
             else if (MODE == 4) { motor_step<3, false>(RM[s], dv, RJ[s], ACCV, 0.f); }
+            else if (MODE == 6) { RJ[s] = row_step_normal(RM[s], RM[(s + 1) & 7], 0.1f, RJ[s], 1.0f, dv, lsq); }
+            else if (MODE == 7) { float aA = RJ[s], aB = RJ[(s + 1) & 7]; row_step_cone(RM[s], RM[(s+2)&7], RM[(s+1)&7], RM[(s+3)&7], 0.1f, 0.2f, aA, aB, 1.f, 1.f, 0.5f, EPS, dv, lsq); RJ[s] = aA; RJ[(s + 1) & 7] = aB; }
         }
     }
     unsigned long long t1 = now();
@@ -326,5 +416,7 @@ int main(int argc, char** argv) {
     if (m < 0 || m == 3) run<3>("cone + skip bit (active)");
     if (m < 0 || m == 5) run<3>("cone + skip bit (all inert)", 0.0f);
     if (m < 0 || m == 4) run<4>("motor direct");
+    if (m < 0 || m == 6) run<6>("32-link normal row (64-lane)");
+    if (m < 0 || m == 7) run<7>("32-link cone pair (64-lane)");
     return 0;
 }
