@@ -8,7 +8,7 @@ sys.path.insert(0, '.'); sys.path.insert(0, 'oracle'); sys.path.insert(0, 'tests
 import oracle as orc
 from conftest import random_state
 pkg = importlib.import_module("bullet-envs_amd")
-n, B = 16, 512
+n, B = 16, int(sys.argv[1]) if len(sys.argv) > 1 else 512
 rng = np.random.default_rng(4321)
 S = np.zeros((B, 13 + 2 * n))
 for i in range(B):
