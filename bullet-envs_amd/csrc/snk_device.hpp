@@ -172,6 +172,15 @@ struct Lds<N, true> : LdsCommon<N> {
 
 __device__ __forceinline__ void lds_sync() { __syncthreads(); }
 
+// What the caller knows about a substep's place in the servo loop (snake.py:283-304).  The joint-0
+// force sensor (obs[55]) is only observable after the LAST substep of an env-step, so the
+// register-resident substep runs its second ABA pass only when this substep can be the last one.
+struct SensorHint {
+    bool always;        // single-substep API: every substep is observable
+    int counter_next;   // value of `counter` after this substep
+    float h_prev;       // checkSnakeHeight's mean height of the pose the substep starts from
+};
+
 // ----------------------------------------------------------------------------------
 // S1: forward kinematics + link velocities of the chain (serial recurrence, evaluated
 // uniformly by the wave; lane 0 stores)
@@ -1093,7 +1102,8 @@ __device__ void substep_v1(LT& L, const DevModel& M, int lane, float mu, int& it
 namespace snk {
 
 template <class LT>
-__device__ __forceinline__ void substep(LT& L, const DevModel& M0, int lane_in, float mu, int& iters, int& ncontacts) {
+__device__ __forceinline__ void substep(LT& L, const DevModel& M0, int lane_in, float mu, int& iters, int& ncontacts,
+                                        const SensorHint& hint) {
     int lane = lane_in;
     // Launder the model pointer once per substep: otherwise ~100 per-lane model constants are
     // hoisted out of the substep loop and stay live (or spilled) across the whole solve.
@@ -1103,7 +1113,7 @@ __device__ __forceinline__ void substep(LT& L, const DevModel& M0, int lane_in, 
     // ... and the lane id: hundreds of per-lane LDS addresses are loop-invariant and would
     // otherwise be computed in the kernel prologue and spilled.
     asm volatile("" : "+v"(lane));
-    if constexpr (LT::kV2) substep_v2(L, M, lane, mu, iters, ncontacts);
+    if constexpr (LT::kV2) substep_v2(L, M, lane, mu, iters, ncontacts, hint);
     else substep_v1(L, M, lane, mu, iters, ncontacts);
 }
 
@@ -1185,13 +1195,18 @@ __global__ __launch_bounds__(64, 2) void env_step_kernel(const DevModel* __restr
     int counter = 0;
     bool end_height = false;
     int it_dummy = 0, nc_dummy = 0;
+    SensorHint hint;
+    hint.always = false;
+    hint.h_prev = mean_height(L, M, lane);
     while (true) {
         float e = (lane < N) ? (L.targets[lane] - L.q()[lane]) : 0.f;
         float nrm = sqrtf(wave_sum<64>(e * e));
         if (!(nrm > M.servo_tol)) break;
-        substep(L, M, lane, mu, it_dummy, nc_dummy);
+        hint.counter_next = counter + 1;
+        substep(L, M, lane, mu, it_dummy, nc_dummy, hint);
         counter++;
-        if (mean_height(L, M, lane) > M.height_thr) { end_height = true; break; }
+        hint.h_prev = mean_height(L, M, lane);
+        if (hint.h_prev > M.height_thr) { end_height = true; break; }
         if (counter > M.max_counter) break;
     }
     // SnakeGymEnv.step (SnakeGymEnv.py:36-42)
@@ -1241,7 +1256,9 @@ __global__ __launch_bounds__(64, 2) void substep_kernel(const DevModel* __restri
     float mu = fminf(M.mu_link * mu_plane[env], 10.0f);
     fk_vel(L, M, lane);
     int iters = 0, nc = 0;
-    for (int s = 0; s < k; s++) substep(L, M, lane, mu, iters, nc);
+    SensorHint hint;
+    hint.always = true; hint.counter_next = 0; hint.h_prev = 0.f;
+    for (int s = 0; s < k; s++) substep(L, M, lane, mu, iters, nc, hint);
     if (info && lane == 0) { info[2 * env] = iters; info[2 * env + 1] = nc; }
     store_rec(L, recs + (size_t)env * LT::REC, lane);
 }
