@@ -49,6 +49,7 @@ struct snk_handle {
     int32_t* d_info = nullptr;
     float* d_h = nullptr;
     float* d_linkpos = nullptr;   // allocated on first snk_link_positions
+    float* d_rows = nullptr;      // 32-link chains: constraint rows streamed from global memory (snk_device.hpp: pgs_v1)
     int32_t* d_order = nullptr;
     bool plan = true;
     size_t lds_bytes = 0;
@@ -66,13 +67,13 @@ int launch_step(snk_handle* h, float* act, float* obs, float* rew, uint8_t* done
         hipLaunchKernelGGL((snk::plan_kernel<N>), dim3(1), dim3(1024), 0, st, h->d_model, h->d_recs, act, h->d_order,
                            h->n_envs);
     hipLaunchKernelGGL((snk::env_step_kernel<N>), dim3(h->n_envs), dim3(64), h->lds_bytes, st, h->d_model, h->d_recs,
-                       h->d_mu, act, obs, rew, done, sub, vec_mode, h->n_envs, h->plan ? h->d_order : nullptr);
+                       h->d_mu, act, obs, rew, done, sub, vec_mode, h->n_envs, h->plan ? h->d_order : nullptr, h->d_rows);
     return 0;
 }
 template <int N>
 int launch_substep(snk_handle* h, const float* tgt, int k, int32_t* info, hipStream_t st) {
     hipLaunchKernelGGL((snk::substep_kernel<N>), dim3(h->n_envs), dim3(64), h->lds_bytes, st, h->d_model, h->d_recs,
-                       h->d_mu, tgt, k, info, h->n_envs);
+                       h->d_mu, tgt, k, info, h->n_envs, h->d_rows);
     return 0;
 }
 template <int N>
@@ -195,6 +196,11 @@ int snk_create(const snk_params* p, int32_t n_envs, int32_t device, snk_handle**
     HIP_TRY(hipMalloc(&h->d_info, ne * 2 * sizeof(int32_t)));
     HIP_TRY(hipMalloc(&h->d_h, ne * sizeof(float)));
     HIP_TRY(hipMalloc(&h->d_order, ne * sizeof(int32_t)));
+    if (h->n == 32) {
+        const size_t bytes = ne * snk::Lds<32, false>::kRowFloats * sizeof(float);
+        HIP_TRY(hipMalloc(&h->d_rows, bytes));
+        HIP_TRY(hipMemset(h->d_rows, 0, bytes));     // the last three rows of every block stay zero for good
+    }
     h->plan = getenv("SNK_NO_PLAN") == nullptr;
     // hard reset (snake.py:88-95)
     SNK_DISPATCH(h, launch_reset<16>(h, nullptr, nullptr, 1, nullptr), launch_reset<32>(h, nullptr, nullptr, 1, nullptr));
@@ -209,7 +215,7 @@ int snk_destroy(snk_handle* h) {
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
     void* bufs[] = {h->d_model, h->d_recs, h->d_mu, h->d_act, h->d_obs, h->d_rew, h->d_done,
-                    h->d_sub, h->d_mask, h->d_tgt, h->d_info, h->d_h, h->d_order};
+                    h->d_sub, h->d_mask, h->d_tgt, h->d_info, h->d_h, h->d_order, h->d_rows, h->d_linkpos};
     for (void* b : bufs) (void)hipFree(b);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
     delete h;

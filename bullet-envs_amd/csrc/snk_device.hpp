@@ -144,16 +144,18 @@ struct Lds<N, false> : LdsCommon<N> {
     static constexpr int NC = 4 * N, NR = 12 * N, ND = N + 6;
     float cP[NC][3], cdist[NC], cdA[NC][3], cdB[NC][3];   // indexed by contact slot
     int clist[NC];
-    // kPad extra rows: the solve walks the rows four contacts per loop trip, so the rows of up to
-    // three contacts behind the last one are zeroed (inert), and lanes >= ND read the last 12
-    // rows, which are always zero (see pgs_v1)
-    static constexpr int kPad = 24;
-    float Jc[NR + kPad][ND], Mc[NR + kPad][ND];
+    // The contact rows themselves (J and M^-1 J^T, 2 x 384 x 38 floats = 117 KB) do not fit LDS next
+    // to anything else; they live in a per-environment block of global memory that the solve
+    // streams once per iteration (see pgs_v1): kRows rows of J, then kRows rows of M^-1 J^T.
+    static constexpr int kRing = 16;                       // contacts per loop trip of the solve
+    static constexpr int kRows = NR + 6 * kRing + 3;       // + inert padding, the refill's over-read, 3 rows always zero
+    static constexpr size_t kRowFloats = 2 * (size_t)kRows * ND;
+    float utmp[64][N + 1];                                 // row builder: joint-space residuals of the lane's row
     // per-contact scalars of the rows, grouped the way the solve reads them (one ds_read_b128 each):
     //   cN[ci] = {rhs, den, accumulated impulse, 1/den} of the normal row 3ci
     //   cF[ci] = {rhsA, rhsB, denA, denB | accA, accB, 1/denA, 1/denB} of the friction rows 3ci+1, 3ci+2
-    alignas(16) float cN[NC + 4][4];
-    alignas(16) float cF[NC + 4][8];
+    alignas(16) float cN[NC + kRing + 1][4];
+    alignas(16) float cF[NC + kRing + 1][8];
 };
 
 // v2: rows live in VGPRs during the solve; LDS only stages one 64-row batch while they are built
@@ -552,7 +554,7 @@ __device__ void aba_main(LT& L, const DevModel& M, int lane) {
 // (btMultiBodyConstraintSolver::setupMultiBodyContactConstraint / btMultiBodyJointMotor [U]).
 // ----------------------------------------------------------------------------------
 template <class LT>
-__device__ void build_rows_v1(LT& L, const DevModel& M, int lane, int nc, int& n_noncontact) {
+__device__ void build_rows_v1(LT& L, const DevModel& M, int lane, int nc, int& n_noncontact, float* __restrict__ rows) {
     constexpr int N = LT::kN;
     constexpr int ND = N + 6;
     const int nrows = N + 3 * nc;
@@ -561,11 +563,13 @@ __device__ void build_rows_v1(LT& L, const DevModel& M, int lane, int nc, int& n
         const bool motor = rid < N;
         int k, slot = 0, kind = 0;
         f3 P = mk3(0, 0, 0), d = mk3(0, 0, 0);
-        float* Mrow;
-        float* Jrow = nullptr;
+        float* Mrow;             // final row of M^-1 J^T: LDS for a motor, global memory for a contact row
+        float* Jrow = nullptr;   // final J row (contact rows only)
+        float* utmp;             // joint-space residuals between the two sweeps
         if (motor) {
             k = rid + 1;
             Mrow = L.Mm[rid];
+            utmp = Mrow + 6;
         } else {
             const int ci = (rid - N) / 3;
             kind = (rid - N) - 3 * ci;
@@ -573,8 +577,9 @@ __device__ void build_rows_v1(LT& L, const DevModel& M, int lane, int nc, int& n
             k = ((slot >> 1) + 1) >> 1;
             P = ld3(L.cP[slot]);
             d = kind == 0 ? mk3(0.f, 0.f, 1.f) : (kind == 1 ? ld3(L.cdA[slot]) : ld3(L.cdB[slot]));
-            Mrow = L.Mc[rid - N];
-            Jrow = L.Jc[rid - N];
+            Jrow = rows + (size_t)(rid - N) * ND;
+            Mrow = Jrow + (size_t)LT::kRows * ND;
+            utmp = L.utmp[lane];
         }
         // backward sweep of the delta problem (zero velocity, impulse only)
         f3 pN = mk3(0, 0, 0), pF = mk3(0, 0, 0);
@@ -586,7 +591,7 @@ __device__ void build_rows_v1(LT& L, const DevModel& M, int lane, int nc, int& n
             }
             float u = -dot(ax, pN);
             if (motor && b == k) u += 1.0f;
-            Mrow[6 + b - 1] = u;
+            utmp[b - 1] = u;
             float t = u * L.Dinv[b];
             f3 paN = pN + ld3(L.Ua[b]) * t, paF = pF + ld3(L.Ub[b]) * t;
             pN = paN + cross(ld3(L.r[b]), paF);
@@ -613,7 +618,7 @@ __device__ void build_rows_v1(LT& L, const DevModel& M, int lane, int nc, int& n
         if (!motor) { st3(Jrow, J0); st3(Jrow + 3, J1); }
         for (int b = 1; b <= N; b++) {
             a = a + cross(al, ld3(L.r[b]));
-            float u = Mrow[6 + b - 1];
+            float u = utmp[b - 1];
             float qdd = (u - (dot(ld3(L.Ua[b]), al) + dot(ld3(L.Ub[b]), a))) * L.Dinv[b];
             f3 ax = ld3(L.ax[b]);
             al = al + ax * qdd;
@@ -644,7 +649,6 @@ __device__ void build_rows_v1(LT& L, const DevModel& M, int lane, int nc, int& n
                 float* cf = L.cF[cid] + (kind - 1);
                 cf[0] = target * dinv; cf[2] = den; cf[4] = 0.f; cf[6] = dinv;
             }
-            for (int d2 = 0; d2 < ND; d2++) Jrow[d2] *= dinv;   // the solve works on J / den (one multiply less per row step)
         }
     }
     lds_sync();
@@ -718,8 +722,9 @@ __device__ void build_rows_v1(LT& L, const DevModel& M, int lane, int nc, int& n
     "v_add_f32_dpp " B ", " B ", " B " " MODE "\n\t"      \
     "s_nop 0\n\t"
 
-// a contact-normal row: a' = max(a + rhs - (J/den).dv, 0); dv += M^-1 J^T (a' - a).  Returns a'.
-__device__ __forceinline__ float row_step_normal(float jv, float mv, float rhs, float acc, float den, float& dv, float& lsq) {
+// a contact-normal row: a' = max(a + rhs - (J.dv)/den, 0); dv += M^-1 J^T (a' - a).  Returns a'.
+__device__ __forceinline__ float row_step_normal(float jv, float mv, float rhs, float acc, float den, float dinv, float& dv,
+                                                 float& lsq) {
     float t, x, dI, P, s;
     asm volatile(
         "v_mul_f32 %[t], %[jv], %[dv]\n\t"
@@ -729,7 +734,7 @@ __device__ __forceinline__ float row_step_normal(float jv, float mv, float rhs, 
         "s_nop 0\n\t"
         "v_readlane_b32 %[s], %[t], 63\n\t"
         "s_nop 1\n\t"
-        "v_subrev_f32 %[x], %[s], %[x]\n\t"
+        "v_fma_f32 %[x], -%[s], %[dinv], %[x]\n\t"
         "v_max_f32 %[x], 0, %[x]\n\t"
         "v_sub_f32 %[dI], %[x], %[acc]\n\t"
         "v_mul_f32 %[P], %[dI], %[mv]\n\t"
@@ -737,15 +742,15 @@ __device__ __forceinline__ float row_step_normal(float jv, float mv, float rhs, 
         "v_add_f32 %[dv], %[dv], %[P]\n\t"
         "v_max_f32 %[lsq], %[lsq], |%[t]|\n\t"
         : [t] "=&v"(t), [x] "=&v"(x), [dI] "=&v"(dI), [P] "=&v"(P), [s] "=&s"(s), [dv] "+v"(dv), [lsq] "+v"(lsq)
-        : [jv] "v"(jv), [mv] "v"(mv), [rhs] "v"(rhs), [acc] "v"(acc), [den] "v"(den));
+        : [jv] "v"(jv), [mv] "v"(mv), [rhs] "v"(rhs), [acc] "v"(acc), [den] "v"(den), [dinv] "v"(dinv));
     return x;
 }
 
 // Bullet's cone-friction pair of one contact: both dots from the same delta-v, the new pair
 // (a + rhs - dot) projected radially onto the disc of radius lim.
 __device__ __forceinline__ void row_step_cone(float jA, float mA, float jB, float mB, float rhsA, float rhsB, float& accA,
-                                              float& accB, float denA, float denB, float lim, float EPS, float& dv,
-                                              float& lsq) {
+                                              float& accB, float denA, float denB, float dinvA, float dinvB, float lim,
+                                              float EPS, float& dv, float& lsq) {
     float tA, tB, xA, xB, r2, P, sA, sB;
     asm volatile(
         "v_mul_f32 %[tA], %[jA], %[dv]\n\t"
@@ -762,8 +767,8 @@ __device__ __forceinline__ void row_step_cone(float jA, float mA, float jB, floa
         "v_readlane_b32 %[sA], %[tA], 63\n\t"
         "v_readlane_b32 %[sB], %[tB], 63\n\t"
         "s_nop 0\n\t"
-        "v_subrev_f32 %[xA], %[sA], %[xA]\n\t"
-        "v_subrev_f32 %[xB], %[sB], %[xB]\n\t"
+        "v_fma_f32 %[xA], -%[sA], %[dinvA], %[xA]\n\t"
+        "v_fma_f32 %[xB], -%[sB], %[dinvB], %[xB]\n\t"
         "v_fma_f32 %[r2], %[xA], %[xA], %[EPS]\n\t"
         "v_fma_f32 %[r2], %[xB], %[xB], %[r2]\n\t"
         "v_rsq_f32 %[r2], %[r2]\n\t"
@@ -782,13 +787,15 @@ __device__ __forceinline__ void row_step_cone(float jA, float mA, float jB, floa
         : [tA] "=&v"(tA), [tB] "=&v"(tB), [xA] "=&v"(xA), [xB] "=&v"(xB), [r2] "=&v"(r2), [P] "=&v"(P), [sA] "=&s"(sA),
           [sB] "=&s"(sB), [dv] "+v"(dv), [lsq] "+v"(lsq)
         : [jA] "v"(jA), [mA] "v"(mA), [jB] "v"(jB), [mB] "v"(mB), [rhsA] "v"(rhsA), [rhsB] "v"(rhsB), [accA] "v"(accA),
-          [accB] "v"(accB), [denA] "v"(denA), [denB] "v"(denB), [lim] "v"(lim), [EPS] "v"(EPS));
+          [accB] "v"(accB), [denA] "v"(denA), [denB] "v"(denB), [dinvA] "v"(dinvA), [dinvB] "v"(dinvB), [lim] "v"(lim),
+          [EPS] "v"(EPS));
     accA = xA;
     accB = xB;
 }
 
 template <class LT>
-__device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, float mu, int& iters) {
+__device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, float mu, int& iters,
+                        float* __restrict__ rows) {
     constexpr int N = LT::kN;
     constexpr int ND = N + 6;
     static_assert(ND > 32 && ND <= 64, "this solve is laid out for one row per 64-lane register");
@@ -809,26 +816,29 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
     const float TARGV = (mot && DINVV > 0.f) ? L.nc_rhs[nlim + jm] * L.nc_den[nlim + jm] : 0.f;
     float ACCV = 0.f;                               // accumulated motor impulses, motor j in lane 6+j
     const float EPS = 1e-30f;
-    // One pointer per lane walks the rows, four contacts (12 rows) per loop trip: lane d < ND reads
-    // column d of its rows through immediate offsets (the M^-1 J^T row sits sizeof(Jc) further);
-    // lanes >= ND stay on the last 12 rows of the arrays, which are always zero, so no load needs
-    // a mask.  The rows and scalars of up to three contacts behind the last real one are zeroed
-    // too: a trip that runs past nc resolves inert rows (dI = 0 exactly).
-    constexpr int kPad = LT::kPad;
+    // Row operands come from global memory, kRing contacts per loop trip, each contact's two (or
+    // four) row vectors requested kRing contacts before they are used (the next trip's loads are
+    // issued one by one as this trip's slots are consumed).  Lane d < ND reads column d of a row
+    // (152 contiguous bytes per row: coalesced); lanes >= ND stay on the last three rows of the
+    // block, which are never written (zero).  The rows and scalars of the contacts between nc and
+    // the end of the last trip are zeroed: resolving them changes nothing (dI = 0 exactly).
+    constexpr int kRing = LT::kRing;
+    constexpr int kRows = LT::kRows;
+    const int nc_pad = (nc + kRing - 1) / kRing * kRing;
     {
-        const int r0 = 3 * nc;
-        if (lane < ND) {
-            for (int r = 0; r < 9; r++) { L.Jc[r0 + r][lane] = 0.f; L.Mc[r0 + r][lane] = 0.f; }
-#pragma unroll
-            for (int r = kPad - 12; r < kPad; r++) { L.Jc[NR + r][lane] = 0.f; L.Mc[NR + r][lane] = 0.f; }
-        }
-        if (lane < 12) L.cN[nc + lane / 4][lane & 3] = 0.f;
-        if (lane < 24) L.cF[nc + lane / 8][lane & 7] = 0.f;
+        float* Jz = rows + (size_t)3 * nc * ND;
+        float* Mz = Jz + (size_t)kRows * ND;
+        const int nz = 3 * (nc_pad - nc) * ND;
+        for (int i = lane; i < nz; i += 64) { Jz[i] = 0.f; Mz[i] = 0.f; }
+        for (int i = lane; i < 4 * (nc_pad - nc); i += 64) L.cN[nc][i] = 0.f;
+        for (int i = lane; i < 8 * (nc_pad - nc); i += 64) L.cF[nc][i] = 0.f;
     }
+    __threadfence();          // the rows were written lane = row, they are read lane = column
     lds_sync();
-    const float* const row0 = act ? &L.Jc[0][lane] : &L.Jc[NR + kPad - 12][0];
-    const int rstep4 = act ? 12 * ND : 0;
-    constexpr int kM = (NR + kPad) * ND;            // floats from a J row to its M^-1 J^T row
+    const float* const Jg = rows;
+    const float* const Mg = rows + (size_t)kRows * ND;
+    const int off0 = act ? lane : (kRows - 3) * ND;          // float offset of this lane's column in row 0
+    const int ostep = act ? 3 * ND : 0;                        // ... its advance per contact
     float dv = 0.f;
     int it = 0;
     for (; it < n_iter; it++) {
@@ -851,8 +861,8 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
             }
         };
         auto motor_rows = [&](bool fwd) {
-            const float* mrow = act ? &L.Mm[fwd ? 0 : N - 1][lane] : &L.Jc[NR + kPad - 12][0];
-            const int mstep = act ? (fwd ? ND : -ND) : 0;
+            const float* mrow = &L.Mm[fwd ? 0 : N - 1][act ? lane : 0];
+            const int mstep = fwd ? ND : -ND;
             float mvn = mrow[0];
             float denn = L.nc_den[nlim + (fwd ? 0 : N - 1)];
             for (int jj = 0; jj < N; jj++) {
@@ -863,98 +873,88 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
                     mvn = mrow[0];
                     denn = L.nc_den[nlim + (fwd ? j + 1 : j - 1)];
                 }
-                float u = (TARGV - dv) * DINVV;                          // every motor's candidate dI, lane-local
+                float u = (TARGV - dv) * DINVV;                          // every motor's candidate dI, lane-local (DINVV = 0 beyond the joints)
                 if (mi < 1e30f) u = fminf(fmaxf(ACCV + u, -mi), mi) - ACCV;
                 const float sdI = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(u), 6 + j));
                 ACCV = (lane == 6 + j) ? ACCV + u : ACCV;
-                dv += sdI * mv;
+                dv += act ? sdI * mv : 0.f;
                 lsq_nc = fmaxf(lsq_nc, fabsf(sdI * den));
             }
         };
         if (it & 1) { limit_rows(true); motor_rows(true); }
         else { motor_rows(false); limit_rows(false); }
         if (nc > 0) {
-            // Rows are walked two per loop trip with two operand sets (a, b): the reads of the
-            // next row are issued before the current row's step and nothing is copied.  The
-            // per-row scalars (rhs, den, accumulated impulse) are read through a VGPR address
-            // with immediate offsets (qoff is laundered so the compiler does not turn each of
-            // them into an SGPR address + v_mov).
-            int qoff = 0;
-            asm volatile("" : "+v"(qoff));
-            float* const qN0 = &L.cN[0][0] + qoff;
-            float* const qF0 = &L.cF[0][0] + qoff;
-            struct NOps { float jv, mv, rhs, acc, den; };
-            auto fetchN = [&](const float* pp, const float* qq, int k) {      // k-th contact of the trip
-                NOps o;
-                o.jv = pp[3 * ND * k]; o.mv = pp[kM + 3 * ND * k];
-                o.rhs = qq[4 * k]; o.den = qq[4 * k + 1]; o.acc = qq[4 * k + 2];
-                return o;
-            };
-            {
-                const float* p = row0;
-                float* q = qN0;
-                NOps a = fetchN(p, q, 0);
-                for (int ci = 0; ci < nc; ci += 4) {
-                    const NOps b = fetchN(p, q, 1);
-                    q[2] = row_step_normal(a.jv, a.mv, a.rhs, a.acc, a.den, dv, lsq);
-                    const NOps c = fetchN(p, q, 2);
-                    q[6] = row_step_normal(b.jv, b.mv, b.rhs, b.acc, b.den, dv, lsq);
-                    const NOps d4 = fetchN(p, q, 3);
-                    q[10] = row_step_normal(c.jv, c.mv, c.rhs, c.acc, c.den, dv, lsq);
-                    float* const qd = q;
-                    p += rstep4; q += 16;
-                    if (ci + 4 < nc) a = fetchN(p, q, 0);
-                    qd[14] = row_step_normal(d4.jv, d4.mv, d4.rhs, d4.acc, d4.den, dv, lsq);
+            // normals: slot k of the ring holds contact (trip base + k).  A slot is refilled with
+            // the contact kRing further on as soon as it has been consumed (unconditionally: behind
+            // the last trip this reads padding rows that nobody uses); the contact's scalars
+            // {rhs, den, a, 1/den} come from LDS one step ahead.
+            float jr[kRing], mr[kRing];
+#pragma unroll
+            for (int k = 0; k < kRing; k++) {
+                jr[k] = Jg[off0 + k * ostep];
+                mr[k] = Mg[off0 + k * ostep];
+            }
+            int off = off0;
+            float4 sn = *reinterpret_cast<const float4*>(L.cN[0]);
+            for (int base = 0; base < nc_pad; base += kRing) {
+                off += kRing * ostep;
+#pragma unroll
+                for (int k = 0; k < kRing; k++) {
+                    const float4 sc = sn;
+                    sn = *reinterpret_cast<const float4*>(L.cN[base + k + 1]);
+                    const float jv = jr[k], mv = mr[k];
+                    jr[k] = Jg[off + k * ostep];
+                    mr[k] = Mg[off + k * ostep];
+                    L.cN[base + k][2] = row_step_normal(jv, mv, sc.x, sc.z, sc.y, sc.w, dv, lsq);
                 }
             }
-            // friction pairs
-            struct COps { float jA, jB, mA, mB, rA, rB, aA, aB, dA, dB, lim; };
-            auto fetchC = [&](const float* pp, const float* qq, const float* qn, int k) {
-                COps o;
-                o.jA = pp[ND + 3 * ND * k]; o.jB = pp[2 * ND + 3 * ND * k];
-                o.mA = pp[kM + ND + 3 * ND * k]; o.mB = pp[kM + 2 * ND + 3 * ND * k];
-                const float* c = qq + 8 * k;
-                o.rA = c[0]; o.rB = c[1]; o.dA = c[2]; o.dB = c[3]; o.aA = c[4]; o.aB = c[5];
-                o.lim = mu * qn[4 * k + 2];
-                return o;
-            };
-#define SNK_CONE_ROW(O, QQ, K)                                                                          \
-    row_step_cone(O.jA, O.mA, O.jB, O.mB, O.rA, O.rB, O.aA, O.aB, O.dA, O.dB, O.lim, EPS, dv, lsq);       \
-    (QQ)[8 * (K) + 4] = O.aA; (QQ)[8 * (K) + 5] = O.aB;
             if (cone) {
-                const float* p = row0;
-                float* q = qF0;
-                const float* qn = qN0;
-                COps a = fetchC(p, q, qn, 0);
-                for (int ci = 0; ci < nc; ci += 4) {
-                    COps b = fetchC(p, q, qn, 1);
-                    SNK_CONE_ROW(a, q, 0)
-                    COps c = fetchC(p, q, qn, 2);
-                    SNK_CONE_ROW(b, q, 1)
-                    COps d4 = fetchC(p, q, qn, 3);
-                    SNK_CONE_ROW(c, q, 2)
-                    float* const qd = q;
-                    p += rstep4; q += 32; qn += 16;
-                    if (ci + 4 < nc) a = fetchC(p, q, qn, 0);
-                    SNK_CONE_ROW(d4, qd, 3)
+                // friction pairs: half a ring of contacts in flight (four vectors per contact)
+                constexpr int kC = kRing / 2;
+                float jA[kC], jB[kC], mA[kC], mB[kC];
+#pragma unroll
+                for (int k = 0; k < kC; k++) {
+                    const int o = off0 + k * ostep;
+                    jA[k] = Jg[o + ND]; jB[k] = Jg[o + 2 * ND];
+                    mA[k] = Mg[o + ND]; mB[k] = Mg[o + 2 * ND];
                 }
-#undef SNK_CONE_ROW
+                off = off0;
+                float4 f0 = *reinterpret_cast<const float4*>(L.cF[0]), f1 = *reinterpret_cast<const float4*>(L.cF[0] + 4);
+                float ln = mu * L.cN[0][2];
+                for (int base = 0; base < nc_pad; base += kC) {
+                    off += kC * ostep;
+#pragma unroll
+                    for (int k = 0; k < kC; k++) {
+                        const float4 c0 = f0, c1 = f1;
+                        const float lim = ln;
+                        f0 = *reinterpret_cast<const float4*>(L.cF[base + k + 1]);
+                        f1 = *reinterpret_cast<const float4*>(L.cF[base + k + 1] + 4);
+                        ln = mu * L.cN[base + k + 1][2];
+                        const float cjA = jA[k], cjB = jB[k], cmA = mA[k], cmB = mB[k];
+                        const int o = off + k * ostep;
+                        jA[k] = Jg[o + ND]; jB[k] = Jg[o + 2 * ND];
+                        mA[k] = Mg[o + ND]; mB[k] = Mg[o + 2 * ND];
+                        float aA = c1.x, aB = c1.y;
+                        row_step_cone(cjA, cmA, cjB, cmB, c0.x, c0.y, aA, aB, c0.z, c0.w, c1.z, c1.w, lim, EPS, dv, lsq);
+                        L.cF[base + k][4] = aA; L.cF[base + k][5] = aB;
+                    }
+                }
             } else {
                 // pyramid friction (not Bullet's default here): box-clamped rows, one after the other
-                const float* p = row0;
-                for (int ci = 0; ci < nc; ci++, p += rstep4 / 4) {
+                int o = off0;
+                for (int ci = 0; ci < nc; ci++, o += ostep) {
                     float* cf = L.cF[ci];
                     const float lim = mu * L.cN[ci][2];
                     if (!(lim > 0.f)) continue;
                     const float accA = cf[4], accB = cf[5];
-                    float uA = wave_sum<64>(p[ND] * dv);
+                    float uA = wave_sum<64>(Jg[o + ND] * dv) * cf[6];
                     float sA = fminf(fmaxf(accA + (cf[0] - uA), -lim), lim);
                     float eA = sA - accA;
-                    dv += p[kM + ND] * eA;
-                    float uB = wave_sum<64>(p[2 * ND] * dv);
+                    dv += Mg[o + ND] * eA;
+                    float uB = wave_sum<64>(Jg[o + 2 * ND] * dv) * cf[7];
                     float sB = fminf(fmaxf(accB + (cf[1] - uB), -lim), lim);
                     float eB = sB - accB;
-                    dv += p[kM + 2 * ND] * eB;
+                    dv += Mg[o + 2 * ND] * eB;
                     cf[4] = sA; cf[5] = sB;
                     lsq = fmaxf(lsq, fmaxf(fabsf(eA * cf[2]), fabsf(eB * cf[3])));
                 }
@@ -973,7 +973,7 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
 // one physics substep
 // ----------------------------------------------------------------------------------
 template <class LT>
-__device__ void substep_v1(LT& L, const DevModel& M, int lane, float mu, int& iters, int& ncontacts) {
+__device__ void substep_v1(LT& L, const DevModel& M, int lane, float mu, int& iters, int& ncontacts, float* __restrict__ rows) {
     constexpr int N = LT::kN;
     constexpr int ND = N + 6;
     const float dt = M.dt;
@@ -1005,8 +1005,8 @@ __device__ void substep_v1(LT& L, const DevModel& M, int lane, float mu, int& it
     lds_sync();
     // (4) rows, (5) PGS
     int nn = 0;
-    build_rows_v1(L, M, lane, nc, nn);
-    float dv = pgs_v1(L, M, lane, nc, nn, mu, iters);
+    build_rows_v1(L, M, lane, nc, nn, rows);
+    float dv = pgs_v1(L, M, lane, nc, nn, mu, iters, rows);
     // (6) constraint pass for the joint-0 sensor [U]: ABA at the velocities after (3) with the
     // constraint forces as the only link forces, joint torques still applied
     if (lane <= N) {
@@ -1103,7 +1103,7 @@ namespace snk {
 
 template <class LT>
 __device__ __forceinline__ void substep(LT& L, const DevModel& M0, int lane_in, float mu, int& iters, int& ncontacts,
-                                        const SensorHint& hint) {
+                                        const SensorHint& hint, float* __restrict__ rows) {
     int lane = lane_in;
     // Launder the model pointer once per substep: otherwise ~100 per-lane model constants are
     // hoisted out of the substep loop and stay live (or spilled) across the whole solve.
@@ -1114,7 +1114,7 @@ __device__ __forceinline__ void substep(LT& L, const DevModel& M0, int lane_in, 
     // otherwise be computed in the kernel prologue and spilled.
     asm volatile("" : "+v"(lane));
     if constexpr (LT::kV2) substep_v2(L, M, lane, mu, iters, ncontacts, hint);
-    else substep_v1(L, M, lane, mu, iters, ncontacts);
+    else substep_v1(L, M, lane, mu, iters, ncontacts, rows);
 }
 
 // ----------------------------------------------------------------------------------
@@ -1162,7 +1162,7 @@ __global__ __launch_bounds__(64, 2) void env_step_kernel(const DevModel* __restr
                                                       float* __restrict__ actions, float* __restrict__ obs,
                                                       float* __restrict__ rew, uint8_t* __restrict__ done,
                                                       int32_t* __restrict__ substeps, int vec_mode, int n_envs,
-                                                      const int32_t* __restrict__ order) {
+                                                      const int32_t* __restrict__ order, float* __restrict__ rows_all) {
     extern __shared__ float4 smem_raw[];
     using LT = Lds<N, (N == 16)>;
     LT& L = *reinterpret_cast<LT*>(smem_raw);
@@ -1190,6 +1190,8 @@ __global__ __launch_bounds__(64, 2) void env_step_kernel(const DevModel* __restr
     }
     lds_sync();
     float mu = fminf(M.mu_link * mu_plane[env], 10.0f);
+    float* env_rows = nullptr;      // constraint rows of chains too long for the register-resident solve
+    if constexpr (!LT::kV2) env_rows = rows_all + (size_t)env * LT::kRowFloats;
     fk_vel(L, M, lane);
     // Snake.step servo loop (snake.py:283-304)
     int counter = 0;
@@ -1203,7 +1205,7 @@ __global__ __launch_bounds__(64, 2) void env_step_kernel(const DevModel* __restr
         float nrm = sqrtf(wave_sum<64>(e * e));
         if (!(nrm > M.servo_tol)) break;
         hint.counter_next = counter + 1;
-        substep(L, M, lane, mu, it_dummy, nc_dummy, hint);
+        substep(L, M, lane, mu, it_dummy, nc_dummy, hint, env_rows);
         counter++;
         hint.h_prev = mean_height(L, M, lane);
         if (hint.h_prev > M.height_thr) { end_height = true; break; }
@@ -1242,7 +1244,7 @@ template <int N>
 __global__ __launch_bounds__(64, 2) void substep_kernel(const DevModel* __restrict__ Mp, float* __restrict__ recs,
                                                      const float* __restrict__ mu_plane,
                                                      const float* __restrict__ targets, int k,
-                                                     int32_t* __restrict__ info, int n_envs) {
+                                                     int32_t* __restrict__ info, int n_envs, float* __restrict__ rows_all) {
     extern __shared__ float4 smem_raw[];
     using LT = Lds<N, (N == 16)>;
     LT& L = *reinterpret_cast<LT*>(smem_raw);
@@ -1258,7 +1260,9 @@ __global__ __launch_bounds__(64, 2) void substep_kernel(const DevModel* __restri
     int iters = 0, nc = 0;
     SensorHint hint;
     hint.always = true; hint.counter_next = 0; hint.h_prev = 0.f;
-    for (int s = 0; s < k; s++) substep(L, M, lane, mu, iters, nc, hint);
+    float* env_rows = nullptr;
+    if constexpr (!LT::kV2) env_rows = rows_all + (size_t)env * LT::kRowFloats;
+    for (int s = 0; s < k; s++) substep(L, M, lane, mu, iters, nc, hint, env_rows);
     if (info && lane == 0) { info[2 * env] = iters; info[2 * env + 1] = nc; }
     store_rec(L, recs + (size_t)env * LT::REC, lane);
 }
