@@ -239,7 +239,7 @@ def main():
         try:
             import glob
             cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_summary.json")))
-            if cands:
+            if cands and NL == 16:      # the committed PMC passes are of the headline (16-link) kernel
                 with open(cands[-1]) as f:
                     pm = json.load(f)
                 traffic = pm.get("hbm_bytes_per_launch")

@@ -150,7 +150,6 @@ struct Lds<N, false> : LdsCommon<N> {
     static constexpr int kRing = 16;                       // contacts per loop trip of the solve
     static constexpr int kRows = NR + 6 * kRing + 3;       // + inert padding, the refill's over-read, 3 rows always zero
     static constexpr size_t kRowFloats = 2 * (size_t)kRows * ND;
-    float utmp[64][N + 1];                                 // row builder: joint-space residuals of the lane's row
     // per-contact scalars of the rows, grouped the way the solve reads them (one ds_read_b128 each):
     //   cN[ci] = {rhs, den, accumulated impulse, 1/den} of the normal row 3ci
     //   cF[ci] = {rhsA, rhsB, denA, denB | accA, accB, 1/denA, 1/denB} of the friction rows 3ci+1, 3ci+2
@@ -565,11 +564,10 @@ __device__ void build_rows_v1(LT& L, const DevModel& M, int lane, int nc, int& n
         f3 P = mk3(0, 0, 0), d = mk3(0, 0, 0);
         float* Mrow;             // final row of M^-1 J^T: LDS for a motor, global memory for a contact row
         float* Jrow = nullptr;   // final J row (contact rows only)
-        float* utmp;             // joint-space residuals between the two sweeps
+        float uu[N];             // joint-space residuals between the two sweeps, in registers (both sweeps are fully unrolled)
         if (motor) {
             k = rid + 1;
             Mrow = L.Mm[rid];
-            utmp = Mrow + 6;
         } else {
             const int ci = (rid - N) / 3;
             kind = (rid - N) - 3 * ci;
@@ -579,10 +577,10 @@ __device__ void build_rows_v1(LT& L, const DevModel& M, int lane, int nc, int& n
             d = kind == 0 ? mk3(0.f, 0.f, 1.f) : (kind == 1 ? ld3(L.cdA[slot]) : ld3(L.cdB[slot]));
             Jrow = rows + (size_t)(rid - N) * ND;
             Mrow = Jrow + (size_t)LT::kRows * ND;
-            utmp = L.utmp[lane];
         }
         // backward sweep of the delta problem (zero velocity, impulse only)
         f3 pN = mk3(0, 0, 0), pF = mk3(0, 0, 0);
+#pragma unroll
         for (int b = N; b >= 1; b--) {
             f3 ax = ld3(L.ax[b]);
             if (!motor && b == k) {
@@ -591,7 +589,7 @@ __device__ void build_rows_v1(LT& L, const DevModel& M, int lane, int nc, int& n
             }
             float u = -dot(ax, pN);
             if (motor && b == k) u += 1.0f;
-            utmp[b - 1] = u;
+            uu[b - 1] = u;
             float t = u * L.Dinv[b];
             f3 paN = pN + ld3(L.Ua[b]) * t, paF = pF + ld3(L.Ub[b]) * t;
             pN = paN + cross(ld3(L.r[b]), paF);
@@ -616,9 +614,10 @@ __device__ void build_rows_v1(LT& L, const DevModel& M, int lane, int nc, int& n
         float den = dot(J0, al) + dot(J1, a);
         float rv = dot(J0, ld3(gb)) + dot(J1, ld3(gb + 3));
         if (!motor) { st3(Jrow, J0); st3(Jrow + 3, J1); }
+#pragma unroll
         for (int b = 1; b <= N; b++) {
             a = a + cross(al, ld3(L.r[b]));
-            float u = utmp[b - 1];
+            float u = uu[b - 1];
             float qdd = (u - (dot(ld3(L.Ua[b]), al) + dot(ld3(L.Ub[b]), a))) * L.Dinv[b];
             f3 ax = ld3(L.ax[b]);
             al = al + ax * qdd;
