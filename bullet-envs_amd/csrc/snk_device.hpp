@@ -149,7 +149,12 @@ struct Lds<N, false> : LdsCommon<N> {
     // streams once per iteration (see pgs_v1): kRows rows of J, then kRows rows of M^-1 J^T.
     static constexpr int kRing = 16;                       // contacts per loop trip of the solve
     static constexpr int kRows = NR + 6 * kRing + 3;       // + inert padding, the refill's over-read, 3 rows always zero
-    static constexpr size_t kRowFloats = 2 * (size_t)kRows * ND;
+    // a row of the block: [J (ND floats), pad, M^-1 J^T (ND floats), pad], 320 B = five aligned 64-B
+    // sectors for 304 useful bytes (separate, unaligned 152-B rows fetched 1.4x their size)
+    static constexpr int kRS = 80;                         // floats per row of the block
+    static constexpr int kMO = 40;                         // float offset of the M^-1 J^T half
+    static_assert(ND <= kMO, "row layout");
+    static constexpr size_t kRowFloats = (size_t)kRows * kRS;
     // per-contact scalars of the rows, grouped the way the solve reads them (one ds_read_b128 each):
     //   cN[ci] = {rhs, den, accumulated impulse, 1/den} of the normal row 3ci
     //   cF[ci] = {rhsA, rhsB, denA, denB | accA, accB, 1/denA, 1/denB} of the friction rows 3ci+1, 3ci+2
@@ -575,8 +580,8 @@ __device__ void build_rows_v1(LT& L, const DevModel& M, int lane, int nc, int& n
             k = ((slot >> 1) + 1) >> 1;
             P = ld3(L.cP[slot]);
             d = kind == 0 ? mk3(0.f, 0.f, 1.f) : (kind == 1 ? ld3(L.cdA[slot]) : ld3(L.cdB[slot]));
-            Jrow = rows + (size_t)(rid - N) * ND;
-            Mrow = Jrow + (size_t)LT::kRows * ND;
+            Jrow = rows + (size_t)(rid - N) * LT::kRS;
+            Mrow = Jrow + LT::kMO;
         }
         // backward sweep of the delta problem (zero velocity, impulse only)
         f3 pN = mk3(0, 0, 0), pF = mk3(0, 0, 0);
@@ -825,19 +830,19 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
     constexpr int kRows = LT::kRows;
     const int nc_pad = (nc + kRing - 1) / kRing * kRing;
     {
-        float* Jz = rows + (size_t)3 * nc * ND;
-        float* Mz = Jz + (size_t)kRows * ND;
-        const int nz = 3 * (nc_pad - nc) * ND;
-        for (int i = lane; i < nz; i += 64) { Jz[i] = 0.f; Mz[i] = 0.f; }
+        float* z = rows + (size_t)3 * nc * LT::kRS;
+        const int nz = 3 * (nc_pad - nc) * LT::kRS;
+        for (int i = lane; i < nz; i += 64) z[i] = 0.f;
         for (int i = lane; i < 4 * (nc_pad - nc); i += 64) L.cN[nc][i] = 0.f;
         for (int i = lane; i < 8 * (nc_pad - nc); i += 64) L.cF[nc][i] = 0.f;
     }
     __threadfence();          // the rows were written lane = row, they are read lane = column
     lds_sync();
     const float* const Jg = rows;
-    const float* const Mg = rows + (size_t)kRows * ND;
-    const int off0 = act ? lane : (kRows - 3) * ND;          // float offset of this lane's column in row 0
-    const int ostep = act ? 3 * ND : 0;                        // ... its advance per contact
+    constexpr int kRS = LT::kRS;
+    const float* const Mg = rows + LT::kMO;
+    const int off0 = act ? lane : (kRows - 3) * kRS;         // float offset of this lane's column in row 0
+    const int ostep = act ? 3 * kRS : 0;                       // ... its advance per contact
     float dv = 0.f;
     int it = 0;
     for (; it < n_iter; it++) {
@@ -914,8 +919,8 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
 #pragma unroll
                 for (int k = 0; k < kC; k++) {
                     const int o = off0 + k * ostep;
-                    jA[k] = Jg[o + ND]; jB[k] = Jg[o + 2 * ND];
-                    mA[k] = Mg[o + ND]; mB[k] = Mg[o + 2 * ND];
+                    jA[k] = Jg[o + kRS]; jB[k] = Jg[o + 2 * kRS];
+                    mA[k] = Mg[o + kRS]; mB[k] = Mg[o + 2 * kRS];
                 }
                 off = off0;
                 float4 f0 = *reinterpret_cast<const float4*>(L.cF[0]), f1 = *reinterpret_cast<const float4*>(L.cF[0] + 4);
@@ -931,8 +936,8 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
                         ln = mu * L.cN[base + k + 1][2];
                         const float cjA = jA[k], cjB = jB[k], cmA = mA[k], cmB = mB[k];
                         const int o = off + k * ostep;
-                        jA[k] = Jg[o + ND]; jB[k] = Jg[o + 2 * ND];
-                        mA[k] = Mg[o + ND]; mB[k] = Mg[o + 2 * ND];
+                        jA[k] = Jg[o + kRS]; jB[k] = Jg[o + 2 * kRS];
+                        mA[k] = Mg[o + kRS]; mB[k] = Mg[o + 2 * kRS];
                         float aA = c1.x, aB = c1.y;
                         row_step_cone(cjA, cmA, cjB, cmB, c0.x, c0.y, aA, aB, c0.z, c0.w, c1.z, c1.w, lim, EPS, dv, lsq);
                         L.cF[base + k][4] = aA; L.cF[base + k][5] = aB;
@@ -946,14 +951,14 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
                     const float lim = mu * L.cN[ci][2];
                     if (!(lim > 0.f)) continue;
                     const float accA = cf[4], accB = cf[5];
-                    float uA = wave_sum<64>(Jg[o + ND] * dv) * cf[6];
+                    float uA = wave_sum<64>(Jg[o + kRS] * dv) * cf[6];
                     float sA = fminf(fmaxf(accA + (cf[0] - uA), -lim), lim);
                     float eA = sA - accA;
-                    dv += Mg[o + ND] * eA;
-                    float uB = wave_sum<64>(Jg[o + 2 * ND] * dv) * cf[7];
+                    dv += Mg[o + kRS] * eA;
+                    float uB = wave_sum<64>(Jg[o + 2 * kRS] * dv) * cf[7];
                     float sB = fminf(fmaxf(accB + (cf[1] - uB), -lim), lim);
                     float eB = sB - accB;
-                    dv += Mg[o + 2 * ND] * eB;
+                    dv += Mg[o + 2 * kRS] * eB;
                     cf[4] = sA; cf[5] = sB;
                     lsq = fmaxf(lsq, fmaxf(fabsf(eA * cf[2]), fabsf(eB * cf[3])));
                 }
