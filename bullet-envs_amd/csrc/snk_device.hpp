@@ -147,7 +147,7 @@ struct Lds<N, false> : LdsCommon<N> {
     // The contact rows themselves (J and M^-1 J^T, 2 x 384 x 38 floats = 117 KB) do not fit LDS next
     // to anything else; they live in a per-environment block of global memory that the solve
     // streams once per iteration (see pgs_v1): kRows rows of J, then kRows rows of M^-1 J^T.
-    static constexpr int kRing = 16;                       // contacts per loop trip of the solve
+    static constexpr int kRing = 32;                       // contacts per loop trip of the solve
     static constexpr int kRows = NR + 6 * kRing + 3;       // + inert padding, the refill's over-read, 3 rows always zero
     // a row of the block: [J (ND floats), pad, M^-1 J^T (ND floats), pad], 320 B = five aligned 64-B
     // sectors for 304 useful bytes (separate, unaligned 152-B rows fetched 1.4x their size)
