@@ -3,7 +3,7 @@ import numpy as np
 sys.path.insert(0, '.')
 pkg = importlib.import_module("bullet-envs_amd")
 k = 5
-for B in (256, 1024, 1280, 2048):
+for B in (256, 1280):
     res = {}
     for nit in (1, 10, 50):
         st = pkg.Stepper(B, n_modules=32, n_iterations=nit, residual_threshold=0.0)
