@@ -143,7 +143,8 @@ struct Lds<N, false> : LdsCommon<N> {
     static constexpr bool kV2 = false;
     static constexpr int NC = 4 * N, NR = 12 * N, ND = N + 6;
     float cP[NC][3], cdist[NC], cdA[NC][3], cdB[NC][3];   // indexed by contact slot
-    int clist[NC];
+    int clist[NC];               // compact contact index -> slot
+    int cidx[NC];                // slot -> compact contact index (-1: not in contact)
     // The contact rows themselves (J and M^-1 J^T, 2 x 384 x 38 floats = 117 KB) do not fit LDS next
     // to anything else; they live in a per-environment block of global memory that the solve
     // streams once per iteration (see pgs_v1): kRows rows of J, then kRows rows of M^-1 J^T.
@@ -359,9 +360,11 @@ __device__ int find_contacts_v1(LT& L, const DevModel& M, int lane) {
             st3(L.cdB[slot], mulRv(Rw, mk3(l2.x * a.x, l2.y * a.y, l2.z * a.z)));
         }
         unsigned long long bal = __ballot(active);
+        if (slot < 4 * N) L.cidx[slot] = -1;
         if (active) {
             int idx = total + __popcll(bal & ((1ull << lane) - 1ull));
             L.clist[idx] = slot;
+            L.cidx[slot] = idx;
         }
         total += __popcll(bal);
     }
@@ -1016,10 +1019,13 @@ __device__ void substep_v1(LT& L, const DevModel& M, int lane, float mu, int& it
     if (lane <= N) {
         const int b = lane;
         f3 eN = mk3(0, 0, 0), eF = mk3(0, 0, 0);
-        // contact slots of body b: cylinders 2b-1, 2b (body 0: cylinder 0)
-        for (int ci = 0; ci < nc; ci++) {
-            const int slot = L.clist[ci];
-            if ((((slot >> 1) + 1) >> 1) == b) {
+        // contact slots of body b: cylinders 2b-1, 2b (body 0: cylinder 0) = slots 4b-2 .. 4b+1, in
+        // contact order
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int slot = 4 * b - 2 + j;
+            const int ci = (slot >= 0 && slot < 4 * N) ? L.cidx[slot] : -1;
+            if (ci >= 0) {
                 f3 F = (mk3(0.f, 0.f, 1.f) * L.cN[ci][2] + ld3(L.cdA[slot]) * L.cF[ci][4] +
                         ld3(L.cdB[slot]) * L.cF[ci][5]) * M.inv_dt;
                 eF = eF + F;
