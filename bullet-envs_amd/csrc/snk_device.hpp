@@ -188,6 +188,33 @@ struct SensorHint {
     float h_prev;       // checkSnakeHeight's mean height of the pose the substep starts from
 };
 
+// True when the substep whose solve just produced `dv` (this lane's component of the velocity
+// change) can be the LAST of its env-step, i.e. when obs[55] (the joint-0 force sensor, the second
+// ABA pass) can be observed: the servo error after it is within the tolerance, or the counter
+// reaches its cap, or the mean height can cross its threshold.  The first two are evaluated
+// exactly as the loop does (with a 1e-3 safety factor on the tolerance); for the third, no
+// sampled point can move further in one substep than dt * (|v| + L_chain * (|omega| + sum |qd|)):
+// rigid rotations about the base and the joints.
+template <class LT>
+__device__ __forceinline__ bool sensor_pass_needed(LT& L, const DevModel& M, int lane, float dv, const SensorHint& hint) {
+    constexpr int N = LT::kN;
+    constexpr int ND = N + 6;
+    if (hint.always) return true;
+    const float dt = M.dt;
+    float e = 0.f, wgt = 0.f;
+    if (lane < ND) {
+        const float vold = lane < 6 ? L.base()[7 + lane] : L.qd()[lane - 6];
+        const float x = fminf(fmaxf(vold + dv, -M.max_vel), M.max_vel);
+        if (lane >= 6) e = L.targets[lane - 6] - (L.q()[lane - 6] + dt * x);
+        wgt = fabsf(x) * ((lane >= 3 && lane < 6) ? 1.0f : 0.0639f * (N + 2));
+    }
+    const float se = wave_sum<64>(e * e);
+    const float reach = dt * wave_sum<64>(wgt);
+    const float tol = M.servo_tol * 1.001f;
+    const bool sensor = !(se > tol * tol) || hint.counter_next > M.max_counter || !(hint.h_prev + reach < M.height_thr);
+    return __builtin_amdgcn_readfirstlane(sensor ? 1 : 0) != 0;
+}
+
 // ----------------------------------------------------------------------------------
 // S1: forward kinematics + link velocities of the chain (serial recurrence, evaluated
 // uniformly by the wave; lane 0 stores)
@@ -980,7 +1007,8 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
 // one physics substep
 // ----------------------------------------------------------------------------------
 template <class LT>
-__device__ void substep_v1(LT& L, const DevModel& M, int lane, float mu, int& iters, int& ncontacts, float* __restrict__ rows) {
+__device__ void substep_v1(LT& L, const DevModel& M, int lane, float mu, int& iters, int& ncontacts, float* __restrict__ rows,
+                           const SensorHint& hint) {
     constexpr int N = LT::kN;
     constexpr int ND = N + 6;
     const float dt = M.dt;
@@ -1014,55 +1042,58 @@ __device__ void substep_v1(LT& L, const DevModel& M, int lane, float mu, int& it
     int nn = 0;
     build_rows_v1(L, M, lane, nc, nn, rows);
     float dv = pgs_v1(L, M, lane, nc, nn, mu, iters, rows);
-    // (6) constraint pass for the joint-0 sensor [U]: ABA at the velocities after (3) with the
-    // constraint forces as the only link forces, joint torques still applied
-    if (lane <= N) {
-        const int b = lane;
-        f3 eN = mk3(0, 0, 0), eF = mk3(0, 0, 0);
-        // contact slots of body b: cylinders 2b-1, 2b (body 0: cylinder 0) = slots 4b-2 .. 4b+1, in
-        // contact order
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int slot = 4 * b - 2 + j;
-            const int ci = (slot >= 0 && slot < 4 * N) ? L.cidx[slot] : -1;
-            if (ci >= 0) {
-                f3 F = (mk3(0.f, 0.f, 1.f) * L.cN[ci][2] + ld3(L.cdA[slot]) * L.cF[ci][4] +
-                        ld3(L.cdB[slot]) * L.cF[ci][5]) * M.inv_dt;
-                eF = eF + F;
-                eN = eN + cross(ld3(L.cP[slot]) - ld3(L.o[b]), F);
+    // only when this substep can be the last of its env-step (sensor_pass_needed)
+    if (sensor_pass_needed(L, M, lane, dv, hint)) {
+        // (6) constraint pass for the joint-0 sensor [U]: ABA at the velocities after (3) with the
+        // constraint forces as the only link forces, joint torques still applied
+        if (lane <= N) {
+            const int b = lane;
+            f3 eN = mk3(0, 0, 0), eF = mk3(0, 0, 0);
+            // contact slots of body b: cylinders 2b-1, 2b (body 0: cylinder 0) = slots 4b-2 .. 4b+1, in
+            // contact order
+    #pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int slot = 4 * b - 2 + j;
+                const int ci = (slot >= 0 && slot < 4 * N) ? L.cidx[slot] : -1;
+                if (ci >= 0) {
+                    f3 F = (mk3(0.f, 0.f, 1.f) * L.cN[ci][2] + ld3(L.cdA[slot]) * L.cF[ci][4] +
+                            ld3(L.cdB[slot]) * L.cF[ci][5]) * M.inv_dt;
+                    eF = eF + F;
+                    eN = eN + cross(ld3(L.cP[slot]) - ld3(L.o[b]), F);
+                }
+            }
+            st3(&L.ext[b][0], eN);
+            st3(&L.ext[b][3], eF);
+        }
+        if (lane < N) L.tauj[lane] = -M.joint_damp * L.qd_old[lane];
+        lds_sync();
+        if (lane == 0) {
+            for (int i = 0; i < nn; i++) L.tauj[L.nc_joint[i]] += L.nc_sign[i] * L.nc_app[i] * M.inv_dt;
+        }
+        lds_sync();
+        // velocities changed in (3): refresh w, v, zeta of every body (pose unchanged)
+        {
+            f3 wp = ld3(L.base() + 7), vp = ld3(L.base() + 10);
+            if (lane == 0) { st3(L.w[0], wp); st3(L.v[0], vp); }
+            for (int b = 1; b <= N; b++) {
+                f3 ax = ld3(L.ax[b]), rb = ld3(L.r[b]);
+                float qdb = L.qd()[b - 1];
+                f3 w = wp + ax * qdb, v = vp + cross(wp, rb);
+                f3 za = cross(wp, ax) * qdb, zl = cross(wp, cross(wp, rb));
+                if (lane == 0) { st3(L.w[b], w); st3(L.v[b], v); st3(&L.zeta[b][0], za); st3(&L.zeta[b][3], zl); }
+                wp = w; vp = v;
             }
         }
-        st3(&L.ext[b][0], eN);
-        st3(&L.ext[b][3], eF);
-    }
-    if (lane < N) L.tauj[lane] = -M.joint_damp * L.qd_old[lane];
-    lds_sync();
-    if (lane == 0) {
-        for (int i = 0; i < nn; i++) L.tauj[L.nc_joint[i]] += L.nc_sign[i] * L.nc_app[i] * M.inv_dt;
-    }
-    lds_sync();
-    // velocities changed in (3): refresh w, v, zeta of every body (pose unchanged)
-    {
-        f3 wp = ld3(L.base() + 7), vp = ld3(L.base() + 10);
-        if (lane == 0) { st3(L.w[0], wp); st3(L.v[0], vp); }
-        for (int b = 1; b <= N; b++) {
-            f3 ax = ld3(L.ax[b]), rb = ld3(L.r[b]);
-            float qdb = L.qd()[b - 1];
-            f3 w = wp + ax * qdb, v = vp + cross(wp, rb);
-            f3 za = cross(wp, ax) * qdb, zl = cross(wp, cross(wp, rb));
-            if (lane == 0) { st3(L.w[b], w); st3(L.v[b], v); st3(&L.zeta[b][0], za); st3(&L.zeta[b][3], zl); }
-            wp = w; vp = v;
+        lds_sync();
+        body_bias<LT, false>(L, M, lane);
+        lds_sync();
+        aba_main<LT, false>(L, M, lane);
+        {
+            f3 v1 = ld3(L.base() + 10);
+            float nv1 = sqrtf(dot(v1, v1));
+            f3 a2 = ld3(&L.acc0[3]);
+            fz += -dot(zb, a2 * M.m_root + v1 * (M.m_root * (M.lin_damp + M.lin_damp * nv1)));
         }
-    }
-    lds_sync();
-    body_bias<LT, false>(L, M, lane);
-    lds_sync();
-    aba_main<LT, false>(L, M, lane);
-    {
-        f3 v1 = ld3(L.base() + 10);
-        float nv1 = sqrtf(dot(v1, v1));
-        f3 a2 = ld3(&L.acc0[3]);
-        fz += -dot(zb, a2 * M.m_root + v1 * (M.m_root * (M.lin_damp + M.lin_damp * nv1)));
     }
     // (7) apply the solver's delta-v (clamped), motor torques, integrate positions
     if (lane < 6) {
@@ -1124,7 +1155,7 @@ __device__ __forceinline__ void substep(LT& L, const DevModel& M0, int lane_in, 
     // otherwise be computed in the kernel prologue and spilled.
     asm volatile("" : "+v"(lane));
     if constexpr (LT::kV2) substep_v2(L, M, lane, mu, iters, ncontacts, hint);
-    else substep_v1(L, M, lane, mu, iters, ncontacts, rows);
+    else substep_v1(L, M, lane, mu, iters, ncontacts, rows, hint);
 }
 
 // ----------------------------------------------------------------------------------

@@ -801,21 +801,7 @@ __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane, f
     // first two are evaluated exactly as the loop does (with a 1e-3 safety factor on the
     // tolerance); for the third, no sampled point can move further in one substep than
     // dt * (|v| + L_chain * (|omega| + sum |qd|)): rigid rotations about the base and the joints.
-    bool sensor = hint.always;
-    if (!sensor) {
-        float e = 0.f, wgt = 0.f;
-        if (lane < ND) {
-            const float vold = lane < 6 ? L.base()[7 + lane] : L.qd()[lane - 6];
-            const float x = fminf(fmaxf(vold + dv, -M.max_vel), M.max_vel);
-            if (lane >= 6) e = L.targets[lane - 6] - (L.q()[lane - 6] + dt * x);
-            wgt = fabsf(x) * ((lane >= 3 && lane < 6) ? 1.0f : 0.0639f * (N + 2));
-        }
-        const float se = wave_sum<64>(e * e);
-        const float reach = dt * wave_sum<64>(wgt);
-        const float tol = M.servo_tol * 1.001f;
-        sensor = !(se > tol * tol) || hint.counter_next > M.max_counter || !(hint.h_prev + reach < M.height_thr);
-        sensor = __builtin_amdgcn_readfirstlane(sensor ? 1 : 0) != 0;
-    }
+    const bool sensor = sensor_pass_needed(L, M, lane, dv, hint);
     float fz = L.fz();
     if (sensor) {
         // lane = contact: its force and its moment about the body's joint origin (staging rows are

@@ -465,26 +465,26 @@ def test_env_logic_branches(pkg, oracle_mod):
     assert g[3] == 0 == o[3] and g[1] == -10.0 == o[1] and g[0][55] == 15.0
 
 
-def test_sensor_pass_only_when_observable(pkg):
+@pytest.mark.parametrize("n", [16, 32])
+def test_sensor_pass_only_when_observable(pkg, n):
     """The fused env-step kernel skips the joint-0 force sensor pass on substeps that cannot be
     the last of their env-step.  obs[55] must still be exactly what the always-evaluating
     single-substep API gives when the same substeps are replayed one by one."""
     from bench import gait_actions
-    B = 512
-    st = pkg.Stepper(B)
-    rp = pkg.Stepper(B)
+    B, A = (512, 8) if n == 16 else (128, 16)
+    st = pkg.Stepper(B, n_modules=n)
+    rp = pkg.Stepper(B, n_modules=n)
     st.reset()
     rng = np.random.default_rng(3)
-    for j in range(6):
-        a = gait_actions(np.arange(B), j).astype(np.float32) if j % 2 == 0 else rng.uniform(-1, 1, (B, 8)).astype(np.float32)
+    for j in range(6 if n == 16 else 3):
+        a = gait_actions(np.arange(B), j, A).astype(np.float32) if j % 2 == 0 else rng.uniform(-1, 1, (B, A)).astype(np.float32)
         S, X = st.get_state()
         obs, rew, done, sub = st.step(a.copy(), vec_mode=False)          # terminal obs even when done
         # replay with the substep API: group envs by their substep count
-        T = np.zeros((B, 16), np.float32)
+        T = np.zeros((B, n), np.float32)
         T[:, 1::2] = np.clip(a, -1, 1) * np.float32(np.pi / 6)
         rp.set_state(S, X)
         left = sub.copy()
-        ob55 = X[:, 16].copy()
         # advance all envs together; an env that is finished is restored afterwards (it must not move)
         final = {}
         for k in range(int(sub.max())):
@@ -499,6 +499,6 @@ def test_sensor_pass_only_when_observable(pkg):
         _, Xf = rp.get_state()
         moved = sub > 0
         assert moved.sum() > B // 2
-        assert np.array_equal(obs[moved, 55], Xf[moved, 16]), np.abs(obs[moved, 55] - Xf[moved, 16]).max()
-        assert np.array_equal(obs[~moved, 55], X[~moved, 16])
+        assert np.array_equal(obs[moved, 3 * n + 7], Xf[moved, n]), np.abs(obs[moved, 3 * n + 7] - Xf[moved, n]).max()
+        assert np.array_equal(obs[~moved, 3 * n + 7], X[~moved, n])
     st.close(); rp.close()
