@@ -142,7 +142,6 @@ template <int N>
 struct Lds<N, false> : LdsCommon<N> {
     static constexpr bool kV2 = false;
     static constexpr int NC = 4 * N, NR = 12 * N, ND = N + 6;
-    float cP[NC][3], cdist[NC], cdA[NC][3], cdB[NC][3];   // indexed by contact slot
     int clist[NC];               // compact contact index -> slot
     int cidx[NC];                // slot -> compact contact index (-1: not in contact)
     // The contact rows themselves (J and M^-1 J^T, 2 x 384 x 38 floats = 117 KB) do not fit LDS next
@@ -155,7 +154,12 @@ struct Lds<N, false> : LdsCommon<N> {
     static constexpr int kRS = 80;                         // floats per row of the block
     static constexpr int kMO = 40;                         // float offset of the M^-1 J^T half
     static_assert(ND <= kMO, "row layout");
-    static constexpr size_t kRowFloats = (size_t)kRows * kRS;
+    // behind the rows: the contact geometry of the NC slots, 12 floats each: P[3], distance, friction
+    // direction A[3], B[3], pad[2] (written lane = slot by find_contacts_v1, read by the row builder
+    // and the sensor pass)
+    static constexpr int kGeo = 12;
+    static constexpr size_t kGeoOff = (size_t)kRows * kRS;
+    static constexpr size_t kRowFloats = kGeoOff + (size_t)NC * kGeo;
     // per-contact scalars of the rows, grouped the way the solve reads them (one ds_read_b128 each):
     //   cN[ci] = {rhs, den, accumulated impulse, 1/den} of the normal row 3ci
     //   cF[ci] = {rhsA, rhsB, denA, denB | accA, accB, 1/denA, 1/denB} of the friction rows 3ci+1, 3ci+2
@@ -352,7 +356,7 @@ __device__ void body_bias(LT& L, const DevModel& M, int lane) {
 // the cylinder link's axes: d' = Rc diag(aniso) Rc^T d  (snake.py:104-106).
 // ----------------------------------------------------------------------------------
 template <class LT>
-__device__ int find_contacts_v1(LT& L, const DevModel& M, int lane) {
+__device__ int find_contacts_v1(LT& L, const DevModel& M, int lane, float* __restrict__ rows) {
     constexpr int N = LT::kN;
     int total = 0;
     for (int base = 0; base < 4 * N; base += 64) {
@@ -378,13 +382,14 @@ __device__ int find_contacts_v1(LT& L, const DevModel& M, int lane) {
             f3 P = ld3(L.o[b]) + mulRv(Rb, ld3(M.cyl_c[c])) + mulRv(Rw, loc);
             float dist = P.z;
             active = dist < M.break_thr;
-            st3(L.cP[slot], P);
-            L.cdist[slot] = dist;
+            float* geo = rows + LT::kGeoOff + (size_t)slot * LT::kGeo;
+            st3(geo, P);
+            geo[3] = dist;
             f3 a = mk3(M.aniso[0], M.aniso[1], M.aniso[2]);
             f3 l1 = mulRtv(Rw, mk3(0.f, -1.f, 0.f));
             f3 l2 = mulRtv(Rw, mk3(1.f, 0.f, 0.f));
-            st3(L.cdA[slot], mulRv(Rw, mk3(l1.x * a.x, l1.y * a.y, l1.z * a.z)));
-            st3(L.cdB[slot], mulRv(Rw, mk3(l2.x * a.x, l2.y * a.y, l2.z * a.z)));
+            st3(geo + 4, mulRv(Rw, mk3(l1.x * a.x, l1.y * a.y, l1.z * a.z)));
+            st3(geo + 7, mulRv(Rw, mk3(l2.x * a.x, l2.y * a.y, l2.z * a.z)));
         }
         unsigned long long bal = __ballot(active);
         if (slot < 4 * N) L.cidx[slot] = -1;
@@ -597,6 +602,7 @@ __device__ void build_rows_v1(LT& L, const DevModel& M, int lane, int nc, int& n
         const bool motor = rid < N;
         int k, slot = 0, kind = 0;
         f3 P = mk3(0, 0, 0), d = mk3(0, 0, 0);
+        float cdist_slot = 0.f;
         float* Mrow;             // final row of M^-1 J^T: LDS for a motor, global memory for a contact row
         float* Jrow = nullptr;   // final J row (contact rows only)
         float uu[N];             // joint-space residuals between the two sweeps, in registers (both sweeps are fully unrolled)
@@ -608,8 +614,10 @@ __device__ void build_rows_v1(LT& L, const DevModel& M, int lane, int nc, int& n
             kind = (rid - N) - 3 * ci;
             slot = L.clist[ci];
             k = ((slot >> 1) + 1) >> 1;
-            P = ld3(L.cP[slot]);
-            d = kind == 0 ? mk3(0.f, 0.f, 1.f) : (kind == 1 ? ld3(L.cdA[slot]) : ld3(L.cdB[slot]));
+            const float* geo = rows + LT::kGeoOff + (size_t)slot * LT::kGeo;
+            P = ld3(geo);
+            d = kind == 0 ? mk3(0.f, 0.f, 1.f) : (kind == 1 ? ld3(geo + 4) : ld3(geo + 7));
+            cdist_slot = geo[3];
             Jrow = rows + (size_t)(rid - N) * LT::kRS;
             Mrow = Jrow + LT::kMO;
         }
@@ -671,7 +679,7 @@ __device__ void build_rows_v1(LT& L, const DevModel& M, int lane, int nc, int& n
             float dinv = den > 1.1920929e-7f ? 1.0f / den : 0.f;
             float target;
             if (kind == 0) {
-                float pen = L.cdist[slot] + M.slop;
+                float pen = cdist_slot + M.slop;
                 target = -rv + (pen > 0.f ? -pen * M.inv_dt : -pen * M.contact_erp * M.inv_dt);
             } else {
                 target = -rv;
@@ -1013,8 +1021,9 @@ __device__ void substep_v1(LT& L, const DevModel& M, int lane, float mu, int& it
     constexpr int ND = N + 6;
     const float dt = M.dt;
     // (1) contacts of the current pose, (2) bias forces with gravity, joint damping torque
-    const int nc = find_contacts_v1(L, M, lane);
+    const int nc = find_contacts_v1(L, M, lane, rows);
     ncontacts = nc;
+    __threadfence();      // contact geometry: written lane = slot, read lane = row
     if (lane < N) {
         float qd = L.qd()[lane];
         L.qd_old[lane] = qd;
@@ -1056,10 +1065,11 @@ __device__ void substep_v1(LT& L, const DevModel& M, int lane, float mu, int& it
                 const int slot = 4 * b - 2 + j;
                 const int ci = (slot >= 0 && slot < 4 * N) ? L.cidx[slot] : -1;
                 if (ci >= 0) {
-                    f3 F = (mk3(0.f, 0.f, 1.f) * L.cN[ci][2] + ld3(L.cdA[slot]) * L.cF[ci][4] +
-                            ld3(L.cdB[slot]) * L.cF[ci][5]) * M.inv_dt;
+                    const float* geo = rows + LT::kGeoOff + (size_t)slot * LT::kGeo;
+                    f3 F = (mk3(0.f, 0.f, 1.f) * L.cN[ci][2] + ld3(geo + 4) * L.cF[ci][4] +
+                            ld3(geo + 7) * L.cF[ci][5]) * M.inv_dt;
                     eF = eF + F;
-                    eN = eN + cross(ld3(L.cP[slot]) - ld3(L.o[b]), F);
+                    eN = eN + cross(ld3(geo) - ld3(L.o[b]), F);
                 }
             }
             st3(&L.ext[b][0], eN);
