@@ -41,6 +41,8 @@ def build(force=False, verbose=False, defines=(), out=None):
 if __name__ == "__main__":
     if "--profile" in sys.argv:
         print(build(force=True, defines=("SNK_PROFILE",), out=os.path.join(HERE, "libsnk_prof.so")))
+    elif "--sched-debug" in sys.argv:      # per-wave accounting of the step kernel's scheduler (tools/sched_stats.py)
+        print(build(force=True, defines=("SNK_SCHED_DEBUG",), out=os.path.join(HERE, "libsnk_dbg.so")))
     else:
         build(force="--force" in sys.argv, verbose="-v" in sys.argv)
         print(LIB)

@@ -8,6 +8,7 @@
 #include <cstring>
 #include <limits>
 #include <string>
+#include <mutex>
 #include <vector>
 
 #include "../../include/snk.h"
@@ -52,6 +53,12 @@ struct snk_handle {
     float* d_rows = nullptr;      // 32-link chains: constraint rows streamed from global memory (snk_device.hpp: pgs_v1)
     int32_t* d_order = nullptr;
     bool plan = true;
+    // in-launch scheduler of env_step_sched_kernel (snk_device.hpp): rings, counters, the host-mapped alarm word
+    snk::Sched sched = {};
+    int32_t* h_alarm = nullptr;
+    int grid_waves = 0;           // resident waves of the step kernel
+    int model_slot = -1;          // index into snk::g_models (constant memory); -1: none free, unscheduled kernel
+    bool use_sched = true;
     size_t lds_bytes = 0;
     // timing: pool of event pairs, one pair per snk_step launch, read back in one go
     std::vector<hipEvent_t> ev;
@@ -63,6 +70,13 @@ namespace {
 template <int N>
 int launch_step(snk_handle* h, float* act, float* obs, float* rew, uint8_t* done, int32_t* sub, int vec_mode,
                 hipStream_t st) {
+    if (h->use_sched) {
+        hipLaunchKernelGGL((snk::plan_sched_kernel<N>), dim3(1), dim3(1024), 0, st, h->d_model, h->d_recs, act, h->sched,
+                           h->n_envs);
+        hipLaunchKernelGGL((snk::env_step_sched_kernel<N>), dim3(h->grid_waves), dim3(64), h->lds_bytes, st, h->model_slot,
+                           h->d_recs, h->d_mu, act, obs, rew, done, sub, vec_mode, h->n_envs, h->sched, h->d_rows);
+        return 0;
+    }
     if (h->plan)
         hipLaunchKernelGGL((snk::plan_kernel<N>), dim3(1), dim3(1024), 0, st, h->d_model, h->d_recs, act, h->d_order,
                            h->n_envs);
@@ -88,9 +102,25 @@ int launch_obs(snk_handle* h, float* obs, float* height, hipStream_t st, float* 
                        height, linkpos, h->n_envs);
     return 0;
 }
+// Waves of the step kernel a CU holds: __launch_bounds__(64, 2) = 2 per SIMD, 4 SIMDs, and the CU's LDS (160 KB on
+// gfx950; hipOccupancyMaxActiveBlocksPerMultiprocessor assumes 64 KB and under-counts).  Too many is harmless (late
+// blocks find the queue drained), too few idles the chip.
+int resident_waves(size_t bytes, int device, int* out) {
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    size_t lds = prop.maxSharedMemoryPerMultiProcessor;
+    if (lds < 160 * 1024) lds = 160 * 1024;
+    int per_cu = (int)(lds / (bytes ? bytes : 1));
+    if (per_cu > 8) per_cu = 8;
+    if (per_cu < 1) per_cu = 1;
+    *out = per_cu * prop.multiProcessorCount;
+    return 0;
+}
 template <int N>
 int set_lds_attr(size_t bytes) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&snk::env_step_kernel<N>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&snk::env_step_sched_kernel<N>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&snk::substep_kernel<N>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
@@ -104,6 +134,28 @@ int set_lds_attr(size_t bytes) {
 // Kernels are instantiated for the chain lengths the BASELINE configs use.
 #define SNK_DISPATCH(h, CALL16, CALL32)                                       \
     ((h)->n == 16 ? (CALL16) : ((h)->n == 32 ? (CALL32) : fail("unsupported n_modules (16 or 32)")))
+
+// slots of snk::g_models, shared by the handles of this process
+std::mutex g_slot_mutex;
+bool g_slot_used[snk::kModelSlots] = {};
+int take_model_slot() {
+    std::lock_guard<std::mutex> lk(g_slot_mutex);
+    for (int i = 0; i < snk::kModelSlots; i++)
+        if (!g_slot_used[i]) { g_slot_used[i] = true; return i; }
+    return -1;
+}
+void release_model_slot(int i) {
+    if (i < 0) return;
+    std::lock_guard<std::mutex> lk(g_slot_mutex);
+    g_slot_used[i] = false;
+}
+
+// the step kernel's bounded waits (snk_device.hpp: sched_pop) raise this word when one runs out
+int check_alarm(const snk_handle* h) {
+    if (h->h_alarm && *(volatile int32_t*)h->h_alarm)
+        return fail("env-step scheduler: a bounded wait ran out (state of this handle is no longer valid)");
+    return 0;
+}
 
 int check_launch() {
     hipError_t e = hipGetLastError();
@@ -202,6 +254,40 @@ int snk_create(const snk_params* p, int32_t n_envs, int32_t device, snk_handle**
         HIP_TRY(hipMemset(h->d_rows, 0, bytes));     // the last three rows of every block stay zero for good
     }
     h->plan = getenv("SNK_NO_PLAN") == nullptr;
+    {
+        // scheduler state (snk_device.hpp: Sched)
+        const char* q = getenv("SNK_QUANTUM");       // substeps per slice; 0 = whole env-steps in launch order
+        int quantum = q ? atoi(q) : 3;
+        h->model_slot = quantum > 0 ? take_model_slot() : -1;
+        h->use_sched = h->model_slot >= 0;
+        if (h->use_sched)
+            HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(snk::g_models), &h->D, sizeof(snk::DevModel),
+                                      (size_t)h->model_slot * sizeof(snk::DevModel), hipMemcpyHostToDevice));
+        snk::Sched& sc = h->sched;
+        sc.cap = 2u * (uint32_t)n_envs;
+        sc.quantum = quantum;
+        HIP_TRY(hipMalloc(&sc.head, sizeof(uint32_t)));
+        HIP_TRY(hipMalloc(&sc.tail, sizeof(uint32_t)));
+        HIP_TRY(hipMemset(sc.head, 0, sizeof(uint32_t)));
+        HIP_TRY(hipMemset(sc.tail, 0, sizeof(uint32_t)));
+        HIP_TRY(hipMalloc(&sc.waiting, snk::kBuckets * sizeof(int32_t)));
+        HIP_TRY(hipMemset(sc.waiting, 0, snk::kBuckets * sizeof(int32_t)));
+        HIP_TRY(hipMalloc(&sc.ent, (size_t)sc.cap * sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(sc.ent, 0xFF, (size_t)sc.cap * sizeof(unsigned long long)));
+        HIP_TRY(hipMalloc(&sc.counter, ne * sizeof(int32_t)));
+        HIP_TRY(hipMalloc(&sc.finished, sizeof(int32_t)));
+        HIP_TRY(hipMemset(sc.finished, 0, sizeof(int32_t)));
+        HIP_TRY(hipHostMalloc(&h->h_alarm, 64 * sizeof(int32_t), hipHostMallocMapped));
+        memset(h->h_alarm, 0, 64 * sizeof(int32_t));
+        HIP_TRY(hipHostGetDevicePointer((void**)&sc.alarm, h->h_alarm, 0));
+        int waves = 0;
+        rc = resident_waves(h->lds_bytes, device, &waves);
+        if (rc) return rc;
+        h->grid_waves = waves > 0 && waves < n_envs ? waves : n_envs;
+#ifdef SNK_SCHED_DEBUG
+        HIP_TRY(hipMalloc(&sc.wstat, (size_t)h->grid_waves * 8 * sizeof(long long)));
+#endif
+    }
     // hard reset (snake.py:88-95)
     SNK_DISPATCH(h, launch_reset<16>(h, nullptr, nullptr, 1, nullptr), launch_reset<32>(h, nullptr, nullptr, 1, nullptr));
     if (check_launch()) { return 1; }
@@ -215,13 +301,25 @@ int snk_destroy(snk_handle* h) {
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
     void* bufs[] = {h->d_model, h->d_recs, h->d_mu, h->d_act, h->d_obs, h->d_rew, h->d_done,
-                    h->d_sub, h->d_mask, h->d_tgt, h->d_info, h->d_h, h->d_order, h->d_rows, h->d_linkpos};
+                    h->d_sub, h->d_mask, h->d_tgt, h->d_info, h->d_h, h->d_order, h->d_rows, h->d_linkpos,
+                    h->sched.head, h->sched.tail, h->sched.ent, h->sched.waiting, h->sched.counter, h->sched.finished};
     for (void* b : bufs) (void)hipFree(b);
+    if (h->h_alarm) (void)hipHostFree(h->h_alarm);
+    release_model_slot(h->model_slot);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
     delete h;
     return 0;
 }
 
+#ifdef SNK_SCHED_DEBUG
+// per resident wave of the last step: ticks (100 MHz) waiting in the queue, ticks alive, slices, substeps
+int snk_sched_stats(snk_handle* h, long long* out, int32_t* n_waves) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, h->sched.wstat, (size_t)h->grid_waves * 8 * sizeof(long long), hipMemcpyDeviceToHost));
+    *n_waves = h->grid_waves;
+    return 0;
+}
+#endif
 int32_t snk_num_envs(const snk_handle* h) { return h->n_envs; }
 int32_t snk_obs_dim(const snk_handle* h) { return h->D.obs_dim; }
 int32_t snk_act_dim(const snk_handle* h) { return h->D.act_dim; }
@@ -240,6 +338,7 @@ int snk_step(snk_handle* h, float* actions_dev, float* obs_dev, float* rew_dev, 
              int32_t* substeps_dev, int32_t vec_mode, void* stream) {
     if (!h) return fail("snk_step: null handle");
     if (!actions_dev || !obs_dev || !rew_dev || !done_dev) return fail("snk_step: null buffer");
+    if (check_alarm(h)) return 1;
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t st = (hipStream_t)stream;
     const bool timed = 2 * h->ev_used + 1 < (int)h->ev.size();
@@ -305,6 +404,7 @@ int snk_step_host(snk_handle* h, float* actions, float* obs, float* rew, uint8_t
     int rc = snk_step(h, h->d_act, h->d_obs, h->d_rew, h->d_done, h->d_sub, vec_mode, nullptr);
     if (rc) return rc;
     HIP_TRY(hipDeviceSynchronize());
+    if (check_alarm(h)) return 1;
     HIP_TRY(hipMemcpy(actions, h->d_act, ne * h->D.act_dim * sizeof(float), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(obs, h->d_obs, ne * h->D.obs_dim * sizeof(float), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(rew, h->d_rew, ne * sizeof(float), hipMemcpyDeviceToHost));

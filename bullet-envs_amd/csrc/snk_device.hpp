@@ -1420,6 +1420,321 @@ __global__ __launch_bounds__(1024) void plan_kernel(const DevModel* __restrict__
     }
 }
 
+// ----------------------------------------------------------------------------------
+// In-launch scheduling of env-steps (env_step_sched_kernel).
+//
+// An env-step is 0..41 sequential substeps (snake.py:283-304); a launch of E env-steps on G
+// resident waves ends when the slowest wave does.  With whole env-steps as the unit, that is
+// (longest + shortest) substeps when E = 2 G -- 45 for the bench workload whose mean load is 35.5
+// per wave (tools/balance_dump.py) -- because the jobs are too coarse to level.  An env-step can be
+// cut at any substep boundary, though: its whole state is the env's record (plus the substep
+// counter).  So G persistent waves pull env-steps from a queue, run them for `quantum` substeps
+// and put them back at the end of the queue -- unless no waiting env has more work left than
+// this one, in which case the wave just carries on ("longest remaining time first", which
+// levels the finish times to within about a quantum).  The remaining work is known almost
+// exactly: the position motors shrink the servo error by (1 - kp) per substep [U], so
+// remaining = log(err / tol) / -log(1 - kp), capped by the substep counter's limit.
+//
+// Queue: one ring of {ticket, remaining, env} entries.  A pop is ONE returning atomic add on
+// `head` (a ticket), then a wait for that ticket's entry; a push is one atomic add on `tail` and
+// one 8-byte agent-scope store.  (A compare-and-swap pop costs O(G^2) attempts when G waves reach
+// a slice boundary together: 14 ms per launch, measured.)  Tickets are never reset; unsigned
+// wrap-around is harmless.  Pops in excess of pushes wait for an entry that may never come; they
+// leave when `finished` says every env-step is complete, and the next launch starts its tickets at
+// `head`.  waiting[r] counts queued env-steps with r substeps left (the carry-on test).
+// The record hand-off between waves follows MI355X_MICROARCH.md "inter-workgroup visibility":
+// stores, s_waitcnt vmcnt(0), agent release, wait, then the queue entry; consumer: entry seen,
+// agent acquire, wait, plain loads.  Results do not depend on the schedule: a slice boundary
+// stores and reloads exactly the floats a continuing wave keeps (the property test-mode telemetry
+// relies on, tests/test_gpu_env.py).
+//
+// Every wait is bounded in wall-clock time (kWaitTicks): a wave that gives up raises the
+// host-visible word `alarm` and leaves; the others follow, so the grid always drains.
+// ----------------------------------------------------------------------------------
+constexpr int kBuckets = 64;
+constexpr long long kWaitTicks = 200000000;    // wall_clock64() runs at 100 MHz: 2 s (an env-step is < 50 ms)
+
+// The model of the scheduled kernel lives in constant memory: its queue atomics and fences make the
+// compiler treat every load through a global pointer as clobbered (vector loads where the plain
+// kernel has scalar ones); loads from __constant__ stay scalar.  One slot per live handle
+// (snk_api.hip hands them out).
+constexpr int kModelSlots = 32;
+__constant__ DevModel g_models[kModelSlots];
+
+struct Sched {
+    uint32_t* head;             // tickets claimed
+    uint32_t* tail;             // tickets issued
+    unsigned long long* ent;    // [cap]: (ticket << 32) | (remaining << 24) | env; all-ones when never written
+    int32_t* waiting;           // [kBuckets] queued env-steps by substeps left
+    int32_t* counter;           // [n_envs] substeps done so far in this env-step
+    int32_t* finished;          // env-steps completed in this launch
+    int32_t* alarm;             // host-mapped: set when a bounded wait ran out
+    uint32_t cap;               // ring size (2 n_envs: an env is queued at most once)
+    int32_t quantum;            // substeps per slice
+    long long* wstat;           // SNK_SCHED_DEBUG: [grid][4] ticks waiting, ticks alive, slices, substeps
+};
+
+__device__ __forceinline__ int predict_remaining(const DevModel& M, float err, int counter) {
+    if (!(err > M.servo_tol)) return 0;
+    const float decay = fmaxf(-__log2f(fminf(fmaxf(1.0f - M.kp, 1e-6f), 0.999f)), 1e-3f);
+    const float r = ceilf(__log2f(err / M.servo_tol) / decay);
+    const int cap = M.max_counter + 1 - counter;
+    int R = (int)fminf(r, (float)cap);
+    R = R < 1 ? 1 : R;
+    return R > kBuckets - 1 ? kBuckets - 1 : R;
+}
+
+// a wave-uniform condition as a scalar the compiler knows to be uniform (keeps the scheduler's loops out of
+// exec-mask control flow)
+__device__ __forceinline__ bool uni(bool c) { return __builtin_amdgcn_readfirstlane(c ? 1 : 0) != 0; }
+
+// most substeps left among the queued env-steps (-1: queue empty)
+__device__ __forceinline__ int sched_top(const Sched& sc, int lane) {
+    const int w = __hip_atomic_load(&sc.waiting[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long m = __ballot(w > 0);
+    return m ? 63 - __clzll(m) : -1;
+}
+
+__device__ __forceinline__ void sched_alarm(const Sched& sc, int lane) {
+    (void)lane;
+    __hip_atomic_store(sc.alarm, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // every lane, same word
+}
+
+// next env for this wave, or -1 when every env-step of the launch is complete (or on alarm).
+// The wait is a 4-byte sc1 poll of `tail` (a word only atomic adds touch: the form the guide lists as
+// observed cross-XCD); the entry itself is then read with returning atomics, which execute at the
+// memory side -- an 8-byte sc1 LOAD that polled the slot before it was written kept returning the
+// old value (a hang, round 1).
+__device__ __forceinline__ int sched_pop(const Sched& sc, int lane, int n_envs) {
+    // NO `if (lane == 0)` around the queue operations of this file: with a lane-dependent branch at the top of the
+    // scheduling loop the compiler threads the loop's back edge per lane, lane 0 and lanes 1..63 then run the loop
+    // body in separate passes, and every cross-lane operation of the solver breaks (observed: a wave that
+    // re-processes one env for ever).  Every lane issues the atomic with its own operand instead (the atomic
+    // optimizer folds the 64 into one memory operation).
+    uint32_t tk = atomicAdd(sc.head, lane == 0 ? 1u : 0u);
+    tk = (uint32_t)__builtin_amdgcn_readfirstlane((int)tk);
+    const long long t_start = wall_clock64();
+    int nap = 1;
+    for (;;) {
+        const uint32_t t = __hip_atomic_load(sc.tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((int32_t)((uint32_t)__builtin_amdgcn_readfirstlane((int)t) - tk) > 0) break;    // ticket tk has been issued
+        const int fin = __hip_atomic_load(sc.finished, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__builtin_amdgcn_readfirstlane(fin) >= n_envs) return -1;
+        if (uni(wall_clock64() - t_start > kWaitTicks)) {
+            // give up once nobody can still be working, or when somebody else already has
+            if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(sc.alarm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) ||
+                uni(wall_clock64() - t_start > 4 * kWaitTicks)) {
+                sched_alarm(sc, lane);
+                return -1;
+            }
+        }
+        for (int i = 0; i < nap; i++) __builtin_amdgcn_s_sleep(16);      // ~0.5 us, backing off to ~7 us
+        if (nap < 16) nap++;
+    }
+    unsigned long long* e = sc.ent + (tk % sc.cap);
+    for (;;) {
+        const unsigned long long v = __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+        if (hi == tk) {
+            atomicAdd(&sc.waiting[lo >> 24], lane == 0 ? -1 : 0);
+            return (int)(lo & 0xFFFFFFu);
+        }
+        if (uni(wall_clock64() - t_start > 4 * kWaitTicks)) break;
+        __builtin_amdgcn_s_sleep(4);
+    }
+    sched_alarm(sc, lane);
+    return -1;
+}
+
+// hand an unfinished env-step (record already stored by every lane) to whoever pops it
+__device__ __forceinline__ void sched_push(const Sched& sc, int lane, int env, int remaining) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    atomicAdd(&sc.waiting[remaining], lane == 0 ? 1 : 0);
+    const uint32_t tk = (uint32_t)__builtin_amdgcn_readfirstlane((int)atomicAdd(sc.tail, lane == 0 ? 1u : 0u));
+    __hip_atomic_store(sc.ent + (tk % sc.cap),        // every lane stores the same 8 bytes
+                       ((unsigned long long)tk << 32) | ((unsigned long long)remaining << 24) |
+                           (unsigned long long)(uint32_t)env,
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// One block: the queue of a launch, env-steps with the most predicted substeps first (counting sort).
+template <int N>
+__global__ __launch_bounds__(1024) void plan_sched_kernel(const DevModel* __restrict__ Mp, const float* __restrict__ recs,
+                                                          const float* __restrict__ actions, Sched sc, int n_envs) {
+    constexpr int REC = (N <= 16) ? 64 : 128;
+    __shared__ uint32_t hist[kBuckets], base[kBuckets];
+    const DevModel& M = *Mp;
+    const int tid = threadIdx.x;
+    if (tid < kBuckets) hist[tid] = 0;
+    __syncthreads();
+    const int A = M.act_dim;
+    auto key_of = [&](int e) {
+        const float* q = recs + (size_t)e * REC + 13;
+        float err2 = 0.f;
+        for (int j = 0; j < N; j++) {
+            int k = (M.gait == 0) ? ((j & 1) ? -1 : j / 2) : ((M.gait == 1) ? ((j & 1) ? j / 2 : -1) : j);
+            float t = 0.f;
+            if (k >= 0 && k < A) t = fminf(fmaxf(actions[(size_t)e * A + k], -1.f), 1.f) * M.scaling;
+            float d = t - q[j];
+            err2 += d * d;
+        }
+        return predict_remaining(M, sqrtf(err2), 0);
+    };
+    for (int e = tid; e < n_envs; e += blockDim.x) atomicAdd(&hist[key_of(e)], 1u);
+    __syncthreads();
+    const uint32_t t0 = *sc.head;       // tickets the previous launch's leaving waves took are skipped
+    if (tid == 0) {
+        uint32_t run = t0;
+        for (int b = kBuckets - 1; b >= 0; b--) { base[b] = run; run += hist[b]; }
+        *sc.tail = run;
+        *sc.finished = 0;
+    }
+    if (tid < kBuckets) sc.waiting[tid] = (int32_t)hist[tid];
+    __syncthreads();
+    for (int e = tid; e < n_envs; e += blockDim.x) {
+        const int b = key_of(e);
+        const uint32_t tk = atomicAdd(&base[b], 1u);
+        sc.ent[tk % sc.cap] = ((unsigned long long)tk << 32) | ((unsigned long long)b << 24) | (unsigned long long)(uint32_t)e;
+        sc.counter[e] = 0;
+    }
+}
+
+template <int N>
+__global__ __launch_bounds__(64, 2) void env_step_sched_kernel(int model_slot, float* __restrict__ recs,
+                                                            const float* __restrict__ mu_plane,
+                                                            float* __restrict__ actions, float* __restrict__ obs,
+                                                            float* __restrict__ rew, uint8_t* __restrict__ done,
+                                                            int32_t* __restrict__ substeps, int vec_mode, int n_envs,
+                                                            Sched sc, float* __restrict__ rows_all) {
+    extern __shared__ float4 smem_raw[];
+    using LT = Lds<N, (N == 16)>;
+    LT& L = *reinterpret_cast<LT*>(smem_raw);
+    const DevModel& M = g_models[model_slot];
+    const int lane = threadIdx.x;
+    const int A = M.act_dim;
+    float* env_rows = nullptr;      // constraint rows of chains too long for the register-resident solve:
+    if constexpr (!LT::kV2) env_rows = rows_all + (size_t)blockIdx.x * LT::kRowFloats;   // one block per resident wave
+    const int quantum = sc.quantum;
+#ifdef SNK_SCHED_DEBUG
+    long long t_wait = 0, n_slices = 0, n_sub = 0, n_chk = 0, n_req = 0, s_top = 0, s_rem = 0;
+    const long long t_birth = wall_clock64();
+#endif
+    for (;;) {
+#ifdef SNK_SCHED_DEBUG
+        const long long t_p0 = wall_clock64();
+#endif
+        if (__builtin_amdgcn_readfirstlane((int)__popcll(__ballot(1))) != 64) {   // the 64 lanes stay together (see sched_pop)
+            sched_alarm(sc, lane);
+            break;
+        }
+        const int env = __builtin_amdgcn_readfirstlane(sched_pop(sc, lane, n_envs));
+#ifdef SNK_SCHED_DEBUG
+        if (env >= 0) { t_wait += wall_clock64() - t_p0; n_slices++; }
+        else if (lane == 0) {
+            long long* w = sc.wstat + 8 * (size_t)blockIdx.x;
+            w[0] = t_wait; w[1] = t_p0 - t_birth; w[2] = n_slices; w[3] = n_sub;
+            w[4] = n_chk; w[5] = n_req; w[6] = s_top; w[7] = s_rem;
+        }
+#endif
+        if (env < 0) break;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        float* rec = recs + (size_t)env * LT::REC;
+        load_rec(L, rec, lane);
+        int counter = __builtin_amdgcn_readfirstlane(sc.counter[env]);
+        if (counter < 0 || counter > M.max_counter + 1 || env >= n_envs) {     // never, unless a hand-off went wrong
+            sched_alarm(sc, lane);
+            break;
+        }
+        // checkBound (SnakeGymEnv.py:82-88) clips the caller's array in place
+        float act = 0.f;
+        if (lane < A) {
+            act = actions[(size_t)env * A + lane];
+            float cl = fminf(fmaxf(act, -1.0f), 1.0f);
+            if (cl != act) actions[(size_t)env * A + lane] = cl;
+            act = cl;
+        }
+        // createAction (snake.py:247-269) + convertActionToJointCommand (snake.py:223-225)
+        if (lane < N) L.targets[lane] = 0.f;
+        lds_sync();
+        if (lane < A) {
+            int slot = (M.gait == 0) ? 2 * lane : ((M.gait == 1) ? 2 * lane + 1 : lane);
+            L.targets[slot] = act * M.scaling;
+        }
+        lds_sync();
+        const float mu = fminf(M.mu_link * mu_plane[env], 10.0f);
+        fk_vel(L, M, lane);
+        // Snake.step servo loop (snake.py:283-304), `quantum` substeps at a time
+        bool end_height = false, complete = false;
+        int it_dummy = 0, nc_dummy = 0, in_slice = 0;
+        SensorHint hint;
+        hint.always = false;
+        hint.h_prev = mean_height(L, M, lane);
+        while (true) {
+            float e = (lane < N) ? (L.targets[lane] - L.q()[lane]) : 0.f;
+            float nrm = sqrtf(wave_sum<64>(e * e));
+            if (uni(!(nrm > M.servo_tol))) { complete = true; break; }
+            if (in_slice >= quantum) {
+                // slice boundary: carry on unless an env with more work left is waiting
+                const int remaining = predict_remaining(M, __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(nrm))), counter);
+                const int top = sched_top(sc, lane);
+#ifdef SNK_SCHED_DEBUG
+                n_chk++; s_top += top; s_rem += remaining; if (top > remaining) n_req++;
+#endif
+                if (top > remaining) {
+                    store_rec(L, rec, lane);
+                    sc.counter[env] = counter;
+                    sched_push(sc, lane, env, remaining);
+                    break;
+                }
+                in_slice = 0;
+            }
+            hint.counter_next = counter + 1;
+            substep(L, M, lane, mu, it_dummy, nc_dummy, hint, env_rows);
+#ifdef SNK_SCHED_DEBUG
+            n_sub++;
+#endif
+            counter++;
+            in_slice++;
+            hint.h_prev = mean_height(L, M, lane);
+            if (uni(hint.h_prev > M.height_thr)) { end_height = true; complete = true; break; }
+            if (counter > M.max_counter) { complete = true; break; }
+        }
+        if (!complete) continue;
+        // SnakeGymEnv.step (SnakeGymEnv.py:36-42)
+        float en = (lane < N) ? L.qd()[lane] * L.taum()[lane] * M.energy_dt : 0.f;   // snake.py:336-341
+        float energy = wave_sum<64>(en);
+        float x = L.rec[0], y = L.rec[1], fzv = L.fz();
+        float r = M.alpha * (x - L.prev_x()) + (fabsf(fzv) > M.coll_force ? M.coll_pen : 0.f) - M.beta * fabsf(y) -
+                  M.gamma * energy;
+        bool dn = uni(fabsf(L.rec[13 + M.term_index]) > M.term_angle);
+        if (!dn) dn = uni(mean_height(L, M, lane) > M.height_thr);
+        if (!dn) dn = end_height;
+        if (dn) r += M.done_pen;
+        float* ob = obs + (size_t)env * (3 * N + 8);
+        if (!(dn && vec_mode)) write_obs(L, ob, lane);
+        lds_sync();
+        if (dn) {
+            soft_reset(L, lane);
+            lds_sync();
+            if (vec_mode) write_obs(L, ob, lane);   // worker returns env.reset()'s obs
+        }
+        lds_sync();
+        if (lane == 0) {
+            // _observation = terminal obs (SnakeGymEnv.py:42); the worker's reset() refreshes it
+            L.prev_x() = (dn && vec_mode) ? 0.0f : x;
+            rew[env] = r;
+            done[env] = dn ? 1 : 0;
+            if (substeps) substeps[env] = counter;
+        }
+        store_rec(L, rec, lane);
+        atomicAdd(sc.finished, lane == 0 ? 1 : 0);
+    }
+}
+
 // self test of wave_sum / lane_bcast: out[0] = sum32, out[1] = sum64, out[2] = bcast
 __global__ __launch_bounds__(64) void selftest_kernel(float* out) {
     const int lane = threadIdx.x;

@@ -443,6 +443,7 @@ __device__ __forceinline__ void cone_step(float& RJ, const float RM, const float
 template <int J, bool CLAMP>
 __device__ __forceinline__ float motor_step(const float RMj, float& dv, const float TARGV, float& ACCV, float PMIV) {
     float u, xs, s;
+    unsigned long long sv;      // the caller's exec mask (the one-lane update runs under its own)
     if (CLAMP) {
         asm volatile(
             "v_sub_f32 %[u], %[TARGV], %[dv]\n\t"
@@ -451,22 +452,24 @@ __device__ __forceinline__ float motor_step(const float RMj, float& dv, const fl
             "v_sub_f32 %[u], %[xs], %[ACCV]\n\t"
             "s_nop 0\n\t"
             "v_readlane_b32 %[s], %[u], %[LN]\n\t"
+            "s_mov_b64 %[sv], exec\n\t"
             "s_mov_b64 exec, %[MASK]\n\t"
             "v_add_f32 %[ACCV], %[ACCV], %[u]\n\t"
-            "s_mov_b64 exec, -1\n\t"
+            "s_mov_b64 exec, %[sv]\n\t"
             "v_fmac_f32 %[dv], %[s], %[RMj]\n\t"
-            : [u] "=&v"(u), [xs] "=&v"(xs), [s] "=&s"(s), [ACCV] "+v"(ACCV), [dv] "+v"(dv)
+            : [u] "=&v"(u), [xs] "=&v"(xs), [s] "=&s"(s), [sv] "=&s"(sv), [ACCV] "+v"(ACCV), [dv] "+v"(dv)
             : [RMj] "v"(RMj), [TARGV] "v"(TARGV), [PMIV] "v"(PMIV), [LN] "n"(6 + J), [MASK] "n"(1 << (6 + J)));
     } else {
         asm volatile(
             "v_sub_f32 %[u], %[TARGV], %[dv]\n\t"
             "s_nop 0\n\t"
             "v_readlane_b32 %[s], %[u], %[LN]\n\t"
+            "s_mov_b64 %[sv], exec\n\t"
             "s_mov_b64 exec, %[MASK]\n\t"
             "v_add_f32 %[ACCV], %[ACCV], %[u]\n\t"
-            "s_mov_b64 exec, -1\n\t"
+            "s_mov_b64 exec, %[sv]\n\t"
             "v_fmac_f32 %[dv], %[s], %[RMj]\n\t"
-            : [u] "=&v"(u), [s] "=&s"(s), [ACCV] "+v"(ACCV), [dv] "+v"(dv)
+            : [u] "=&v"(u), [s] "=&s"(s), [sv] "=&s"(sv), [ACCV] "+v"(ACCV), [dv] "+v"(dv)
             : [RMj] "v"(RMj), [TARGV] "v"(TARGV), [LN] "n"(6 + J), [MASK] "n"(1 << (6 + J)));
         (void)xs;
     }
