@@ -257,7 +257,7 @@ int snk_create(const snk_params* p, int32_t n_envs, int32_t device, snk_handle**
     {
         // scheduler state (snk_device.hpp: Sched)
         const char* q = getenv("SNK_QUANTUM");       // substeps per slice; 0 = whole env-steps in launch order
-        int quantum = q ? atoi(q) : 3;
+        int quantum = q ? atoi(q) : 1;
         h->model_slot = quantum > 0 ? take_model_slot() : -1;
         h->use_sched = h->model_slot >= 0;
         if (h->use_sched)

@@ -1185,6 +1185,19 @@ __device__ __forceinline__ void store_rec(LT& L, float* __restrict__ rec, int la
 #pragma unroll
     for (int i = lane; i < LT::REC; i += 64) rec[i] = L.rec[i];
 }
+// The same store, write-through (sc1): the record leaves this XCD's L2 for memory at once, so a wave on another
+// XCD can take the env-step over after an agent-scope acquire without this wave writing its whole L2 back
+// (MI355X_MICROARCH.md, inter-workgroup visibility: every handed-off byte stored sc1 and drained with
+// s_waitcnt vmcnt(0) before the flag needs no agent release).  One 16-byte store per lane.
+template <class LT>
+__device__ __forceinline__ void store_rec_through(LT& L, float* __restrict__ rec, int lane) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    lds_sync();
+    if (lane < LT::REC / 4) {
+        const v4f v = reinterpret_cast<const v4f*>(L.rec)[lane];
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(rec + 4 * lane), "v"(v) : "memory");
+    }
+}
 template <class LT>
 __device__ __forceinline__ void write_obs(LT& L, float* __restrict__ obs, int lane) {
     constexpr int N = LT::kN;
@@ -1443,8 +1456,8 @@ __global__ __launch_bounds__(1024) void plan_kernel(const DevModel* __restrict__
 // leave when `finished` says every env-step is complete, and the next launch starts its tickets at
 // `head`.  waiting[r] counts queued env-steps with r substeps left (the carry-on test).
 // The record hand-off between waves follows MI355X_MICROARCH.md "inter-workgroup visibility":
-// stores, s_waitcnt vmcnt(0), agent release, wait, then the queue entry; consumer: entry seen,
-// agent acquire, wait, plain loads.  Results do not depend on the schedule: a slice boundary
+// every handed-off byte stored write-through (sc1), s_waitcnt vmcnt(0), then the queue entry;
+// consumer: entry seen, agent acquire, wait, plain loads.  Results do not depend on the schedule: a slice boundary
 // stores and reloads exactly the floats a continuing wave keeps (the property test-mode telemetry
 // relies on, tests/test_gpu_env.py).
 //
@@ -1547,11 +1560,9 @@ __device__ __forceinline__ int sched_pop(const Sched& sc, int lane, int n_envs) 
     return -1;
 }
 
-// hand an unfinished env-step (record already stored by every lane) to whoever pops it
+// hand an unfinished env-step (record and counter already stored write-through by this wave) to whoever pops it
 __device__ __forceinline__ void sched_push(const Sched& sc, int lane, int env, int remaining) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the write-through stores have left before the entry does
     atomicAdd(&sc.waiting[remaining], lane == 0 ? 1 : 0);
     const uint32_t tk = (uint32_t)__builtin_amdgcn_readfirstlane((int)atomicAdd(sc.tail, lane == 0 ? 1u : 0u));
     __hip_atomic_store(sc.ent + (tk % sc.cap),        // every lane stores the same 8 bytes
@@ -1685,8 +1696,8 @@ __global__ __launch_bounds__(64, 2) void env_step_sched_kernel(int model_slot, f
                 n_chk++; s_top += top; s_rem += remaining; if (top > remaining) n_req++;
 #endif
                 if (top > remaining) {
-                    store_rec(L, rec, lane);
-                    sc.counter[env] = counter;
+                    store_rec_through(L, rec, lane);
+                    __hip_atomic_store(&sc.counter[env], counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     sched_push(sc, lane, env, remaining);
                     break;
                 }

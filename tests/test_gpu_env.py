@@ -502,3 +502,59 @@ def test_sensor_pass_only_when_observable(pkg, n):
         assert np.array_equal(obs[moved, 3 * n + 7], Xf[moved, n]), np.abs(obs[moved, 3 * n + 7] - Xf[moved, n]).max()
         assert np.array_equal(obs[~moved, 3 * n + 7], X[~moved, n])
     st.close(); rp.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [16, 32])
+def test_schedule_does_not_change_results(pkg, monkeypatch, n):
+    """The step kernel cuts env-steps into slices that move between waves (snk_device.hpp:
+    env_step_sched_kernel).  Whatever the slice length -- 1 substep, 3, whole env-steps, or the
+    unscheduled kernel (SNK_QUANTUM=0) -- every env must end every step on the same bits: a slice
+    boundary stores and reloads exactly the state a continuing wave keeps.  5000 envs over 4 steps is
+    ~300 000 hand-offs between waves on all 8 XCDs, so a stale record would show."""
+    B = 5000 if n == 16 else 1200
+    A = n // 2
+
+    def run(quantum):
+        monkeypatch.setenv("SNK_QUANTUM", str(quantum))
+        st = pkg.Stepper(B, n_modules=n)
+        st.reset()
+        st.set_ground_friction((0.5 + np.arange(B) % 11 / 10.0).astype(np.float32))
+        outs = []
+        for j in range(4):
+            a = (gait(range(B), j, A) * 1.2).astype(np.float32)     # some components get clipped in place
+            o, r, d, s = st.step(a)
+            outs.append((o.copy(), r.copy(), d.copy(), s.copy(), a.copy()))
+        S, X = st.get_state()
+        st.close()
+        return outs, S, X
+
+    ref, S0, X0 = run(0)
+    assert max(s.max() for _, _, _, s, _ in ref) > 25 and min(s.min() for _, _, _, s, _ in ref) < 20
+    for quantum in (1, 3, 64):
+        got, S, X = run(quantum)
+        for (o, r, d, s, a), (O, R, D, Sx, Ax) in zip(got, ref):
+            assert np.array_equal(s, Sx) and np.array_equal(d, D)
+            assert np.array_equal(o, O) and np.array_equal(r, R) and np.array_equal(a, Ax)
+        assert np.array_equal(S, S0) and np.array_equal(X, X0)
+
+
+@pytest.mark.gpu
+def test_many_live_handles(pkg):
+    """The scheduled kernel reads its model from one of 32 constant-memory slots; handles beyond that
+    fall back to the unscheduled kernel and give the same results; slots come back on close()."""
+    a = gait(range(4), 0, 8)
+    hs = [pkg.Stepper(4) for _ in range(36)]
+    outs = []
+    for h in hs:
+        h.reset()
+        outs.append(h.step(a.copy()))
+    for o, r, d, s in outs[1:]:
+        assert np.array_equal(o, outs[0][0]) and np.array_equal(r, outs[0][1]) and np.array_equal(s, outs[0][3])
+    for h in hs:
+        h.close()
+    h = pkg.Stepper(4, kp=0.2)           # a freed slot, a different model
+    h.reset()
+    o2, _, _, s2 = h.step(a.copy())
+    assert s2.max() < outs[0][3].max()   # stiffer servo converges in fewer substeps
+    h.close()
