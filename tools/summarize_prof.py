@@ -1,6 +1,6 @@
 """Turns a gpurun_out/profN directory (rocprofv3 kernel trace + separate PMC passes of
 bench.py) into the summaries committed under profiles/.  Usage:
-    python tools/summarize_prof.py gpurun_out/prof4 r01_v3"""
+    python tools/summarize_prof.py gpurun_out/prof4 r01_v3 [kernel name, default env_step_sched_kernel<16>]"""
 import collections, csv, glob, json, os, shutil, sys
 src, tag = sys.argv[1], sys.argv[2]
 def one(pattern):
@@ -13,7 +13,7 @@ def agg(path, kern):
         if kern in r['Kernel_Name']:
             d[r['Counter_Name']].append(float(r['Counter_Value']))
     return d
-K = 'env_step_kernel<16>'
+K = sys.argv[3] if len(sys.argv) > 3 else 'env_step_sched_kernel<16>'   # sets up to r01_v6: env_step_kernel<16>
 stats = one('trace/*/*kernel_stats.csv')
 shutil.copy(stats, 'profiles/%s_kernel_stats.csv' % tag)
 kavg = None
