@@ -13,7 +13,7 @@ memory (the trainers are host-side).  Actions ("serpenoid gait")
 precomputed and resident in HBM before the timed region.
 
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
-  roofline      dominant kernel (env_step_kernel) against the HBM roofline, algorithmic
+  roofline      dominant kernel (env_step_sched_kernel) against the HBM roofline, algorithmic
                 bytes / HIP-event launch time
   cpu_baseline  the CPU oracle (oracle/, kind "port") timed on this box's host cores on a
                 bounded sample of the same workload (N=1 only)
@@ -280,7 +280,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                "kernel": "env_step_kernel<%d>" % NL, "kernel_ms": kernel_ms, "launches": kcount,
+                "kernel": "env_step_sched_kernel<%d> (+ its plan kernel)" % NL, "kernel_ms": kernel_ms, "launches": kcount,
                 "algorithmic_bytes_per_launch": alg_bytes_launch,
                 "valu": valu,
                 "note": "recurrence-bound path: ~1e3 flop per algorithmic byte; the HBM fraction is "

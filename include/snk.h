@@ -99,7 +99,12 @@ int snk_reset(snk_handle* h, const uint8_t* mask_dev, float* obs_dev, void* stre
  *   substeps_dev [n_envs] i32 (may be NULL): Snake.counter
  *   vec_mode     1: worker semantics, obs of a done env is the post-reset one
  *                (multiprocessing_env.py:13-15); 0: SnakeGymEnv.step semantics, terminal obs
- * Asynchronous on `stream`; results are ready after the stream is synchronised. */
+ * Asynchronous on `stream`; results are ready after the stream is synchronised.
+ * Internally two launches: a one-block plan kernel and the step kernel, whose resident waves share
+ * the env-steps through an in-launch queue.  Results do not depend on that schedule.
+ * Every wait inside the kernel is bounded; if one ever runs out the kernel drains, and this and
+ * every later call on the handle return non-zero ("env-step scheduler: ...").  Environment:
+ * SNK_QUANTUM=<substeps per slice> (default 1; 0 = the unscheduled kernel), read by snk_create. */
 int snk_step(snk_handle* h, float* actions_dev, float* obs_dev, float* rew_dev,
              uint8_t* done_dev, int32_t* substeps_dev, int32_t vec_mode, void* stream);
 
