@@ -1,19 +1,35 @@
+"""Soak of the step kernel (scheduler included): long gait run, random and out-of-range actions, random
+per-env friction, both chain lengths; every output finite, no scheduler alarm (a stalled queue would turn into
+a RuntimeError within seconds).  python tools/soak.py [steps]"""
 import importlib, sys, time
 import numpy as np
-sys.path.insert(0,'.')
+sys.path.insert(0, '.')
 from bench import gait_actions
 pkg = importlib.import_module("bullet-envs_amd")
-B=4096
-st = pkg.Stepper(B); st.reset()
-tot_done=0; tot_sub=0; t0=time.time()
-for j in range(600):
-    o,r,d,s = st.step(gait_actions(np.arange(B), j).astype(np.float32))
-    assert np.isfinite(o).all() and np.isfinite(r).all(), j
-    tot_done += int(d.sum()); tot_sub += int(s.sum())
-print("600 env-steps x 4096 envs: finite everywhere, %d episode ends, mean substeps %.2f, %.1f s" % (tot_done, tot_sub/(600*B), time.time()-t0))
-# random actions incl. out-of-range
-rng=np.random.default_rng(0)
-for j in range(100):
-    o,r,d,s = st.step(rng.uniform(-3,3,(B,8)).astype(np.float32))
-    assert np.isfinite(o).all() and np.isfinite(r).all(), j
-print("100 random-action steps finite; max |qd| %.1f, max |obs55| %.1f" % (np.abs(o[:,16:32]).max(), np.abs(o[:,55]).max()))
+STEPS = int(sys.argv[1]) if len(sys.argv) > 1 else 600
+rng = np.random.default_rng(0)
+for n, B in ((16, 4096), (32, 4096), (16, 1537)):
+    A = n // 2
+    st = pkg.Stepper(B, n_modules=n)
+    st.reset()
+    st.set_ground_friction(rng.uniform(0.5, 1.5, B).astype(np.float32))
+    steps = STEPS if n == 16 else STEPS // 6
+    tot_done = tot_sub = 0
+    hist = np.zeros(64, np.int64)
+    t0 = time.time()
+    for j in range(steps):
+        o, r, d, s = st.step(gait_actions(np.arange(B), j, A).astype(np.float32))
+        assert np.isfinite(o).all() and np.isfinite(r).all(), j
+        tot_done += int(d.sum()); tot_sub += int(s.sum()); hist += np.bincount(s, minlength=64)
+    print("%d links, %d envs: %d gait steps finite, %d episode ends, mean substeps %.2f (min %d max %d), %.1f s"
+          % (n, B, steps, tot_done, tot_sub / (steps * B), np.nonzero(hist)[0][0], np.nonzero(hist)[0][-1], time.time() - t0), flush=True)
+    for j in range(steps // 4):
+        a = rng.uniform(-3, 3, (B, A)).astype(np.float32)
+        if j % 3 == 0:
+            a[rng.random(B) < 0.5] = 0.0            # half the envs already on target: 0-substep env-steps
+        o, r, d, s = st.step(a)
+        assert np.isfinite(o).all() and np.isfinite(r).all(), j
+    print("   %d random-action steps finite; max |qd| %.1f, max |obs fz| %.1f, substeps %d..%d"
+          % (steps // 4, np.abs(o[:, n:2 * n]).max(), np.abs(o[:, -1]).max(), s.min(), s.max()), flush=True)
+    st.close()
+print("soak ok")
