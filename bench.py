@@ -89,7 +89,10 @@ def cpu_baseline(n_envs=128, steps=10):
     import multiprocessing as mp
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as orc
+    import pybullet_live
     orc.build()
+    # probe for a live PyBullet at run time and say what was found, never substitute silently
+    have_pb = pybullet_live.available()
     cores = max(1, min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count(), 16))
     ids = np.arange(n_envs)
     jobs = [(ids[c::cores].tolist(), steps) for c in range(cores)]
@@ -103,8 +106,10 @@ def cpu_baseline(n_envs=128, steps=10):
     return {
         "value": n_envs * steps / busy, "unit": "env-steps/s", "cores": cores, "kind": "port",
         "sample": "%d envs x %d env-steps of the same gait workload on the float64 CPU oracle "
-                  "(oracle/, restates PyBullet's pipeline; PyBullet itself is not installed), "
-                  "%d processes, %.1f s wall" % (n_envs, steps, cores, wall),
+                  "(oracle/, restates PyBullet's pipeline; %s), "
+                  "%d processes, %.1f s wall" % (n_envs, steps,
+                                                 "a PyBullet IS importable on this box: run oracle/pybullet_live.py to pin the oracle against it"
+                                                 if have_pb else "`import pybullet` fails on this box, probed at run time", cores, wall),
         "substeps_per_s": sub / busy, "mean_substeps": sub / float(n_envs * steps),
     }
 
