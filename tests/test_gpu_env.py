@@ -558,3 +558,37 @@ def test_many_live_handles(pkg):
     o2, _, _, s2 = h.step(a.copy())
     assert s2.max() < outs[0][3].max()   # stiffer servo converges in fewer substeps
     h.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("over", [dict(kp=1.0), dict(kp=0.02), dict(max_counter=100, servo_tol=1e-4),
+                                  dict(gait=2, kp=0.3), dict(max_counter=0)])
+def test_schedule_with_unusual_servo_parameters(pkg, monkeypatch, over):
+    """The scheduler predicts the remaining substeps from kp and the servo error; a wrong prediction may cost time,
+    never results: one-substep servos (kp = 1), servos that hit the counter cap (kp = 0.02), caps beyond the
+    queue's 64 priority classes, the identity gait and a cap of zero all match the unscheduled kernel bit for bit."""
+    B = 700
+    A = 16 if over.get("gait") == 2 else 8
+
+    def run(quantum):
+        monkeypatch.setenv("SNK_QUANTUM", str(quantum))
+        st = pkg.Stepper(B, **over)
+        st.reset()
+        outs = []
+        for j in range(3):
+            o, r, d, s = st.step(gait(range(B), j, A).astype(np.float32))
+            outs.append((o.copy(), r.copy(), d.copy(), s.copy()))
+        st.close()
+        return outs
+
+    ref = run(0)
+    for quantum in (1, 2):
+        for got, want in zip(run(quantum), ref):
+            for g, w in zip(got, want):
+                assert np.array_equal(g, w)
+    if "kp" in over and over["kp"] == 1.0:
+        assert ref[0][3].max() <= 4
+    if over.get("kp") == 0.02:
+        assert ref[0][3].max() == 41
+    if over.get("max_counter") == 100:
+        assert ref[0][3].max() > 41
