@@ -1,19 +1,20 @@
 """Per-wave accounting of the scheduled step kernel (env_step_sched_kernel): time alive, time waiting in the
 queue, slices, substeps, and the carry-on / requeue decisions at slice boundaries.
     python bullet-envs_amd/build.py --sched-debug      (here: builds libsnk_dbg.so with -DSNK_SCHED_DEBUG)
-    SNK_LIB=bullet-envs_amd/libsnk_dbg.so [SNK_QUANTUM=q] python tools/sched_stats.py      (on the GPU box)"""
+    SNK_LIB=bullet-envs_amd/libsnk_dbg.so [SNK_QUANTUM=q] python tools/sched_stats.py [16|32]      (on the GPU box)"""
 import importlib, sys, os, ctypes as C
 import numpy as np
 sys.path.insert(0, '.')
 import bench
 pkg = importlib.import_module("bullet-envs_amd")
 E = 4096
-st = pkg.Stepper(E)
+NL = int(sys.argv[1]) if len(sys.argv) > 1 else 16      # chain length: 16 or 32
+st = pkg.Stepper(E, n_modules=NL)
 st.reset()
 ids = np.arange(E)
 lib = st.lib
 for j in range(6):
-    a = bench.gait_actions(ids, j).astype(np.float32)
+    a = bench.gait_actions(ids, j, NL // 2).astype(np.float32)
     o, r, d, sub = st.step(a)
     if j >= 3:
         buf = np.zeros((4096, 8), np.int64); n = C.c_int32()
