@@ -1,0 +1,79 @@
+"""The reference's PPO training loop (ppo/train.py:95-190) with every tensor on the GPU that owns the envs:
+DeviceVecEnv + rollout.collect / compute_gae / ppo_update.  Hyper-parameters default to
+ppo/params.py (hidden 256x256, lr 3e-4, 20 steps per epoch, 4 PPO epochs); the minibatch size defaults to
+1/32 of the batch because the reference's 5 samples per minibatch were sized for 16 envs.
+
+    python tools/train_ppo_device.py --num_envs 4096 --epochs 20
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 tools/train_ppo_device.py   # one shard per GPU
+
+Checkpoints use the reference's layout ({'frame_idx', 'model', 'best_test_reward', 'optimizer'}, ppo/train.py:155-167),
+so they load into the reference's test scripts and vice versa.
+"""
+import argparse, importlib, os, sys, time
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+snk = importlib.import_module("bullet-envs_amd")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--num_envs", type=int, default=4096, help="per GPU")
+    ap.add_argument("--epochs", type=int, default=10)
+    ap.add_argument("--num_steps", type=int, default=20)
+    ap.add_argument("--ppo_epochs", type=int, default=4)
+    ap.add_argument("--mini_batch_size", type=int, default=0)
+    ap.add_argument("--lr", type=float, default=3e-4)
+    ap.add_argument("--log_dir", default="")
+    args = ap.parse_args()
+
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    torch.manual_seed(0)                      # same initial policy on every rank
+    np.random.seed(rank)
+
+    envs = snk.DeviceVecEnv(args.num_envs, device_index=local)
+    net = snk.rollout.ActorCritic(envs.obs_dim, envs.act_dim, [256, 256]).to(dev)
+    opt = torch.optim.Adam(net.parameters(), lr=args.lr)
+    buf = snk.rollout.RolloutBuffer(args.num_steps, args.num_envs, envs.obs_dim, envs.act_dim, dev)
+    mb = args.mini_batch_size or max(5, args.num_steps * args.num_envs // 32)
+    sync = snk.rollout.allreduce_gradients if world > 1 else None
+
+    state = envs.reset().clone()
+    frame_idx, best = 0, -float("inf")
+    for epoch in range(args.epochs):
+        t0 = time.perf_counter()
+        state = snk.rollout.collect(envs, net, state, buf)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        with torch.no_grad():
+            next_value = net(state)[1]
+        returns = snk.rollout.compute_gae(next_value, buf.rewards, buf.masks, buf.values)
+        losses = snk.rollout.ppo_update(net, opt, args.ppo_epochs, mb, *buf.flat(returns), grad_sync=sync)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        frame_idx += args.num_steps
+        mean_r = float(buf.total_reward) / (args.num_steps * args.num_envs)
+        if rank == 0:
+            print("epoch %3d  frames %5d  reward/env-step %+.4f  loss %.4f  collect %.2f s (%.0f env-steps/s)  update %.2f s"
+                  % (epoch, frame_idx, mean_r, losses["loss"], t1 - t0, world * args.num_steps * args.num_envs / (t1 - t0),
+                     t2 - t1), flush=True)
+            if args.log_dir:
+                os.makedirs(args.log_dir, exist_ok=True)
+                snap = {"frame_idx": frame_idx, "model": net.state_dict(), "best_test_reward": max(best, mean_r),
+                        "optimizer": opt.state_dict()}
+                torch.save(snap, os.path.join(args.log_dir, "weights.pth"))
+                if mean_r > best:
+                    torch.save(snap, os.path.join(args.log_dir, "weights_bestPolicy.pth"))
+        best = max(best, mean_r)
+
+
+if __name__ == "__main__":
+    main()
