@@ -1594,7 +1594,15 @@ __global__ __launch_bounds__(1024) void plan_sched_kernel(const DevModel* __rest
         }
         return predict_remaining(M, sqrtf(err2), 0);
     };
-    for (int e = tid; e < n_envs; e += blockDim.x) atomicAdd(&hist[key_of(e)], 1u);
+    constexpr int kKeep = 8;                 // keys of the first 8 envs of a thread stay in registers for the second pass
+    int keys[kKeep];
+#pragma unroll
+    for (int i = 0; i < kKeep; i++) {
+        const int e = tid + i * 1024;
+        keys[i] = e < n_envs ? key_of(e) : 0;
+        if (e < n_envs) atomicAdd(&hist[keys[i]], 1u);
+    }
+    for (int e = tid + kKeep * 1024; e < n_envs; e += 1024) atomicAdd(&hist[key_of(e)], 1u);
     __syncthreads();
     const uint32_t t0 = *sc.head;       // tickets the previous launch's leaving waves took are skipped
     if (tid == 0) {
@@ -1605,12 +1613,17 @@ __global__ __launch_bounds__(1024) void plan_sched_kernel(const DevModel* __rest
     }
     if (tid < kBuckets) sc.waiting[tid] = (int32_t)hist[tid];
     __syncthreads();
-    for (int e = tid; e < n_envs; e += blockDim.x) {
-        const int b = key_of(e);
+    auto enqueue = [&](int e, int b) {
         const uint32_t tk = atomicAdd(&base[b], 1u);
         sc.ent[tk % sc.cap] = ((unsigned long long)tk << 32) | ((unsigned long long)b << 24) | (unsigned long long)(uint32_t)e;
         sc.counter[e] = 0;
+    };
+#pragma unroll
+    for (int i = 0; i < kKeep; i++) {
+        const int e = tid + i * 1024;
+        if (e < n_envs) enqueue(e, keys[i]);
     }
+    for (int e = tid + kKeep * 1024; e < n_envs; e += 1024) enqueue(e, key_of(e));
 }
 
 template <int N>
