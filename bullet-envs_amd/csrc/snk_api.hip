@@ -210,16 +210,10 @@ void snk_default_params(snk_params* p) {
     p->done_penalty = -5.0;
 }
 
-int snk_create(const snk_params* p, int32_t n_envs, int32_t device, snk_handle** out) {
-    if (!p || !out) return fail("snk_create: null argument");
-    if (n_envs <= 0) return fail("snk_create: n_envs must be positive");
-    if (p->n_modules != 16 && p->n_modules != 32) return fail("snk_create: n_modules must be 16 or 32");
-    if (p->term_index < 0 || p->term_index >= 3 * p->n_modules + 8) return fail("snk_create: term_index out of range");
-    int ndev = 0;
-    HIP_TRY(hipGetDeviceCount(&ndev));
-    if (device < 0 || device >= ndev) return fail("snk_create: no such HIP device");
-    HIP_TRY(hipSetDevice(device));
-    snk_handle* h = new snk_handle();
+int snk_destroy(snk_handle* h);
+namespace {
+// everything snk_create allocates; on failure the caller destroys the half-built handle
+int init_handle(snk_handle* h, const snk_params* p, int32_t n_envs, int32_t device) {
     h->P = *p;
     h->n_envs = n_envs;
     h->device = device;
@@ -229,7 +223,7 @@ int snk_create(const snk_params* p, int32_t n_envs, int32_t device, snk_handle**
     h->rec = h->D.rec_floats;
     h->lds_bytes = h->n == 16 ? sizeof(snk::Lds<16, true>) : sizeof(snk::Lds<32, false>);
     int rc = h->n == 16 ? set_lds_attr<16>(h->lds_bytes) : set_lds_attr<32>(h->lds_bytes);
-    if (rc) { delete h; return rc; }
+    if (rc) return rc;
     const size_t ne = (size_t)n_envs;
     HIP_TRY(hipMalloc(&h->d_model, sizeof(snk::DevModel)));
     HIP_TRY(hipMemcpy(h->d_model, &h->D, sizeof(snk::DevModel), hipMemcpyHostToDevice));
@@ -290,8 +284,28 @@ int snk_create(const snk_params* p, int32_t n_envs, int32_t device, snk_handle**
     }
     // hard reset (snake.py:88-95)
     SNK_DISPATCH(h, launch_reset<16>(h, nullptr, nullptr, 1, nullptr), launch_reset<32>(h, nullptr, nullptr, 1, nullptr));
-    if (check_launch()) { return 1; }
+    if (check_launch()) return 1;
     HIP_TRY(hipDeviceSynchronize());
+    return 0;
+}
+}  // namespace
+
+int snk_create(const snk_params* p, int32_t n_envs, int32_t device, snk_handle** out) {
+    if (!p || !out) return fail("snk_create: null argument");
+    if (n_envs <= 0) return fail("snk_create: n_envs must be positive");
+    if (p->n_modules != 16 && p->n_modules != 32) return fail("snk_create: n_modules must be 16 or 32");
+    if (p->term_index < 0 || p->term_index >= 3 * p->n_modules + 8) return fail("snk_create: term_index out of range");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail("snk_create: no such HIP device");
+    HIP_TRY(hipSetDevice(device));
+    snk_handle* h = new snk_handle();
+    const int rc = init_handle(h, p, n_envs, device);
+    if (rc) {
+        const std::string why = snk_last_error();      // snk_destroy's own calls must not overwrite the reason
+        snk_destroy(h);
+        return fail(why);
+    }
     *out = h;
     return 0;
 }
