@@ -1,6 +1,8 @@
 """Dump what a scheduling study of env_step_kernel needs: for the bench workload, per env-step the
 substep count of every env and the servo error the plan kernel sorts by.  Run on the GPU box:
     python tools/balance_dump.py gpurun_out/balance.npz
+tests/golden/bench_substeps.npy (the fixture of tests/test_sched_model.py) is the first four launches of that
+file's `substeps`, stored as int8.
 """
 import importlib, os, sys
 import numpy as np
