@@ -147,13 +147,19 @@ def main():
     E, K, W = args.envs_per_gpu, args.steps, args.warmup
     NL = args.links
     A = NL // 2
+    if os.environ.get("SNK_BENCH_BACKEND", "nccl") != "nccl":
+        local_rank = local_rank % max(1, torch.cuda.device_count())   # rehearsal: the ranks share the GPUs there are
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("SNK_BENCH_BACKEND", "nccl")     # "gloo": functional rehearsal of N ranks on one GPU
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     local = pkg.DeviceVecEnv(E, device_index=local_rank, n_modules=NL)
     env = pkg.ShardedVecEnv(local, root=0, device=dev) if world > 1 else None

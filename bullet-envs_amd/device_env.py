@@ -82,10 +82,13 @@ class ShardedVecEnv(object):
         self.O = local_env.obs_dim
         self.A = local_env.act_dim
         self.num_envs = self.E * self.world
-        self._act = torch.zeros((self.E, self.A), dtype=torch.float32, device=self.device)
+        # The collectives run where the backend can: on the device for "nccl" (RCCL over xGMI), through host
+        # staging for "gloo" (CPU tests; rehearsing a multi-rank run on a box with one GPU).
+        self._xdev = self.device if dist.get_backend(group) == "nccl" else torch.device("cpu")
+        self._act = torch.zeros((self.E, self.A), dtype=torch.float32, device=self._xdev)
         self._pack = torch.zeros((self.E, self.O + 2), dtype=torch.float32, device=self.device)
         if self.rank == root:
-            self._gather = [torch.zeros((self.E, self.O + 2), dtype=torch.float32, device=self.device)
+            self._gather = [torch.zeros((self.E, self.O + 2), dtype=torch.float32, device=self._xdev)
                             for _ in range(self.world)]
         else:
             self._gather = None
@@ -105,10 +108,10 @@ class ShardedVecEnv(object):
             self._pack[:, self.O + 1] = done.to(t.float32)
         else:
             self._pack[:, self.O:] = 0
-        self.dist.gather(self._pack, self._gather, dst=self.root, group=self.group)
+        self.dist.gather(self._pack.to(self._xdev), self._gather, dst=self.root, group=self.group)
         if self.rank != self.root:
             return None
-        return t.cat(self._gather, dim=0)
+        return t.cat(self._gather, dim=0).to(self.device)
 
     def reset(self):
         allp = self._gather_pack(self.env.reset())
@@ -121,12 +124,12 @@ class ShardedVecEnv(object):
             if a.dim() == 3 and a.shape[2] == 1:
                 a = a[:, :, 0]
             assert tuple(a.shape) == (self.num_envs, self.A), a.shape
-            a = a.to(self.device).contiguous()
+            a = a.to(self._xdev).contiguous()
             chunks = [c.contiguous() for c in a.split(self.E, dim=0)]
         else:
             chunks = None
         self.dist.scatter(self._act, chunks, src=self.root, group=self.group)
-        obs, rew, done = self.env.step(self._act)
+        obs, rew, done = self.env.step(self._act.to(self.device))
         allp = self._gather_pack(obs, rew, done)
         if allp is None:
             return None, None, None, ()

@@ -11,6 +11,7 @@ float64 oracle by 2.5e-3 / 0.24 (max) on the same steps, and the test requires t
 be no worse than twice (32-link: three times) that calibration, measured in the same run.  Substep counts and done
 flags must be identical unless the deciding quantity is within 1e-3 of its threshold."""
 import importlib
+import os
 
 import numpy as np
 import pytest
@@ -623,3 +624,26 @@ def test_free_running_gait_aggregates(pkg, oracle_mod):
     assert abs(g[1] - o[1]) < 0.01, (g, o)                 # episode ends per env-step
     assert abs(g[2] - o[2]) < 0.02 * abs(o[2]), (g, o)     # mean reward
     st.close()
+
+
+@pytest.mark.gpu
+def test_bench_multi_rank_rehearsal():
+    """bench.py's N > 1 path (one process per rank, ShardedVecEnv scatter/gather, max-over-ranks timing, rank 0
+    prints the one JSON line), rehearsed with two ranks that share this box's GPU over the gloo backend
+    (SNK_BENCH_BACKEND=gloo: host-staged collectives; the RCCL form of the same calls is covered by
+    test_sharded_env_over_rccl_world1 and runs on the driver's 8-GPU node)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SNK_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--envs-per-gpu", "512"]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 2 and r["scaling"] == "weak" and r["value"] > 0
+    assert r["config"]["envs_per_gpu"] == 512 and r.get("cpu_baseline") is None      # the CPU baseline is an N = 1 leg
