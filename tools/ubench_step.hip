@@ -359,6 +359,58 @@ __device__ __forceinline__ void row_step_cone(float jA, float mA, float jB, floa
     accB = xB;
 }
 
+// ---- prototype: block-wise Gauss-Seidel with in-block residual updates ----
+// One friction pair (rows 2P, 2P+1 of a 16-row block whose running sums sit in lanes 0..15 of `sv`, their
+// accumulated impulses in lanes 0..15 of `av`): no cross-lane reduction -- the sums are read with v_readlane,
+// the pair is projected onto its friction disc, and the block's other sums are brought up to date with one FMA per
+// row (coupling columns AcA / AcB, lane = row; the diagonal carries the -1 of the accumulated impulse).  delta-v
+// is only accumulated (dv2 += RM * dI, A in the lower half, B in the upper; combined once per block).
+template <int P>
+__device__ __forceinline__ void cone_block_step(float& sv, float& av, const float AcA, const float AcB, const float RM,
+                                                float& dv2, float lim, float EPS, unsigned long long lowmask, float& lsq) {
+    float r2, xA, xB, t;
+    float s1, s3, a1, a3;
+    asm volatile(
+        "s_nop 0\n\t"
+        "v_readlane_b32 %[s1], %[sv], %[LA]\n\t"
+        "v_readlane_b32 %[s3], %[sv], %[LB]\n\t"
+        "v_readlane_b32 %[a1], %[sv], %[LA2]\n\t"
+        "v_readlane_b32 %[a3], %[sv], %[LB2]\n\t"
+        "s_nop 0\n\t"
+        "v_mov_b32 %[xA], %[a1]\n\t"
+        "v_mov_b32 %[xB], %[a3]\n\t"
+        "v_fma_f32 %[r2], %[s1], %[s1], %[EPS]\n\t"
+        "v_fma_f32 %[r2], %[s3], %[s3], %[r2]\n\t"
+        "v_rsq_f32 %[r2], %[r2]\n\t"
+        "s_nop 0\n\t"
+        "v_mul_f32_e64 %[r2], %[lim], %[r2] clamp\n\t"
+        "v_fma_f32 %[xA], %[r2], -%[s1], -%[xA]\n\t"      // dI_A = new - old
+        "v_fma_f32 %[xB], %[r2], -%[s3], -%[xB]\n\t"
+        "v_fmac_f32 %[sv], %[AcA], %[xA]\n\t"             // the block's remaining sums (and this row's own, through the diagonal)
+        "v_fmac_f32 %[sv], %[AcB], %[xB]\n\t"
+        "v_cndmask_b32_e64 %[t], %[xB], %[xA], %[lowmask]\n\t"
+        "v_fmac_f32 %[dv2], %[RM], %[t]\n\t"
+        : [r2] "=&v"(r2), [xA] "=&v"(xA), [xB] "=&v"(xB), [t] "=&v"(t), [s1] "=&s"(s1), [s3] "=&s"(s3), [a1] "=&s"(a1),
+          [a3] "=&s"(a3), [sv] "+v"(sv), [dv2] "+v"(dv2)
+        : [av] "v"(av), [AcA] "v"(AcA), [AcB] "v"(AcB), [RM] "v"(RM), [lim] "v"(lim), [EPS] "v"(EPS), [lowmask] "s"(lowmask),
+          [LA] "n"(2 * P), [LB] "n"(2 * P + 1), [LA2] "n"(16 + 2 * P), [LB2] "n"(17 + 2 * P));
+    // the accumulated impulses live in lanes 16..31 of `sv` (the coupling columns carry a 1 there), so the FMAs
+    // above have already updated them; only the residual is left to track
+    asm volatile("v_max3_f32 %[lsq], %[lsq], |%[xA]|, |%[xB]|" : [lsq] "+v"(lsq) : [xA] "v"(xA), [xB] "v"(xB));
+}
+// per block: the 16 running sums from scratch (lane = row): s = sum_k Jc[k] * dv[k], dv[k] broadcast by v_readlane
+template <int K>
+__device__ __forceinline__ void block_dots(float& sv, const float (&Jc)[22], const float dv) {
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        float d;
+        asm volatile("v_readlane_b32 %0, %1, %2" : "=s"(d) : "v"(dv), "n"(k));
+        asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(acc) : "s"(d), "v"(Jc[k]));
+    }
+    sv = acc;
+}
+
 
 }
 using namespace snk;
@@ -370,6 +422,9 @@ __global__ __launch_bounds__(64) void k(float* out, unsigned long long* cyc, flo
 #pragma unroll
     for (int s = 0; s < 8; s++) { RJ[s] = d < 22 ? seed * (s + 1) * 1e-3f * (d + 1) : (d == 31 ? accinit : 0.f); RM[s] = d < 22 ? 1e-4f * (d - s) : 0.f; }
     float dv = d == 22 ? 1.f : 0.f, lsq = 0.f, ACCV = 0.f;
+    float sv = 0.f, av = 0.f, dv2 = 0.f, Jc[22];
+#pragma unroll
+    for (int k = 0; k < 22; k++) Jc[k] = 1e-3f * (k + 1) * (lane + 1) * seed;
     unsigned zz = 0, zb = __builtin_amdgcn_readfirstlane(accinit == 0.f ? 0xffffffffu : 0u);
     const float E = (d == 31) ? 1.f : 0.f, EPS = 1e-30f;
     unsigned long long t0 = now();
@@ -382,11 +437,30 @@ __global__ __launch_bounds__(64) void k(float* out, unsigned long long* cyc, flo
             else if (MODE == 3) cone_z<31, 5>(RJ[s], RM[s], RJ[(s + 1) & 7], dv, EPS, E, kLowMask, lsq, zb);
             else if (MODE == 4) { motor_step<3, false>(RM[s], dv, RJ[s], ACCV, 0.f); }
             else if (MODE == 6) { RJ[s] = row_step_normal(RM[s], RM[(s + 1) & 7], 0.1f, RJ[s], 1.0f, dv, lsq); }
+            else if (MODE == 8) {
+                // one 16-row block = 8 friction pairs: dots once, then 8 in-block steps (s == 0 starts a block)
+                if (s == 0) {
+                    float tmp = dv2, sw = dv2;
+                    asm volatile("s_nop 0\n\tv_permlane32_swap_b32 %0, %1\n\tv_add_f32 %2, %2, %0\n\tv_add_f32 %2, %2, %1" : "+v"(tmp), "+v"(sw), "+v"(dv));
+                    dv2 = 0.f;
+                    block_dots<22>(sv, Jc, dv);
+                }
+                switch (s) {
+                    case 0: cone_block_step<0>(sv, av, RJ[0], RJ[1], RM[0], dv2, 0.5f, EPS, kLowMask, lsq); break;
+                    case 1: cone_block_step<1>(sv, av, RJ[2], RJ[3], RM[1], dv2, 0.5f, EPS, kLowMask, lsq); break;
+                    case 2: cone_block_step<2>(sv, av, RJ[4], RJ[5], RM[2], dv2, 0.5f, EPS, kLowMask, lsq); break;
+                    case 3: cone_block_step<3>(sv, av, RJ[6], RJ[7], RM[3], dv2, 0.5f, EPS, kLowMask, lsq); break;
+                    case 4: cone_block_step<4>(sv, av, RJ[1], RJ[0], RM[4], dv2, 0.5f, EPS, kLowMask, lsq); break;
+                    case 5: cone_block_step<5>(sv, av, RJ[3], RJ[2], RM[5], dv2, 0.5f, EPS, kLowMask, lsq); break;
+                    case 6: cone_block_step<6>(sv, av, RJ[5], RJ[4], RM[6], dv2, 0.5f, EPS, kLowMask, lsq); break;
+                    default: cone_block_step<7>(sv, av, RJ[7], RJ[6], RM[7], dv2, 0.5f, EPS, kLowMask, lsq); break;
+                }
+            }
             else if (MODE == 7) { float aA = RJ[s], aB = RJ[(s + 1) & 7]; row_step_cone(RM[s], RM[(s+2)&7], RM[(s+1)&7], RM[(s+3)&7], 0.1f, 0.2f, aA, aB, 1.f, 1.f, 0.5f, EPS, dv, lsq); RJ[s] = aA; RJ[(s + 1) & 7] = aB; }
         }
     }
     unsigned long long t1 = now();
-    float acc = dv + lsq + ACCV + (float)zz;
+    float acc = dv + lsq + ACCV + (float)zz + sv + av + dv2;
 #pragma unroll
     for (int s = 0; s < 8; s++) acc += RJ[s];
     out[blockIdx.x * 64 + threadIdx.x] = acc;
@@ -418,5 +492,6 @@ int main(int argc, char** argv) {
     if (m < 0 || m == 4) run<4>("motor direct");
     if (m < 0 || m == 6) run<6>("32-link normal row (64-lane)");
     if (m < 0 || m == 7) run<7>("32-link cone pair (64-lane)");
+    if (m < 0 || m == 8) run<8>("block-wise cone pair (prototype)");
     return 0;
 }
