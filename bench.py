@@ -68,49 +68,60 @@ def gait_actions(global_ids, j, A=8):
 # --------------------------------------------------------------------------------------
 # CPU baseline: the oracle (restatement of the reference's CPU path) on the host cores
 # --------------------------------------------------------------------------------------
-def _cpu_worker(job):
-    ids, steps = job
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import oracle as orc
-    envs = [orc.OracleEnv() for _ in ids]
-    for e in envs:
-        e.reset()
-    sub = 0
-    t0 = time.perf_counter()
-    for j in range(steps):
-        acts = gait_actions(np.asarray(ids), j)
-        for i, e in enumerate(envs):
-            _, _, _, k, _ = e.env_step(acts[i], vec_mode=True)
-            sub += k
-    return time.perf_counter() - t0, sub
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
-def cpu_baseline(n_envs=128, steps=10):
-    import multiprocessing as mp
+def env_friction(global_ids, seed):
+    """BASELINE configs[4]: per-env plane friction mu_e ~ U[0.5, 1.5), counter-based, keyed by (seed, global env)."""
+    with np.errstate(over="ignore"):
+        h = splitmix64(np.asarray(global_ids, dtype=np.uint64) * np.uint64(2) + np.uint64(1)
+                       + np.uint64(seed) * np.uint64(0x100000001B3))
+    return 0.5 + (h >> np.uint64(11)).astype(np.float64) / float(1 << 53)
+
+
+def cpu_baseline(steps=2000, warmup=20, n_links=16, friction_seed=None):
+    """BASELINE.md row B3 / SURVEY 8(d): the float64 C++ oracle on the configs[0] action stream, timed from C++
+    (oracle/snake_oracle.cpp: orc_bench_gait -- no Python in the timed loop), 1 thread and all cores, `steps`
+    env-steps after `warmup` warm-up steps each.  PyBullet itself is probed at run time and reported, never
+    substituted silently."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as orc
     import pybullet_live
     orc.build()
-    # probe for a live PyBullet at run time and say what was found, never substitute silently
     have_pb = pybullet_live.available()
-    cores = max(1, min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count(), 16))
-    ids = np.arange(n_envs)
-    jobs = [(ids[c::cores].tolist(), steps) for c in range(cores)]
-    ctx = mp.get_context("fork")          # forked BEFORE this process touches the GPU
-    t0 = time.perf_counter()
-    with ctx.Pool(cores) as pool:
-        res = pool.map(_cpu_worker, jobs)
-    wall = time.perf_counter() - t0
-    busy = max(r[0] for r in res)
-    sub = sum(r[1] for r in res)
+    nproc = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = max(1, nproc)
+    kw = dict(n_modules=n_links)
+
+    def mu_of(ids):
+        return None if friction_seed is None else env_friction(ids, friction_seed)
+    # one thread: env 0 (the canonical gait, phi_0 = 0) for `steps` env-steps
+    sec1, sub1 = orc.bench_gait(1, env_phases([0]), warmup, steps, 1, mu_plane=mu_of([0]), **kw)
+    # all cores: one env per core, the same number of env-steps in total (at least 20 batched steps)
+    per = max(20, -(-steps // cores))
+    ids = np.arange(cores)
+    secN, subN = orc.bench_gait(cores, env_phases(ids), warmup, per, cores, mu_plane=mu_of(ids), **kw)
     return {
-        "value": n_envs * steps / busy, "unit": "env-steps/s", "cores": cores, "kind": "port",
-        "sample": "%d envs x %d env-steps of the same gait workload on the float64 CPU oracle "
-                  "(oracle/, restates PyBullet's pipeline; %s), "
-                  "%d processes, %.1f s wall" % (n_envs, steps,
-                                                 "a PyBullet IS importable on this box: run oracle/pybullet_live.py to pin the oracle against it"
-                                                 if have_pb else "`import pybullet` fails on this box, probed at run time", cores, wall),
-        "substeps_per_s": sub / busy, "mean_substeps": sub / float(n_envs * steps),
+        "value": cores * per / secN, "unit": "env-steps/s", "cores": cores, "kind": "port",
+        "sample": "float64 C++ oracle (oracle/, restates PyBullet's pipeline; %s), gait stream of BASELINE configs[0]%s, "
+                  "timed inside C++ after %d warm-up steps: all cores = %d envs x %d env-steps on %d threads (%.1f s); "
+                  "one thread = env 0 x %d env-steps (%.1f s)" % (
+                      "a PyBullet IS importable on this box: run oracle/pybullet_live.py to pin the oracle against it"
+                      if have_pb else "`import pybullet` fails on this box, probed at run time",
+                      "" if friction_seed is None else ", plane friction U[0.5,1.5) seed %d" % friction_seed,
+                      warmup, cores, per, cores, secN, steps, sec1),
+        "substeps_per_s": subN / secN, "mean_substeps": subN / float(cores * per),
+        "one_thread": {"value": steps / sec1, "unit": "env-steps/s", "cores": 1, "substeps_per_s": sub1 / sec1,
+                       "mean_substeps": sub1 / float(steps), "env_steps": steps, "seconds": sec1},
+        "cpu_model": _cpu_model(), "nproc": nproc, "n_links": n_links,
     }
 
 
@@ -123,6 +134,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--links", type=int, default=N_LINKS, choices=(16, 32),
                     help="32 = BASELINE configs[3] (a parity-test case, not the headline metric)")
+    ap.add_argument("--friction-seed", type=int, default=None,
+                    help="BASELINE configs[4]: per-env ground friction mu_e ~ U[0.5, 1.5), counter-based generator with "
+                         "this seed (the config says seed 1), keyed by the global env index")
+    ap.add_argument("--cpu-steps", type=int, default=2000,
+                    help="env-steps of the CPU baseline (BASELINE.md B3: 2000 after 20 warm-up steps)")
     ap.add_argument("--policy", action="store_true",
                     help="not the BASELINE metric: actions sampled from an on-device 2x256 actor-critic "
                          "(bullet-envs_amd/rollout.py, SURVEY 8(f)-1) instead of the precomputed gait; 1 GPU")
@@ -138,7 +154,8 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline()              # before any GPU initialisation (fork safety)
+        # C++ threads inside this process (no fork): safe before or after GPU initialisation, profiler or not
+        cpu = cpu_baseline(steps=args.cpu_steps, n_links=args.links, friction_seed=args.friction_seed)
 
     import importlib
     import torch
@@ -162,6 +179,8 @@ def main():
             dist.init_process_group(backend)
 
     local = pkg.DeviceVecEnv(E, device_index=local_rank, n_modules=NL)
+    if args.friction_seed is not None:      # configs[4]: this rank's shard of the per-env plane friction
+        local.set_ground_friction(env_friction(np.arange(rank * E, (rank + 1) * E), args.friction_seed).astype(np.float32))
     env = pkg.ShardedVecEnv(local, root=0, device=dev) if world > 1 else None
 
     # actions for every step, resident in HBM on the trainer rank before timing
@@ -246,11 +265,16 @@ def main():
         achieved = alg_bytes_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         # HBM traffic per launch comes from rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 +
         # WRITE_SIZE, calibrated on reset_kernel), run separately and committed under profiles/
+        # rocprofv3 summaries of THIS configuration (profiles/README.md), replayed here -- they are measured in
+        # separate --pmc runs of the same command, not in this run; the key names say so.
+        cfg_key = ("c%d" % NL) + ("_fric" if args.friction_seed is not None else "") + ("_policy" if args.policy else "")
         traffic, traffic_src, valu = None, None, None
         try:
             import glob
-            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_summary.json")))
-            if cands and NL == 16:      # the committed PMC passes are of the headline (16-link) kernel
+            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_pmc_summary.json" % cfg_key)))
+            if not cands and cfg_key == "c16":
+                cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r01_v*_pmc_summary.json")))
+            if cands:
                 with open(cands[-1]) as f:
                     pm = json.load(f)
                 traffic = pm.get("hbm_bytes_per_launch")
@@ -264,9 +288,11 @@ def main():
                     peak = 1024 * 2.4 * 28.0 / 65.0
                     valu = {"wave_insts_per_launch": sq["SQ_INSTS_VALU"], "achieved_G_wave_insts_per_s": rate,
                             "measured_ceiling_G_wave_insts_per_s": peak, "frac": rate / peak,
-                            "valu_active_per_wave": pm.get("derived", {}).get("valu_active_fraction_of_wave_cycles")}
+                            "valu_active_per_wave": pm.get("derived", {}).get("valu_active_fraction_of_wave_cycles"),
+                            "profiled_kernel_ms": pm["kernel_trace_average_ms"]}
         except Exception:  # noqa: BLE001
             pass
+        cfg_index = 3 if NL == 32 else (4 if args.friction_seed is not None else (1 if world == 1 else 2))
         out = {
             "metric": "env-steps/sec (whole node), %d-link snake, 4096 envs/GPU" % NL + (
                 " -- with on-device policy inference (not the BASELINE metric)" if args.policy else ""),
@@ -277,11 +303,15 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": ("%d envs/GPU x %d-link snake, flat ground plane, %s "
-                             "(BASELINE configs[%d])" % (E, NL, "actions sampled from a random-init 2x256 actor-critic on the GPU"
-                                                         if args.policy else "serpenoid gait actions",
-                                                         (1 if world == 1 else 2) if NL == 16 else 3)),
-                "envs_per_gpu": E, "n_links": NL,
+                "workload": ("%d envs/GPU x %d-link snake, %s, %s "
+                             "(BASELINE configs[%d])" % (E, NL,
+                                                         "flat ground plane" if args.friction_seed is None else
+                                                         "ground friction mu_e ~ U[0.5,1.5) seed %d" % args.friction_seed,
+                                                         "actions sampled from a random-init 2x256 actor-critic on the GPU"
+                                                         if args.policy else "serpenoid gait actions", cfg_index)),
+                "envs_per_gpu": E, "n_links": NL, "friction_seed": args.friction_seed,
+                "world_size": (dist.get_world_size() if dist is not None else 1),
+                "backend": (dist.get_backend() if dist is not None else None),
                 "parallelism": "envs sharded over %d GPU(s), no data-path collective; "
                                "RCCL actions scatter + obs/reward/done gather to rank 0" % world
                                if world > 1 else "1 GPU, one wavefront per env",
@@ -291,9 +321,11 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                "traffic_note": "HBM bytes per launch from separate rocprofv3 --pmc passes of this configuration, "
+                                "replayed from the committed summary (not collected in this run)",
                 "kernel": "env_step_sched_kernel<%d> (+ its plan kernel)" % NL, "kernel_ms": kernel_ms, "launches": kcount,
                 "algorithmic_bytes_per_launch": alg_bytes_launch,
-                "valu": valu,
+                "valu_replayed_from_profile": valu,
                 "note": "recurrence-bound path: ~1e3 flop per algorithmic byte; the HBM fraction is "
                         "reported as the contract asks, it is not the limiter (DESIGN.md §5)",
             },

@@ -64,6 +64,8 @@ SYMBOLS = {
     "snk_mean_height": (C.c_int, [_vp, _F]),
     "snk_link_positions": (C.c_int, [_vp, _F]),
     "snk_set_ground_friction": (C.c_int, [_vp, _F]),
+    "snk_get_ground_friction": (C.c_int, [_vp, _F]),
+    "snk_debug_set_tickets": (C.c_int, [_vp, C.c_uint32]),
     "snk_selftest": (C.c_int, [C.c_int32]),
     "snk_timing_enable": (C.c_int, [_vp, C.c_int32]),
     "snk_timing_read": (C.c_int, [_vp, _D, _I32]),
@@ -224,7 +226,15 @@ class Stepper:
         m = np.ascontiguousarray(mu, dtype=np.float32)
         assert m.shape == (self.n_envs,)
         check(self.lib.snk_set_ground_friction(self.h, fptr(m)), "snk_set_ground_friction")
-        self.ground_friction = m.copy()      # kept for checkpoint.save_state
+
+    def get_ground_friction(self):
+        """The effective per-env plane friction (ones unless set), read back from the device."""
+        m = np.zeros(self.n_envs, dtype=np.float32)
+        check(self.lib.snk_get_ground_friction(self.h, fptr(m)), "snk_get_ground_friction")
+        return m
+
+    def debug_set_tickets(self, base):
+        check(self.lib.snk_debug_set_tickets(self.h, int(base) & 0xFFFFFFFF), "snk_debug_set_tickets")
 
     def model_describe(self):
         bodies = np.zeros((self.n + 1, 10))

@@ -5,6 +5,7 @@ a PyBullet world cannot be resumed mid-rollout.  Here the whole simulator state 
 environments is the per-env record (`snk_get_state`): pose, velocities, joint state, last
 motor torques, joint-0 force, previous x for the reward -- plus the per-env plane friction and
 the model parameters it was produced with.  Restoring it continues bit-for-bit.
+`save_state` / `load_state` synchronise the device (the state accessors of the C ABI do).
 """
 import numpy as np
 
@@ -20,10 +21,10 @@ def save_state(env, path):
     """env: Stepper, SnakeVecEnv or DeviceVecEnv.  Writes one .npz."""
     st = _stepper(env)
     state, aux = st.get_state()
-    mu = getattr(st, "ground_friction", None)
+    # the EFFECTIVE friction, read back from the device (also covers values set through the C ABI directly)
     np.savez_compressed(path, state=state, aux=aux, n_envs=np.int64(st.n_envs),
                         params=np.frombuffer(bytes(st.params), dtype=np.uint8),
-                        ground_friction=np.zeros(0, np.float32) if mu is None else np.asarray(mu, np.float32))
+                        ground_friction=st.get_ground_friction())
 
 
 def load_state(env, path):
@@ -34,6 +35,7 @@ def load_state(env, path):
             raise ValueError("checkpoint holds %d environments, this handle %d" % (int(z["n_envs"]), st.n_envs))
         if z["params"].tobytes() != bytes(st.params):
             raise ValueError("checkpoint was written with different model parameters")
-        if z["ground_friction"].size:
-            st.set_ground_friction(z["ground_friction"])
+        mu = z["ground_friction"]
+        # always restored: a checkpoint of a default-friction world must also undo the target's custom friction
+        st.set_ground_friction(mu if mu.size else np.ones(st.n_envs, np.float32))
         st.set_state(z["state"], z["aux"])

@@ -258,7 +258,8 @@ int init_handle(snk_handle* h, const snk_params* p, int32_t n_envs, int32_t devi
             HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(snk::g_models), &h->D, sizeof(snk::DevModel),
                                       (size_t)h->model_slot * sizeof(snk::DevModel), hipMemcpyHostToDevice));
         snk::Sched& sc = h->sched;
-        sc.cap = 2u * (uint32_t)n_envs;
+        sc.cap = 2u;                                  // power of two >= 2 n_envs: slot = ticket & (cap - 1) survives the
+        while (sc.cap < 2u * (uint32_t)n_envs) sc.cap <<= 1;      // wrap-around of the 32-bit tickets
         sc.quantum = quantum;
         HIP_TRY(hipMalloc(&sc.head, sizeof(uint32_t)));
         HIP_TRY(hipMalloc(&sc.tail, sizeof(uint32_t)));
@@ -293,6 +294,7 @@ int init_handle(snk_handle* h, const snk_params* p, int32_t n_envs, int32_t devi
 int snk_create(const snk_params* p, int32_t n_envs, int32_t device, snk_handle** out) {
     if (!p || !out) return fail("snk_create: null argument");
     if (n_envs <= 0) return fail("snk_create: n_envs must be positive");
+    if (n_envs >= (1 << 24)) return fail("snk_create: n_envs must be below 2^24 (the step queue packs the env index into 24 bits)");
     if (p->n_modules != 16 && p->n_modules != 32) return fail("snk_create: n_modules must be 16 or 32");
     if (p->term_index < 0 || p->term_index >= 3 * p->n_modules + 8) return fail("snk_create: term_index out of range");
     int ndev = 0;
@@ -443,6 +445,7 @@ int snk_substep_host(snk_handle* h, const float* targets, int32_t k, int32_t* in
 int snk_get_state(snk_handle* h, float* state, float* aux) {
     if (!h) return fail("snk_get_state: null handle");
     HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipDeviceSynchronize());      // a step enqueued on a non-blocking stream may still be running
     const size_t ne = (size_t)h->n_envs;
     std::vector<float> recs(ne * h->rec);
     HIP_TRY(hipMemcpy(recs.data(), h->d_recs, recs.size() * sizeof(float), hipMemcpyDeviceToHost));
@@ -457,6 +460,7 @@ int snk_get_state(snk_handle* h, float* state, float* aux) {
 int snk_set_state(snk_handle* h, const float* state, const float* aux) {
     if (!h) return fail("snk_set_state: null handle");
     HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipDeviceSynchronize());      // a step enqueued on a non-blocking stream may still be running
     const size_t ne = (size_t)h->n_envs;
     std::vector<float> recs(ne * h->rec);
     HIP_TRY(hipMemcpy(recs.data(), h->d_recs, recs.size() * sizeof(float), hipMemcpyDeviceToHost));
@@ -472,6 +476,7 @@ int snk_set_state(snk_handle* h, const float* state, const float* aux) {
 int snk_get_obs(snk_handle* h, float* obs) {
     if (!h || !obs) return fail("snk_get_obs: null argument");
     HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipDeviceSynchronize());      // a step enqueued on a non-blocking stream may still be running
     SNK_DISPATCH(h, launch_obs<16>(h, h->d_obs, nullptr, nullptr), launch_obs<32>(h, h->d_obs, nullptr, nullptr));
     if (check_launch()) return 1;
     HIP_TRY(hipDeviceSynchronize());
@@ -482,6 +487,7 @@ int snk_get_obs(snk_handle* h, float* obs) {
 int snk_mean_height(snk_handle* h, float* out) {
     if (!h || !out) return fail("snk_mean_height: null argument");
     HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipDeviceSynchronize());      // a step enqueued on a non-blocking stream may still be running
     SNK_DISPATCH(h, launch_obs<16>(h, nullptr, h->d_h, nullptr), launch_obs<32>(h, nullptr, h->d_h, nullptr));
     if (check_launch()) return 1;
     HIP_TRY(hipDeviceSynchronize());
@@ -492,6 +498,7 @@ int snk_mean_height(snk_handle* h, float* out) {
 int snk_link_positions(snk_handle* h, float* out) {
     if (!h || !out) return fail("snk_link_positions: null argument");
     HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipDeviceSynchronize());      // a step enqueued on a non-blocking stream may still be running
     const size_t bytes = (size_t)h->n_envs * 3 * (h->n + 1) * sizeof(float);
     if (!h->d_linkpos) HIP_TRY(hipMalloc(&h->d_linkpos, bytes));
     SNK_DISPATCH(h, launch_obs<16>(h, nullptr, nullptr, nullptr, h->d_linkpos),
@@ -505,7 +512,25 @@ int snk_link_positions(snk_handle* h, float* out) {
 int snk_set_ground_friction(snk_handle* h, const float* mu) {
     if (!h || !mu) return fail("snk_set_ground_friction: null argument");
     HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipDeviceSynchronize());      // a step enqueued on a non-blocking stream may still be running
     HIP_TRY(hipMemcpy(h->d_mu, mu, (size_t)h->n_envs * sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int snk_get_ground_friction(snk_handle* h, float* mu) {
+    if (!h || !mu) return fail("snk_get_ground_friction: null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(mu, h->d_mu, (size_t)h->n_envs * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int snk_debug_set_tickets(snk_handle* h, uint32_t base) {
+    if (!h) return fail("snk_debug_set_tickets: null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(h->sched.head, &base, sizeof(base), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->sched.tail, &base, sizeof(base), hipMemcpyHostToDevice));
     return 0;
 }
 

@@ -1450,9 +1450,9 @@ __global__ __launch_bounds__(1024) void plan_kernel(const DevModel* __restrict__
 //
 // Queue: one ring of {ticket, remaining, env} entries.  A pop is ONE returning atomic add on
 // `head` (a ticket), then a wait for that ticket's entry; a push is one atomic add on `tail` and
-// one 8-byte agent-scope store.  (A compare-and-swap pop costs O(G^2) attempts when G waves reach
+// one 8-byte agent-scope store (the slot is a tagged granule, read back with a returning atomic: sched_pop).  (A compare-and-swap pop costs O(G^2) attempts when G waves reach
 // a slice boundary together: 14 ms per launch, measured.)  Tickets are never reset; unsigned
-// wrap-around is harmless.  Pops in excess of pushes wait for an entry that may never come; they
+// wrap-around is harmless because the ring size is a power of two (tests preset head/tail just below 2^32).  Pops in excess of pushes wait for an entry that may never come; they
 // leave when `finished` says every env-step is complete, and the next launch starts its tickets at
 // `head`.  waiting[r] counts queued env-steps with r substeps left (the carry-on test).
 // The record hand-off between waves follows MI355X_MICROARCH.md "inter-workgroup visibility":
@@ -1482,7 +1482,8 @@ struct Sched {
     int32_t* counter;           // [n_envs] substeps done so far in this env-step
     int32_t* finished;          // env-steps completed in this launch
     int32_t* alarm;             // host-mapped: set when a bounded wait ran out
-    uint32_t cap;               // ring size (2 n_envs: an env is queued at most once)
+    uint32_t cap;               // ring size: a power of two >= 2 n_envs (an env is queued at most once), so that the
+                                // slot of a ticket, tk & (cap - 1), stays consistent when the 32-bit tickets wrap
     int32_t quantum;            // substeps per slice
     long long* wstat;           // SNK_SCHED_DEBUG: [grid][4] ticks waiting, ticks alive, slices, substeps
 };
@@ -1514,10 +1515,17 @@ __device__ __forceinline__ void sched_alarm(const Sched& sc, int lane) {
 }
 
 // next env for this wave, or -1 when every env-step of the launch is complete (or on alarm).
-// The wait is a 4-byte sc1 poll of `tail` (a word only atomic adds touch: the form the guide lists as
-// observed cross-XCD); the entry itself is then read with returning atomics, which execute at the
-// memory side -- an 8-byte sc1 LOAD that polled the slot before it was written kept returning the
-// old value (a hang, round 1).
+// Two waits.  (1) `tail` -- a word only agent-scope atomic adds touch -- is polled with a 4-byte sc1 load until
+// ticket tk has been issued (MI355X_MICROARCH.md, hand-off table, row 3: "agent-scope atomic adds ... a
+// global_load_dword sc1 poll of that counter").  (2) A producer takes its ticket BEFORE it stores the entry
+// (sched_push), so the slot may still hold the entry of ticket tk - cap: the slot is a tagged 8-byte granule
+// {ticket, remaining|env} and is re-read until the tag matches.  That re-read is a RETURNING ATOMIC (an add of a
+// zero the compiler cannot see through): it executes where agent-scope atomics execute, beyond the per-XCD L2s,
+// so no cached copy of the slot -- in this CU's L1 or in this XCD's L2 -- can answer it.  (Round 1 read the slot
+// with `__hip_atomic_load`, i.e. `global_load_dwordx2 sc1`, which is served by the XCD's own L2; the guide lists
+// that as observed-fresh for granules, not as guaranteed, and its row 3 excludes dwordx2 loads outright.  The one
+// hang on record, gpurun_out/d3000.log, predates the first committed scheduler and had the lane-threaded back edge
+// described below as its cause; the atomic read removes the remaining reliance on an observed behaviour.)
 __device__ __forceinline__ int sched_pop(const Sched& sc, int lane, int n_envs) {
     // NO `if (lane == 0)` around the queue operations of this file: with a lane-dependent branch at the top of the
     // scheduling loop the compiler threads the loop's back edge per lane, lane 0 and lanes 1..63 then run the loop
@@ -1544,9 +1552,12 @@ __device__ __forceinline__ int sched_pop(const Sched& sc, int lane, int n_envs) 
         for (int i = 0; i < nap; i++) __builtin_amdgcn_s_sleep(16);      // ~0.5 us, backing off to ~7 us
         if (nap < 16) nap++;
     }
-    unsigned long long* e = sc.ent + (tk % sc.cap);
+    unsigned long long* e = sc.ent + (tk & (sc.cap - 1u));
+    unsigned long long zero = 0ull;
+    asm volatile("" : "+v"(zero));      // opaque: an add of a literal 0 would be folded into a plain atomic load
     for (;;) {
-        const unsigned long long v = __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // every lane adds 0 to the same slot (the atomic optimizer folds the 64 into one memory operation)
+        const unsigned long long v = __hip_atomic_fetch_add(e, zero, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
         const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
         if (hi == tk) {
@@ -1565,7 +1576,7 @@ __device__ __forceinline__ void sched_push(const Sched& sc, int lane, int env, i
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the write-through stores have left before the entry does
     atomicAdd(&sc.waiting[remaining], lane == 0 ? 1 : 0);
     const uint32_t tk = (uint32_t)__builtin_amdgcn_readfirstlane((int)atomicAdd(sc.tail, lane == 0 ? 1u : 0u));
-    __hip_atomic_store(sc.ent + (tk % sc.cap),        // every lane stores the same 8 bytes
+    __hip_atomic_store(sc.ent + (tk & (sc.cap - 1u)),        // every lane stores the same 8 bytes
                        ((unsigned long long)tk << 32) | ((unsigned long long)remaining << 24) |
                            (unsigned long long)(uint32_t)env,
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1615,7 +1626,7 @@ __global__ __launch_bounds__(1024) void plan_sched_kernel(const DevModel* __rest
     __syncthreads();
     auto enqueue = [&](int e, int b) {
         const uint32_t tk = atomicAdd(&base[b], 1u);
-        sc.ent[tk % sc.cap] = ((unsigned long long)tk << 32) | ((unsigned long long)b << 24) | (unsigned long long)(uint32_t)e;
+        sc.ent[tk & (sc.cap - 1u)] = ((unsigned long long)tk << 32) | ((unsigned long long)b << 24) | (unsigned long long)(uint32_t)e;
         sc.counter[e] = 0;
     };
 #pragma unroll

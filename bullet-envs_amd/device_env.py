@@ -82,14 +82,18 @@ class ShardedVecEnv(object):
         self.O = local_env.obs_dim
         self.A = local_env.act_dim
         self.num_envs = self.E * self.world
+        self.backend = dist.get_backend(group)
         # The collectives run where the backend can: on the device for "nccl" (RCCL over xGMI), through host
         # staging for "gloo" (CPU tests; rehearsing a multi-rank run on a box with one GPU).
         self._xdev = self.device if dist.get_backend(group) == "nccl" else torch.device("cpu")
         self._act = torch.zeros((self.E, self.A), dtype=torch.float32, device=self._xdev)
         self._pack = torch.zeros((self.E, self.O + 2), dtype=torch.float32, device=self.device)
         if self.rank == root:
-            self._gather = [torch.zeros((self.E, self.O + 2), dtype=torch.float32, device=self._xdev)
-                            for _ in range(self.world)]
+            # one preallocated [world * E, O + 2] buffer; the gather writes each rank's block into its slice
+            self._all = torch.zeros((self.num_envs, self.O + 2), dtype=torch.float32, device=self._xdev)
+            self._gather = list(self._all.split(self.E, dim=0))
+            self._all_dev = self._all if self._xdev == self.device else torch.zeros_like(self._all, device=self.device)
+            self._act_all = torch.zeros((self.num_envs, self.A), dtype=torch.float32, device=self._xdev)
         else:
             self._gather = None
 
@@ -111,25 +115,34 @@ class ShardedVecEnv(object):
         self.dist.gather(self._pack.to(self._xdev), self._gather, dst=self.root, group=self.group)
         if self.rank != self.root:
             return None
-        return t.cat(self._gather, dim=0).to(self.device)
+        if self._all_dev is not self._all:
+            self._all_dev.copy_(self._all)
+        return self._all_dev
 
     def reset(self):
         allp = self._gather_pack(self.env.reset())
         return None if allp is None else allp[:, :self.O]
 
     def step(self, actions=None):
+        """The root's `actions` (tensor or ndarray [world * E, A] or [.., A, 1]) are clipped to [-1, 1] IN PLACE, as
+        checkBound does to the caller's array (SnakeGymEnv.py:82-88): the step kernels clip the scattered copies,
+        and the root applies the same clamp to the caller's own buffer."""
         t = self.torch
         if self.rank == self.root:
-            a = t.as_tensor(actions, dtype=t.float32)
-            if a.dim() == 3 and a.shape[2] == 1:
-                a = a[:, :, 0]
-            assert tuple(a.shape) == (self.num_envs, self.A), a.shape
-            a = a.to(self._xdev).contiguous()
-            chunks = [c.contiguous() for c in a.split(self.E, dim=0)]
+            a = t.as_tensor(actions, dtype=t.float32)       # shares memory with a float32 ndarray / tensor
+            a2 = a[:, :, 0] if (a.dim() == 3 and a.shape[2] == 1) else a
+            assert tuple(a2.shape) == (self.num_envs, self.A), a2.shape
+            self._act_all.copy_(a2)
+            chunks = list(self._act_all.split(self.E, dim=0))
         else:
+            a2 = None
             chunks = None
         self.dist.scatter(self._act, chunks, src=self.root, group=self.group)
         obs, rew, done = self.env.step(self._act.to(self.device))
+        if a2 is not None:
+            a2.clamp_(-1.0, 1.0)
+            if isinstance(actions, np.ndarray) and actions.dtype != np.float32:
+                np.clip(actions, -1.0, 1.0, out=actions)
         allp = self._gather_pack(obs, rew, done)
         if allp is None:
             return None, None, None, ()

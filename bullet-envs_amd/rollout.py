@@ -9,8 +9,8 @@ Here the same loop runs with every tensor resident on the GPU that owns the envi
     buf   = RolloutBuffer(num_steps, env.num_envs, 56, 8, env.device)
     state = env.reset().clone()
     state = collect(env, net, state, buf)                      # ppo/train.py:110-140
-    returns = compute_gae(net(state)[1], buf.rewards, buf.masks, buf.values)   # ppo/agent.py:14-22
-    ppo_update(net, opt, 4, 5, *buf.flat(returns))             # ppo/agent.py:24-57
+    ... the trainer's own GAE / PPO update on buf.flat(returns) (ppo/agent.py; host-side caller code, out of
+    scope here -- tools/ppo_trainer_math.py keeps a restatement for the tests and the demo loop) ...
 
 `env` is a DeviceVecEnv (one GPU) or, with one process per GPU, each rank's own DeviceVecEnv:
 every rank runs the policy on its shard and only gradients cross GPUs
@@ -125,21 +125,6 @@ def collect(envs, net, state, buf, generator=None):
     return state
 
 
-def compute_gae(next_value, rewards, masks, values, gamma=0.99, tau=0.95):
-    """Generalised advantage estimation (ppo/agent.py:14-22) on stacked [T, N, 1] tensors;
-    returns `returns` [T, N, 1] (= advantage + value)."""
-    T = rewards.shape[0]
-    returns = torch.empty_like(rewards)
-    gae = torch.zeros_like(next_value)
-    nxt = next_value
-    for step in reversed(range(T)):
-        delta = rewards[step] + gamma * nxt * masks[step] - values[step]
-        gae = delta + gamma * tau * masks[step] * gae
-        returns[step] = gae + values[step]
-        nxt = values[step]
-    return returns
-
-
 def allreduce_gradients(net, group=None):
     """Average the gradients over the ranks (one process per GPU, RCCL): the only exchange of the
     training loop when every rank steps its own shard with its own copy of the policy."""
@@ -156,36 +141,3 @@ def allreduce_gradients(net, group=None):
         n = g.numel()
         g.copy_(flat[o:o + n].view_as(g))
         o += n
-
-
-def ppo_update(net, optimizer, ppo_epochs, mini_batch_size, states, actions, log_probs, returns, advantages,
-               clip_param=0.2, grad_sync=None):
-    """Clipped-surrogate PPO update (ppo/agent.py:24-57).  Minibatch indices come from
-    np.random.randint(0, batch, mini) -- with replacement, like the reference -- and
-    batch // mini minibatches are drawn per epoch.  grad_sync: callable(net) run between
-    backward() and step() (e.g. allreduce_gradients).  Returns the mean losses the reference logs."""
-    batch_size = states.size(0)
-    n_mb = batch_size // mini_batch_size
-    tot = dict(loss=0.0, actor_loss=0.0, critic_loss=0.0, entropy=0.0)
-    for _ in range(ppo_epochs):
-        for _ in range(n_mb):
-            ids = torch.as_tensor(np.random.randint(0, batch_size, mini_batch_size), device=states.device)
-            state, action = states[ids, :], actions[ids, :]
-            old_log_probs, return_, advantage = log_probs[ids, :], returns[ids, :], advantages[ids, :]
-            dist, value = net(state)
-            entropy = dist.entropy().mean()
-            ratio = (dist.log_prob(action) - old_log_probs).exp()
-            surr1 = ratio * advantage
-            surr2 = torch.clamp(ratio, 1.0 - clip_param, 1.0 + clip_param) * advantage
-            actor_loss = -torch.min(surr1, surr2).mean()
-            critic_loss = (return_ - value).pow(2).mean()
-            loss = 0.5 * critic_loss + actor_loss - 0.001 * entropy
-            optimizer.zero_grad()
-            loss.backward()
-            if grad_sync is not None:
-                grad_sync(net)
-            optimizer.step()
-            tot["loss"] += loss.item(); tot["actor_loss"] += actor_loss.item()
-            tot["critic_loss"] += critic_loss.item(); tot["entropy"] += entropy.item()
-    denom = ppo_epochs * (batch_size / float(mini_batch_size))
-    return {k: v / denom for k, v in tot.items()}

@@ -199,15 +199,17 @@ class SnakeGymEnv(object):
             self._scratch = _lib.Stepper(1, device=self._stepper.device, params=self.params)
         sc = self._scratch
         sc.set_state(before[0], before[1])
-        n = r.numMotors
-        targets = np.zeros((1, n), dtype=np.float32)      # createAction + convertActionToJointCommand
-        if self._gaitSelection == 0:
+        n = self.params.n_modules
+        # createAction + convertActionToJointCommand with the gait and scale the DEVICE uses (self.params: they
+        # may have been overridden through **over, which the robot facade does not see)
+        targets = np.zeros((1, n), dtype=np.float32)
+        if self.params.gait == 0:
             targets[0, 0::2] = clipped_action
-        elif self._gaitSelection == 1:
+        elif self.params.gait == 1:
             targets[0, 1::2] = clipped_action
         else:
             targets[0, :] = clipped_action
-        targets *= np.float32(r.SCALING_FACTOR)
+        targets *= np.float32(self.params.scaling_factor)
         for _ in range(n_substeps):
             sc.substep(targets, 1)
             r.step_internal_observations.append(sc.get_obs()[0].astype(np.float64))

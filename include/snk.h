@@ -24,7 +24,7 @@ extern "C" {
  * knowledge of bullet3 (not verifiable here). */
 typedef struct snk_params {
     /* model: snake/snake.urdf (constants generated parametrically, not parsed) */
-    int32_t n_modules;          /* 16 = snake.urdf; 32 = BASELINE config 4 (8 <= n <= 32, even) */
+    int32_t n_modules;          /* 16 = snake.urdf; 32 = BASELINE config 4 (only these two)      */
     int32_t inertia_from_file;  /* 0: inertia from collision AABB [U] (snake.py:93 passes no
                                    URDF_USE_INERTIA_FROM_FILE); 1: urdf:815,871 values       */
     double  default_mass;       /* links without <inertial> (urdf:7,14,818): mass 1 [U]       */
@@ -119,7 +119,9 @@ int snk_step_host(snk_handle* h, float* actions, float* obs, float* rew, uint8_t
  * For single-substep parity tests. */
 int snk_substep_host(snk_handle* h, const float* targets, int32_t k, int32_t* info);
 
-/* State access (host buffers), for parity tests and checkpointing.
+/* State access (host buffers), for parity tests and checkpointing.  These calls (and snk_get_obs,
+ * snk_mean_height, snk_link_positions, snk_set/get_ground_friction) synchronise the device first, so a step
+ * still running on any stream is complete before the records are read or overwritten.
  * state [n_envs x state_dim]; aux [n_envs x (n+2)] = motor torques n, joint-0 Fz, prev obs x. */
 int snk_get_state(snk_handle* h, float* state, float* aux);
 int snk_set_state(snk_handle* h, const float* state, const float* aux);
@@ -134,6 +136,11 @@ int snk_link_positions(snk_handle* h, float* out);
 
 /* BASELINE config 5: per-env lateral friction of the ground plane (reference: plane.urdf = 1). */
 int snk_set_ground_friction(snk_handle* h, const float* mu /* host [n_envs] */);
+int snk_get_ground_friction(snk_handle* h, float* mu /* host [n_envs] */);
+
+/* Test hook: sets the step queue's ticket counters (in-launch scheduling) to `base`, so that a test
+ * can put the wrap-around of the 32-bit tickets inside its next step.  Results never depend on it. */
+int snk_debug_set_tickets(snk_handle* h, uint32_t base);
 
 /* Device-side self test of the wave primitives (DPP reductions); 0 = pass. */
 int snk_selftest(int32_t device);

@@ -27,10 +27,14 @@
  */
 #include "snake_oracle.h"
 
+#include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #ifndef ORC_REAL
@@ -1208,6 +1212,65 @@ int32_t orc_last_normal_impulses(const orc_env* e, double* out, int32_t maxc) {
     int nc = (int)e->last_normal_impulse.size();
     for (int i = 0; i < nc && i < maxc; i++) out[i] = e->last_normal_impulse[i];
     return nc;
+}
+
+/* CPU-baseline driver (bench.py's cpu_baseline leg): n_envs environments step the
+ * "serpenoid gait" action stream a[e,j,k] = -sin((2k+1) 4 + 2 (0.1 j) + phase_e) (snake_gait_test.py:65-67,86;
+ * SURVEY.md 8(d)) for warmup + steps batched env-steps with the worker's auto-reset, on n_threads threads
+ * (static partition of the envs, one barrier per batched step like SubprocVecEnv.step_wait,
+ * ppo/multiprocessing_env.py:125).  No Python in the timed loop.  Returns the wall time of the `steps` timed
+ * batched steps in seconds; *substeps_out = physics substeps executed in them. */
+double orc_bench_gait(const orc_params* p, int32_t n_envs, const double* phases, const double* mu_plane_or_null,
+                      int32_t warmup, int32_t steps, int32_t n_threads, int64_t* substeps_out) {
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > n_envs) n_threads = n_envs;
+    std::vector<orc_env*> envs(n_envs);
+    for (int e = 0; e < n_envs; e++) {
+        envs[e] = orc_create(p);
+        if (mu_plane_or_null) orc_set_plane_friction(envs[e], mu_plane_or_null[e]);
+        orc_reset(envs[e], nullptr);
+    }
+    const int n = p->n_modules;
+    const int A = (p->gait == 0 || p->gait == 1) ? n / 2 : n;
+    const int O = 3 * n + 8;
+    std::mutex mtx;
+    std::condition_variable cv;
+    int arrived = 0, generation = 0;
+    auto barrier = [&]() {
+        std::unique_lock<std::mutex> lk(mtx);
+        const int gen = generation;
+        if (++arrived == n_threads) { arrived = 0; generation++; cv.notify_all(); }
+        else cv.wait(lk, [&] { return generation != gen; });
+    };
+    std::vector<int64_t> sub(n_threads, 0);
+    std::chrono::steady_clock::time_point t0, t1;
+    auto worker = [&](int t) {
+        std::vector<double> act(A), obs(O);
+        for (int j = 0; j < warmup + steps; j++) {
+            if (j == warmup) {
+                barrier();
+                if (t == 0) t0 = std::chrono::steady_clock::now();
+            }
+            for (int e = t; e < n_envs; e += n_threads) {
+                for (int k = 0; k < A; k++) act[k] = -std::sin((2 * k + 1) * 4.0 + 2.0 * (0.1 * j) + phases[e]);
+                double rew;
+                int32_t done, cnt;
+                orc_env_step(envs[e], act.data(), 1, obs.data(), &rew, &done, &cnt);
+                if (j >= warmup) sub[t] += cnt;
+            }
+            barrier();
+        }
+        if (t == 0) t1 = std::chrono::steady_clock::now();
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < n_threads; t++) th.emplace_back(worker, t);
+    worker(0);
+    for (auto& x : th) x.join();
+    int64_t total = 0;
+    for (int t = 0; t < n_threads; t++) total += sub[t];
+    if (substeps_out) *substeps_out = total;
+    for (int e = 0; e < n_envs; e++) orc_destroy(envs[e]);
+    return std::chrono::duration<double>(t1 - t0).count();
 }
 
 }  // extern "C"

@@ -135,6 +135,13 @@ int32_t  orc_contacts(orc_env* e, double* out, int32_t max_contacts);
 /* impulses of the last substep: normal impulses per contact */
 int32_t  orc_last_normal_impulses(const orc_env* e, double* out, int32_t max_contacts);
 
+/* CPU-baseline driver for bench.py: n_envs envs x (warmup + steps) batched env-steps of the
+ * serpenoid-gait stream on n_threads threads, timed inside (no Python in the loop).  Returns seconds for the
+ * `steps` timed batched steps; *substeps_out = physics substeps executed in them. */
+double   orc_bench_gait(const orc_params* p, int32_t n_envs, const double* phases,
+                        const double* mu_plane_or_null, int32_t warmup, int32_t steps,
+                        int32_t n_threads, int64_t* substeps_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -105,3 +105,43 @@ def test_ars_step_on_device(pkg):
     torch.cuda.synchronize()
     assert float(nz.n[0]) == 3 * n and torch.isfinite(tot).all() and torch.isfinite(state).all()
     env.close()
+
+
+@pytest.mark.gpu
+def test_ars_normalizer_and_policy_on_device_match_reference_vectors(pkg):
+    """The vectors generated from the reference's own Normalizer / policy definitions (tests/golden/make_ars_vectors.py),
+    with the statistics, observations and weights on cuda:0 in float64: the batched cumulative-sum form of the
+    reference's sequential Welford loop must agree there as it does on the CPU (1e-9)."""
+    dev = torch.device("cuda", 0)
+    g = np.load(GOLD)
+    nz = pkg.ars.Normalizer([1, 56], device=dev)
+    for step in range(3):
+        Y = nz.observe_normalize(torch.tensor(g["X%d" % step], device=dev))
+        assert Y.is_cuda
+        assert np.allclose(Y.cpu().numpy(), g["Y%d" % step], rtol=1e-9, atol=1e-10)
+        for k in ("n", "mean", "mean_diff", "var"):
+            assert np.allclose(getattr(nz, k).cpu().numpy(), g["%s%d" % (k, step)], rtol=1e-9, atol=1e-11), (k, step)
+    act = pkg.ars.policy(torch.tensor(g["Y2"], device=dev), torch.tensor(g["W"], device=dev))
+    assert act.is_cuda and act.shape == (6, 8, 1)
+    assert np.allclose(act.cpu().numpy(), g["actions"], rtol=1e-9, atol=1e-11)
+
+
+@pytest.mark.gpu
+def test_checkpoint_restores_default_friction_too(pkg, tmp_path):
+    """A checkpoint of a default-friction world, loaded into a handle that carries custom friction, must undo that
+    friction as well (the effective friction is always saved and always restored)."""
+    from bench import gait_actions
+    n = 64
+    a_env = pkg.SnakeVecEnv(n)
+    a_env.reset()
+    a_env.step(gait_actions(np.arange(n), 0).astype(np.float32))
+    path = str(tmp_path / "ck0.npz")
+    pkg.save_state(a_env, path)
+    ref = a_env.step(gait_actions(np.arange(n), 1).astype(np.float32))
+    b_env = pkg.SnakeVecEnv(n)
+    b_env.set_ground_friction(np.full(n, 0.4, np.float32))
+    pkg.load_state(b_env, path)
+    assert np.all(b_env._stepper.get_ground_friction() == 1.0)
+    got = b_env.step(gait_actions(np.arange(n), 1).astype(np.float32))
+    assert np.array_equal(ref[0], got[0]) and np.array_equal(ref[1], got[1])
+    a_env.close(); b_env.close()

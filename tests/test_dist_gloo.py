@@ -41,7 +41,8 @@ class OracleLocalEnv:
 
 def _actions(j, n):
     k = np.arange(8)
-    return (-np.sin((2 * k[None, :] + 1) * 4.0 + 0.2 * j + 0.7 * np.arange(n)[:, None])).astype(np.float32)
+    a = (-np.sin((2 * k[None, :] + 1) * 4.0 + 0.2 * j + 0.7 * np.arange(n)[:, None])).astype(np.float32)
+    return a * np.float32(1.5) if j == 1 else a       # step 1 leaves the [-1, 1] box: checkBound must clip it
 
 
 def _worker(rank, world, port, out_path):
@@ -62,8 +63,11 @@ def _worker(rank, world, port, out_path):
     else:
         assert obs0 is None
     for j in range(STEPS):
-        out = env.step(_actions(j, world * E) if rank == 0 else None)
+        acts = _actions(j, world * E) if rank == 0 else None
+        out = env.step(acts)
         if rank == 0:
+            # the caller's array is clipped in place (SnakeGymEnv.py:82-88), on every shard's rows
+            assert np.array_equal(acts, np.clip(_actions(j, world * E), -1, 1))
             obs, rew, done, infos = out
             assert len(infos) == world * E and obs.shape == (world * E, 56)
             res["obs%d" % j] = obs.numpy().copy()

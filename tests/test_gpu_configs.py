@@ -1,0 +1,179 @@
+"""GPU tests of BASELINE.json configs[3] (4096 x 32-link) and configs[4] (per-env ground friction
+mu_e ~ U[0.5, 1.5), seed 1) AS CONFIGURED: the env-step path (snk_step_host, i.e. servo loop, reward,
+termination, auto-reset), not the substep API, and the scheduler's ticket wrap-around.
+
+Tolerances (configs[4]): GPU float32 against the float64 oracle over one env-step from a synchronised state, judged
+against the float32 BUILD OF THE ORACLE on the very same step (liboracle32.so): stick-slip states at mu_e > 1.25
+(link friction 2 x plane > 2.5) amplify float32 round-off by orders of magnitude, in the oracle exactly as on the
+GPU, so the bound on each error statistic is `factor x the float32 oracle's statistic + floor`, per friction band --
+the high-friction envs are judged, not excluded.  Floors: joint angles / base pose 5e-4, relative joint velocity
+5e-3, reward 2e-3; factors 2 (median, 90th percentile) and 3 (maximum)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _stats(x):
+    x = np.asarray(x, dtype=np.float64)
+    return float(np.percentile(x, 50)), float(np.percentile(x, 90)), float(x.max())
+
+
+def test_c5_env_step_parity_friction_config(pkg, oracle_mod):
+    import bench
+    n, B, J = 16, 32, 6
+    ids = np.arange(B)
+    mu = bench.env_friction(ids, 1)                      # the config's distribution: U[0.5, 1.5), seed 1
+    assert mu.min() >= 0.5 and mu.max() < 1.5 and (mu > 1.25).sum() >= 4 and (mu < 0.8).sum() >= 4
+    st = pkg.Stepper(B)
+    st.set_ground_friction(mu.astype(np.float32))
+    st.reset()
+    mu32 = st.get_ground_friction().astype(np.float64)   # what the device really holds (float32)
+    refs, refs32 = [], []
+    for i in range(B):
+        e, e32 = oracle_mod.OracleEnv(), oracle_mod.OracleEnv(f32=True)
+        e.set_plane_friction(mu32[i]); e32.set_plane_friction(mu32[i])
+        refs.append(e); refs32.append(e32)
+    err = {b: dict(q=[], qd=[], r=[]) for b in ("low", "high")}
+    cal = {b: dict(q=[], qd=[], r=[]) for b in ("low", "high")}
+    mism = 0
+    dones = 0
+    for j in range(J):
+        S, X = st.get_state()
+        a = bench.gait_actions(ids, j).astype(np.float32)
+        obs, rew, done, sub = st.step(a.copy(), vec_mode=True)
+        dones += int(done.sum())
+        for i in range(B):
+            band = "high" if mu32[i] > 1.25 else "low"
+            out = []
+            for e in (refs[i], refs32[i]):
+                e.set_state(S[i].astype(np.float64))
+                e.set_aux(X[i, :n].astype(np.float64), float(X[i, n]), float(X[i, n + 1]))
+                out.append(e.env_step(a[i].astype(np.float64), vec_mode=True))
+            (o, r, d, k, _), (o32, r32, d32, k32, _) = out
+
+            def errs(oo, rr):
+                q = max(np.abs(oo[:n] - o[:n]).max(), np.abs(oo[3 * n:3 * n + 7] - o[3 * n:3 * n + 7]).max())
+                qd = (np.abs(oo[n:2 * n] - o[n:2 * n]) / (1 + np.abs(o[n:2 * n]))).max()
+                return q, qd, abs(rr - r)
+            if k32 == k and d32 == d:
+                for key, v in zip(("q", "qd", "r"), errs(o32, r32)):
+                    cal[band][key].append(v)
+            if k != sub[i] or d != bool(done[i]):
+                mism += 1
+                assert abs(k - sub[i]) <= 1, (i, j, k, sub[i], d, done[i], mu32[i])
+                continue
+            for key, v in zip(("q", "qd", "r"), errs(obs[i].astype(np.float64), float(rew[i]))):
+                err[band][key].append(v)
+    floors = dict(q=5e-4, qd=5e-3, r=2e-3)
+    for band in ("low", "high"):
+        assert len(err[band]["q"]) >= 20, (band, len(err[band]["q"]))
+        for key in ("q", "qd", "r"):
+            g50, g90, gmx = _stats(err[band][key])
+            c50, c90, cmx = _stats(cal[band][key])
+            print("configs[4] band %-4s %-2s GPU-f32 p50 %.2e p90 %.2e max %.2e | oracle-f32 p50 %.2e p90 %.2e max %.2e"
+                  % (band, key, g50, g90, gmx, c50, c90, cmx))
+            assert g50 <= 2 * c50 + floors[key], (band, key, g50, c50)
+            assert g90 <= 2 * c90 + floors[key], (band, key, g90, c90)
+            assert gmx <= 3 * cmx + 10 * floors[key], (band, key, gmx, cmx)
+    assert mism <= max(1, B * J // 20), mism
+    assert dones > 0            # resets happened under varied friction inside the compared steps
+    st.close()
+
+
+def test_c5_friction_changes_the_rollout_and_matches_oracle_aggregates(pkg, oracle_mod):
+    """Free-running (no resynchronisation) configs[4] rollout, 32 envs x 30 env-steps, auto-reset on: what a trainer
+    sees -- mean substeps, episode ends, mean reward, net x displacement -- against the float64 oracle."""
+    import bench
+    B, T = 32, 30
+    ids = np.arange(B)
+    mu = bench.env_friction(ids, 1).astype(np.float32)
+    st = pkg.Stepper(B)
+    st.set_ground_friction(mu)
+    st.reset()
+    refs = [oracle_mod.OracleEnv() for _ in range(B)]
+    for i, r in enumerate(refs):
+        r.set_plane_friction(float(mu[i]))
+        r.reset()
+    g = np.zeros(3)
+    o = np.zeros(3)
+    for j in range(T):
+        a = bench.gait_actions(ids, j)
+        _, r, d, s = st.step(a.astype(np.float32))
+        g += [s.sum(), d.sum(), r.sum()]
+        for i in range(B):
+            _, rr, rd, rk, _ = refs[i].env_step(a[i].copy(), vec_mode=True)
+            o += [rk, int(rd), rr]
+    g /= B * T
+    o /= B * T
+    print("configs[4] free-running aggregates GPU", g, "oracle", o)
+    assert abs(g[0] - o[0]) < 0.02 * o[0], (g, o)
+    assert abs(g[1] - o[1]) < 0.02, (g, o)
+    assert abs(g[2] - o[2]) < 0.05 * abs(o[2]) + 0.01, (g, o)
+    st.close()
+
+
+def test_c4_full_size_properties(pkg):
+    """4096 envs x 32 links (BASELINE configs[3]) at full size: bitwise determinism between two handles, finite
+    outputs, unit quaternions, reward / reset invariants, and independence of an env from its batch."""
+    import bench
+    B, n, A = 4096, 32, 16
+    O = 3 * n + 8
+    a_envs = pkg.Stepper(B, n_modules=n)
+    b_envs = pkg.Stepper(B, n_modules=n)
+    a_envs.reset(); b_envs.reset()
+    ids = np.arange(B)
+    acts = [bench.gait_actions(ids, j, A).astype(np.float32) for j in range(3)]
+    keep = []
+    for j in range(3):
+        oa, ra, da, sa = a_envs.step(acts[j].copy())
+        ob, rb, db, sb = b_envs.step(acts[j].copy())
+        assert oa.shape == (B, O)
+        assert np.array_equal(oa, ob) and np.array_equal(ra, rb) and np.array_equal(da, db) and np.array_equal(sa, sb)
+        assert np.all(np.isfinite(oa)) and np.all(np.isfinite(ra))
+        assert sa.min() >= 0 and sa.max() <= 41
+        assert np.all(ra[da] < -4.0) and np.all(np.abs(ra[~da]) < 4.0)
+        assert np.allclose(np.linalg.norm(oa[:, 3 * n + 3:3 * n + 7], axis=1), 1.0, atol=1e-5)
+        assert np.all(oa[da][:, :2 * n] == 0)
+        keep.append((oa, ra, sa))
+    assert sum(k[2].sum() for k in keep) > 0
+    b_envs.close()
+    pick = [0, 1, 777, 2048, 4095]
+    small = pkg.Stepper(len(pick), n_modules=n)
+    small.reset()
+    for j in range(2):
+        o_s, r_s, d_s, s_s = small.step(acts[j][pick].copy())
+        assert np.array_equal(keep[j][0][pick], o_s) and np.array_equal(keep[j][1][pick], r_s)
+        assert np.array_equal(keep[j][2][pick], s_s)
+    small.close(); a_envs.close()
+
+
+@pytest.mark.parametrize("n,B", [(16, 1536), (32, 384)])
+def test_scheduler_ticket_wraparound(pkg, monkeypatch, n, B):
+    """The step queue's 32-bit tickets are never reset.  With the counters preset just below 2^32 the wrap falls
+    inside the first step's hand-offs; n_envs = 1536 / 384 are sizes whose doubled value is not a power of two (the
+    ring is rounded up to one, so slot = ticket & (cap - 1) stays consistent across the wrap).  Results must match
+    the unscheduled kernel (SNK_QUANTUM=0) bit for bit, and the handle must stay healthy."""
+    A = n // 2
+    k = np.arange(A)
+    acts = [(-np.sin((2 * k[None, :] + 1) * 4.0 + 0.2 * j + 0.37 * np.arange(B)[:, None])).astype(np.float32)
+            for j in range(3)]
+
+    def run(quantum, base):
+        monkeypatch.setenv("SNK_QUANTUM", str(quantum))
+        st = pkg.Stepper(B, n_modules=n)
+        st.reset()
+        if base is not None:
+            st.debug_set_tickets(base)
+        outs = [tuple(x.copy() for x in st.step(a.copy())) for a in acts]
+        st.close()
+        return outs
+
+    ref = run(0, None)
+    for base in (0xFFFFFF00, 0xFFFFFFFF - B):
+        got = run(1, base)
+        for g, w in zip(got, ref):
+            for x, y in zip(g, w):
+                assert np.array_equal(x, y)
+    with pytest.raises(RuntimeError):
+        pkg.Stepper(1 << 24)

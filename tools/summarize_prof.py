@@ -1,46 +1,73 @@
 """Turns a gpurun_out/profN directory (rocprofv3 kernel trace + separate PMC passes of
 bench.py) into the summaries committed under profiles/.  Usage:
-    python tools/summarize_prof.py gpurun_out/prof4 r01_v3 [kernel name, default env_step_sched_kernel<16>]"""
-import collections, csv, glob, json, os, shutil, sys
-src, tag = sys.argv[1], sys.argv[2]
-def one(pattern):
+    python tools/summarize_prof.py gpurun_out/prof_c32 r02_c32 --links 32 --round 2 \
+        --workload "4096 envs x 32-link snake, serpenoid gait" --command "python3 bench.py --links 32 ..."
+The tag's middle part is the configuration key bench.py looks for (profiles/r*_<key>_pmc_summary.json):
+c16, c32, c16_fric.  Expects SRC/trace, SRC/pmc_fetch, SRC/pmc_write and (optionally) SRC/pmc_sq."""
+import argparse, collections, csv, glob, json, os, shutil
+
+ap = argparse.ArgumentParser()
+ap.add_argument("src")
+ap.add_argument("tag")
+ap.add_argument("--links", type=int, default=16)
+ap.add_argument("--round", type=int, default=2)
+ap.add_argument("--kernel", default=None, help="default env_step_sched_kernel<LINKS>")
+ap.add_argument("--workload", default="4096 envs x 16-link snake, serpenoid gait")
+ap.add_argument("--command", default="python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline")
+ap.add_argument("--skip", type=int, default=2, help="leading launches left out of the per-launch means (warm-up)")
+a = ap.parse_args()
+src, tag, N = a.src, a.tag, a.links
+K = a.kernel or 'env_step_sched_kernel<%d>' % N
+RK = 'reset_kernel<%d>' % N
+
+
+def one(pattern, required=True):
     g = glob.glob(os.path.join(src, pattern))
-    assert g, pattern
-    return g[0]
+    assert g or not required, pattern
+    return g[0] if g else None
+
+
 def agg(path, kern):
     d = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
         if kern in r['Kernel_Name']:
             d[r['Counter_Name']].append(float(r['Counter_Value']))
     return d
-K = sys.argv[3] if len(sys.argv) > 3 else 'env_step_sched_kernel<16>'   # sets up to r01_v6: env_step_kernel<16>
+
+
 stats = one('trace/*/*kernel_stats.csv')
 shutil.copy(stats, 'profiles/%s_kernel_stats.csv' % tag)
 kavg = None
 for r in csv.DictReader(open(stats)):
     if K in r['Name']:
         kavg = float(r['AverageNs']) * 1e-6
-f = agg(one('pmc_fetch/*/*counter_collection.csv'), K); w = agg(one('pmc_write/*/*counter_collection.csv'), K)
-q = agg(one('pmc_sq/*/*counter_collection.csv'), K)
-fr = agg(one('pmc_fetch/*/*counter_collection.csv'), 'reset_kernel<16>'); wr = agg(one('pmc_write/*/*counter_collection.csv'), 'reset_kernel<16>')
-fs, ws = f['FETCH_SIZE'][2:], w['WRITE_SIZE'][2:]
+fpath, wpath = one('pmc_fetch/*/*counter_collection.csv'), one('pmc_write/*/*counter_collection.csv')
+f, w = agg(fpath, K), agg(wpath, K)
+fr, wr = agg(fpath, RK), agg(wpath, RK)
+fs, ws = f['FETCH_SIZE'][a.skip:], w['WRITE_SIZE'][a.skip:]
 fetch_kb, write_kb = sum(fs) / len(fs), sum(ws) / len(ws)
-sq = {k: sum(v[2:]) / len(v[2:]) for k, v in q.items()}
+rec_kb = 4096 * (256 if N == 16 else 512) / 1024.0
 out = {
-    "round": 1, "tag": tag, "kernel": "snk::" + K,
-    "workload": "4096 envs x 16-link snake, serpenoid gait (bench.py --steps 10 --warmup 2 --no-cpu-baseline)",
-    "command": "rocprofv3 --pmc <counters> --output-format csv -- python3 bench.py ...  (FETCH_SIZE, WRITE_SIZE and the SQ set in separate passes; kernel trace in its own pass)",
+    "round": a.round, "tag": tag, "kernel": "snk::" + K,
+    "workload": a.workload,
+    "command": "rocprofv3 --pmc <counters> --output-format csv -- %s  (FETCH_SIZE, WRITE_SIZE and the SQ set in "
+               "separate passes; kernel trace in its own pass)" % a.command,
     "kernel_trace_average_ms": kavg,
-    "calibration": {"kernel": "snk::reset_kernel<16>", "known_read_KB": 1024.0, "FETCH_SIZE_KB": fr['FETCH_SIZE'],
-                    "known_write_KB": [1024.0, 1920.0], "WRITE_SIZE_KB": wr['WRITE_SIZE'],
-                    "conclusion": "FETCH_SIZE reads 1/2 of the bytes of this 4-B-per-lane coalesced record load (gfx950 rule of MI355X_MICROARCH.md); WRITE_SIZE exact"},
+    "calibration": {"kernel": "snk::" + RK, "known_read_KB": rec_kb, "FETCH_SIZE_KB": fr['FETCH_SIZE'],
+                    "known_write_KB_record_only": rec_kb, "WRITE_SIZE_KB": wr['WRITE_SIZE'],
+                    "conclusion": "FETCH_SIZE reads 1/2 of the bytes of this 4-B-per-lane coalesced record load "
+                                  "(gfx950 rule of MI355X_MICROARCH.md); WRITE_SIZE exact"},
     "FETCH_SIZE_KB_per_launch": fetch_kb, "WRITE_SIZE_KB_per_launch": write_kb,
     "hbm_bytes_per_launch": (2 * fetch_kb + write_kb) * 1024,
-    "sq_per_launch": sq,
-    "derived": {"valu_insts_per_wave": sq['SQ_INSTS_VALU'] / sq['SQ_WAVES'],
-                "valu_active_fraction_of_wave_cycles": sq['SQ_ACTIVE_INST_VALU'] / sq['SQ_WAVE_CYCLES'],
-                "mean_wave_residency_fraction_of_kernel": (sq['SQ_WAVE_CYCLES'] * 4 / sq['SQ_WAVES']) / (sq['GRBM_GUI_ACTIVE'] / 8),
-                "clock_GHz_from_GRBM": sq['GRBM_GUI_ACTIVE'] / 8 / (kavg * 1e-3) / 1e9 if kavg else None},
 }
+qpath = one('pmc_sq/*/*counter_collection.csv', required=False)
+if qpath:
+    q = agg(qpath, K)
+    sq = {k: sum(v[a.skip:]) / len(v[a.skip:]) for k, v in q.items()}
+    out["sq_per_launch"] = sq
+    out["derived"] = {"valu_insts_per_wave": sq['SQ_INSTS_VALU'] / sq['SQ_WAVES'],
+                      "valu_active_fraction_of_wave_cycles": sq['SQ_ACTIVE_INST_VALU'] / sq['SQ_WAVE_CYCLES'],
+                      "mean_wave_residency_fraction_of_kernel": (sq['SQ_WAVE_CYCLES'] * 4 / sq['SQ_WAVES']) / (sq['GRBM_GUI_ACTIVE'] / 8),
+                      "clock_GHz_from_GRBM": sq['GRBM_GUI_ACTIVE'] / 8 / (kavg * 1e-3) / 1e9 if kavg else None}
 json.dump(out, open('profiles/%s_pmc_summary.json' % tag, 'w'), indent=1)
-print(json.dumps({k: out[k] for k in ("kernel_trace_average_ms", "hbm_bytes_per_launch", "derived")}, indent=1))
+print(json.dumps({k: out.get(k) for k in ("kernel_trace_average_ms", "hbm_bytes_per_launch", "derived")}, indent=1))
