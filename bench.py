@@ -98,7 +98,19 @@ def cpu_baseline(steps=2000, warmup=20, n_links=16, friction_seed=None):
     orc.build()
     have_pb = pybullet_live.available()
     nproc = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cores = max(1, nproc)
+    # "all cores" = the cores this process may actually use: the affinity mask, cut down to the cgroup's CPU quota
+    # where there is one (a 1-GPU box of the pool exposes all 256 hardware threads of the host but grants a share)
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()[:2]
+            if q != "max":
+                quota = max(1, int(float(q) / float(per) + 0.5))
+    except (OSError, ValueError):
+        pass
+    cores = max(1, min(nproc, quota) if quota else nproc)
+    if quota is None and nproc > 64:
+        cores = 64          # no quota visible: one thread per physical core of a 64-core socket at most
     kw = dict(n_modules=n_links)
 
     def mu_of(ids):
@@ -121,7 +133,7 @@ def cpu_baseline(steps=2000, warmup=20, n_links=16, friction_seed=None):
         "substeps_per_s": subN / secN, "mean_substeps": subN / float(cores * per),
         "one_thread": {"value": steps / sec1, "unit": "env-steps/s", "cores": 1, "substeps_per_s": sub1 / sec1,
                        "mean_substeps": sub1 / float(steps), "env_steps": steps, "seconds": sec1},
-        "cpu_model": _cpu_model(), "nproc": nproc, "n_links": n_links,
+        "cpu_model": _cpu_model(), "nproc": nproc, "cgroup_cpu_quota": quota, "n_links": n_links,
     }
 
 

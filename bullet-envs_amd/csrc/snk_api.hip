@@ -175,6 +175,8 @@ void snk_default_params(snk_params* p) {
     p->inertia_from_file = 0;
     p->default_mass = 1.0;
     p->collision_margin = 0.001;
+    p->hull_sides = 0;
+    p->contact_model = 0;
     p->dt = 1.0 / 240.0;
     p->gravity_z = -9.8;
     p->lin_damping = 0.04;
@@ -296,6 +298,8 @@ int snk_create(const snk_params* p, int32_t n_envs, int32_t device, snk_handle**
     if (n_envs <= 0) return fail("snk_create: n_envs must be positive");
     if (n_envs >= (1 << 24)) return fail("snk_create: n_envs must be below 2^24 (the step queue packs the env index into 24 bits)");
     if (p->n_modules != 16 && p->n_modules != 32) return fail("snk_create: n_modules must be 16 or 32");
+    if (p->hull_sides < 0 || p->hull_sides > 32) return fail("snk_create: hull_sides must be 0 (implicit cylinder) .. 32");
+    if (p->contact_model != 0 && p->contact_model != 1) return fail("snk_create: contact_model must be 0 or 1");
     if (p->term_index < 0 || p->term_index >= 3 * p->n_modules + 8) return fail("snk_create: term_index out of range");
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));

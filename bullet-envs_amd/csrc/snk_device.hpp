@@ -178,6 +178,7 @@ struct Lds<N, true> : LdsCommon<N> {
     float stM[64][25];           // staging of one 64-row batch: M^-1 J^T [22], rhs, den, 1/den
     float MmS[N][4];             // the motors' rhs, den, 1/den, target velocity change (their M^-1 rows are Mm)
     float fz_park;               // first-pass part of the joint-0 force, parked across the solve
+    int cylbase[2 * N], cyln[2 * N];   // contacts of cylinder c: compact indices [cylbase[c], + cyln[c])
     float app[2 * (N / 2 + NC / 2 + NC)];   // accumulated impulses by (register slot, half)
 };
 

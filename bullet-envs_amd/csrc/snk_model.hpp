@@ -52,6 +52,12 @@ struct DevModel {
     int cyl_body[kMaxCyl];
     float cyl_c[kMaxCyl][3];   // centre in body frame
     float cyl_R[kMaxCyl][9];   // cylinder link frame -> body frame
+    // contact model: hull_sides > 0 = the prism PyBullet imports a URDF <cylinder> as [U]; hull_xy[s] =
+    // r (sin, cos)(2 pi s / hull_sides), the importer's vertex order; contact_model 1 = persistent manifold;
+    // cyl_zoff = cylinder centre in its link's frame (snake.urdf:807,863), the manifold keeps link coordinates
+    int hull_sides, contact_model;
+    float cyl_zoff;
+    float hull_xy[32][2];
     // sensors
     float m_root;
     float zbase[3];   // z axis of the `base` link in body-0 frame (joint-0 force component)
@@ -212,6 +218,13 @@ inline void build_dev_model(const snk_params& P, const HostModel& H, DevModel& D
     D.contact_erp = (float)P.contact_erp; D.slop = (float)P.linear_slop;
     D.break_thr = (float)P.breaking_threshold; D.margin = (float)P.collision_margin;
     D.cyl_r = 0.026f; D.cyl_hl = 0.0165f;                               // snake.urdf:809
+    D.hull_sides = P.hull_sides; D.contact_model = P.contact_model;
+    D.cyl_zoff = 0.0183f;                                               // snake.urdf:807,863
+    for (int s = 0; s < P.hull_sides && s < 32; s++) {
+        const double th = 2.0 * 3.14159265358979323846 * s / P.hull_sides;
+        D.hull_xy[s][0] = (float)(0.026 * sin(th));
+        D.hull_xy[s][1] = (float)(0.026 * cos(th));
+    }
     D.resid_thr = (float)P.residual_threshold;
     D.n_iter = P.n_iterations; D.cone = P.cone_friction;
     D.scaling = (float)P.scaling_factor; D.servo_tol = (float)P.servo_tol;

@@ -78,27 +78,262 @@ __device__ __forceinline__ float rdlane(float x, int l) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l));
 }
 // ------------------------------------------------------------------------------------
-// contacts of the current pose, written at their COMPACT index (same geometry as v1)
+// contacts of the current pose, written at their COMPACT index.
+//
+// Two contact models, selected per handle (DevModel::contact_model):
+//   0  stateless: lane = slot (cylinder slot/2, end cap slot&1); each end cap contributes the lowest point of its
+//      rim -- of the implicit cylinder, or of the hull_sides-gon PyBullet imports a URDF <cylinder> as [U] --
+//      when closer than the breaking threshold;
+//   1  Bullet's persistent manifold [U] (btConvexPlaneCollisionAlgorithm + btPersistentManifold), lane = cylinder:
+//      one new support point per step merged into a cache of <= 4 points that lives in global memory
+//      (manifold_update below); every cached point gets rows.
+// Both leave the same description behind: contact ci = 0..nc-1 in (cylinder, point) order with L.ccP / ccdist /
+// ccbody / ccdir, and per cylinder the range [L.cylbase[c], + L.cyln[c]) of its contacts (the sensor pass sums a
+// body's contact forces over the ranges of its cylinders).  At most 4 N contacts get rows (the register-resident
+// solve has that many slots): further manifold points are left out, in manifold order.
 // ------------------------------------------------------------------------------------
-template <class LT>
-__device__ int find_contacts_v2(LT& L, const DevModel& M, int lane, unsigned long long& active_slots) {
-    constexpr int N = LT::kN;
-    static_assert(4 * N == 64, "one contact slot per lane");
-    const int slot = lane;
-    const int c = slot >> 1;
-    const int b = (c + 1) >> 1;
-    const float* Rb = L.R[b];
-    const float* Rc = M.cyl_R[c];
-    float Rw[9];
+// lowest rim point (x, y in the cylinder's frame) towards dl = world "down" in that frame
+__device__ __forceinline__ void rim_point(const DevModel& M, f3 dl, float& lx, float& ly) {
+    lx = 0.f; ly = 0.f;
+    if (M.hull_sides > 0) {
+        float best = -3.0e38f;
+        for (int s = 0; s < M.hull_sides; s++) {          // first maximum, the importer's vertex order
+            const float vx = M.hull_xy[s][0], vy = M.hull_xy[s][1];
+            const float val = dl.x * vx + dl.y * vy;
+            if (val > best) { best = val; lx = vx; ly = vy; }
+        }
+    } else {
+        const float rr = sqrtf(dl.x * dl.x + dl.y * dl.y);
+        if (rr > 1e-12f) { lx = M.cyl_r * dl.x / rr; ly = M.cyl_r * dl.y / rr; }
+    }
+}
+// world rotation of cylinder c's frame
+__device__ __forceinline__ void cyl_world_rot(const float* Rb, const float* Rc, float* Rw) {
 #pragma unroll
     for (int i = 0; i < 3; i++)
 #pragma unroll
         for (int j = 0; j < 3; j++)
             Rw[3 * i + j] = Rb[3 * i] * Rc[j] + Rb[3 * i + 1] * Rc[3 + j] + Rb[3 * i + 2] * Rc[6 + j];
+}
+// friction directions (0,-1,0), (1,0,0) scaled anisotropically in the link's axes: d' = Rw diag(aniso) Rw^T d
+__device__ __forceinline__ void friction_dirs(const DevModel& M, const float* Rw, f3& dA, f3& dB) {
+    const f3 a = mk3(M.aniso[0], M.aniso[1], M.aniso[2]);
+    const f3 l1 = mulRtv(Rw, mk3(0.f, -1.f, 0.f));
+    const f3 l2 = mulRtv(Rw, mk3(1.f, 0.f, 0.f));
+    dA = mulRv(Rw, mk3(l1.x * a.x, l1.y * a.y, l1.z * a.z));
+    dB = mulRv(Rw, mk3(l2.x * a.x, l2.y * a.y, l2.z * a.z));
+}
+
+// One cached manifold point: the point on the link in the LINK's coordinates (cylinder frame + cyl_zoff along z),
+// the point on the ground in world coordinates, the refreshed distance.
+struct MPt {
+    f3 a, b;
+    float d;
+};
+typedef float mf_v4 __attribute__((ext_vector_type(4)));
+constexpr int kMfFloats = 28;      // per cylinder: [count, 3 pad, 4 x (a3, b3)]
+
+// btPersistentManifold::sortCachedPoints with gContactCalcArea3Points [U]: which cached point the new one replaces
+__device__ __forceinline__ int manifold_sort_cached(const MPt (&p)[4], const MPt& np) {
+    int mpi = -1;
+    float mp = np.d;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        if (p[i].d < mp) { mpi = i; mp = p[i].d; }
+    auto area = [](f3 a1, f3 a0, f3 b1, f3 b0) { const f3 c = cross(a1 - a0, b1 - b0); return dot(c, c); };
+    float res[4] = {0.f, 0.f, 0.f, 0.f};
+    if (mpi != 0) res[0] = area(np.a, p[1].a, p[3].a, p[2].a);
+    if (mpi != 1) res[1] = area(np.a, p[0].a, p[3].a, p[2].a);
+    if (mpi != 2) res[2] = area(np.a, p[0].a, p[3].a, p[1].a);
+    if (mpi != 3) res[3] = area(np.a, p[0].a, p[2].a, p[1].a);
+    int best = 0;
+    float bv = fabsf(res[0]);
+#pragma unroll
+    for (int i = 1; i < 4; i++)
+        if (fabsf(res[i]) > bv) { bv = fabsf(res[i]); best = i; }
+    return best;
+}
+
+// The manifold of this lane's cylinder, updated for the current pose (see the oracle's find_contacts_manifold for the
+// Bullet calls restated).  mfc -> the cylinder's kMfFloats floats in global memory, read and written write-through
+// (sc1): an env-step moves between waves at substep boundaries, and the bytes must be where the next wave's loads
+// look (same rule as the state record, store_rec_through).  Returns the number of cached points; their world
+// positions on the link and distances in wa / p[].d.
+__device__ __forceinline__ int manifold_update(const DevModel& M, float* __restrict__ mfc, const float* Rw, f3 centre, f3 dl,
+                                               MPt (&p)[4], f3 (&wa)[4]) {
+    mf_v4 v[7];
+    asm volatile(
+        "global_load_dwordx4 %0, %7, off sc1\n\t"
+        "global_load_dwordx4 %1, %7, off offset:16 sc1\n\t"
+        "global_load_dwordx4 %2, %7, off offset:32 sc1\n\t"
+        "global_load_dwordx4 %3, %7, off offset:48 sc1\n\t"
+        "global_load_dwordx4 %4, %7, off offset:64 sc1\n\t"
+        "global_load_dwordx4 %5, %7, off offset:80 sc1\n\t"
+        "global_load_dwordx4 %6, %7, off offset:96 sc1\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6])
+        : "v"(mfc)
+        : "memory");
+    float f[kMfFloats];
+#pragma unroll
+    for (int i = 0; i < 7; i++) { f[4 * i] = v[i].x; f[4 * i + 1] = v[i].y; f[4 * i + 2] = v[i].z; f[4 * i + 3] = v[i].w; }
+    int n = (int)f[0];
+    n = n < 0 ? 0 : (n > 4 ? 4 : n);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        p[j].a = mk3(f[4 + 6 * j], f[5 + 6 * j], f[6 + 6 * j]);
+        p[j].b = mk3(f[7 + 6 * j], f[8 + 6 * j], f[9 + 6 * j]);
+        p[j].d = 0.f;
+    }
+    const float thr = M.break_thr;
+    // the new point: support vertex towards the plane (+ margin along that direction)
+    f3 sv;
+    if (M.hull_sides > 0) {
+        float best = -3.0e38f;
+        sv = mk3(0.f, 0.f, 0.f);
+        for (int k = 0; k < 2 * M.hull_sides; k++) {      // the importer's order: (+z, -z) of vertex 0, 1, ...
+            const f3 c = mk3(M.hull_xy[k >> 1][0], M.hull_xy[k >> 1][1], (k & 1) ? -M.cyl_hl : M.cyl_hl);
+            const float val = dot(dl, c);
+            if (val > best) { best = val; sv = c; }
+        }
+    } else {                                              // btCylinderShapeZ's support function [U]
+        const float rr = sqrtf(dl.x * dl.x + dl.y * dl.y);
+        sv = rr != 0.f ? mk3(M.cyl_r * dl.x / rr, M.cyl_r * dl.y / rr, 0.f) : mk3(M.cyl_r, 0.f, 0.f);
+        sv.z = dl.z < 0.f ? -M.cyl_hl : M.cyl_hl;
+    }
+    const f3 zoff = mk3(0.f, 0.f, M.cyl_zoff);
+    MPt np;
+    const f3 loc = sv + dl * M.margin;                    // in the cylinder's own (centred) frame
+    np.a = loc + zoff;
+    const f3 wnew = centre + mulRv(Rw, loc);
+    np.d = wnew.z;
+    np.b = mk3(wnew.x, wnew.y, 0.f);
+    if (np.d < thr) {
+        int nearest = -1;
+        float shortest = thr * thr;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const f3 d = p[j].a - np.a;
+            const float dd = dot(d, d);
+            if (j < n && dd < shortest) { shortest = dd; nearest = j; }
+        }
+        int where = nearest;
+        if (where < 0) {
+            if (n < 4) where = n++;
+            else where = manifold_sort_cached(p, np);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (j == where) p[j] = np;
+    }
+    // refresh from the current pose, then drop what lifted off or drifted (last to first, the last one moves in)
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        wa[j] = centre + mulRv(Rw, p[j].a - zoff);
+        p[j].d = wa[j].z - p[j].b.z;
+    }
+#pragma unroll
+    for (int j = 3; j >= 0; j--) {
+        if (j < n) {
+            bool drop = !(p[j].d <= thr);
+            if (!drop) {
+                const float dx = p[j].b.x - wa[j].x, dy = p[j].b.y - wa[j].y, dz = p[j].b.z - (wa[j].z - p[j].d);
+                drop = dx * dx + dy * dy + dz * dz > thr * thr;
+            }
+            if (drop) {
+                const int last = n - 1;
+                MPt pl = p[0];
+                f3 wl = wa[0];
+#pragma unroll
+                for (int k = 1; k < 4; k++)
+                    if (k == last) { pl = p[k]; wl = wa[k]; }
+                if (j != last) { p[j] = pl; wa[j] = wl; }
+                n--;
+            }
+        }
+    }
+    // back to memory
+    f[0] = (float)n; f[1] = 0.f; f[2] = 0.f; f[3] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        f[4 + 6 * j] = p[j].a.x; f[5 + 6 * j] = p[j].a.y; f[6 + 6 * j] = p[j].a.z;
+        f[7 + 6 * j] = p[j].b.x; f[8 + 6 * j] = p[j].b.y; f[9 + 6 * j] = p[j].b.z;
+    }
+#pragma unroll
+    for (int i = 0; i < 7; i++) { v[i].x = f[4 * i]; v[i].y = f[4 * i + 1]; v[i].z = f[4 * i + 2]; v[i].w = f[4 * i + 3]; }
+    asm volatile(
+        "global_store_dwordx4 %7, %0, off sc1\n\t"
+        "global_store_dwordx4 %7, %1, off offset:16 sc1\n\t"
+        "global_store_dwordx4 %7, %2, off offset:32 sc1\n\t"
+        "global_store_dwordx4 %7, %3, off offset:48 sc1\n\t"
+        "global_store_dwordx4 %7, %4, off offset:64 sc1\n\t"
+        "global_store_dwordx4 %7, %5, off offset:80 sc1\n\t"
+        "global_store_dwordx4 %7, %6, off offset:96 sc1"
+        :
+        : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(mfc)
+        : "memory");
+    return n;
+}
+
+// exclusive prefix sum over lanes of a small count (0..7), wave-uniform total in `total`
+__device__ __forceinline__ int lane_prefix3(int cnt, int lane, int& total) {
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const unsigned long long b0 = __ballot(cnt & 1), b1 = __ballot(cnt & 2), b2 = __ballot(cnt & 4);
+    total = __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2);
+    return __popcll(b0 & below) + 2 * __popcll(b1 & below) + 4 * __popcll(b2 & below);
+}
+
+template <class LT>
+__device__ int find_contacts_v2(LT& L, const DevModel& M, int lane, float* __restrict__ mf) {
+    constexpr int N = LT::kN;
+    static_assert(4 * N == 64, "one contact slot per lane");
+    if (M.contact_model == 1) {
+        // lane = cylinder
+        int cnt = 0;
+        MPt p[4];
+        f3 wa[4];
+        float Rw[9];
+        const int c = lane < 2 * N ? lane : 0;
+        const int b = (c + 1) >> 1;
+        if (lane < 2 * N) {
+            const float* Rb = L.R[b];
+            cyl_world_rot(Rb, M.cyl_R[c], Rw);
+            const f3 dl = mk3(-Rw[6], -Rw[7], -Rw[8]);
+            const f3 centre = ld3(L.o[b]) + mulRv(Rb, ld3(M.cyl_c[c]));
+            cnt = manifold_update(M, mf + (size_t)c * kMfFloats, Rw, centre, dl, p, wa);
+        }
+        int total;
+        int base = lane_prefix3(cnt, lane, total);
+        if (lane < 2 * N) {
+            if (base > 4 * N) base = 4 * N;
+            if (base + cnt > 4 * N) cnt = 4 * N - base;       // the solve has 4 N contact slots
+            L.cylbase[c] = base;
+            L.cyln[c] = cnt;
+            f3 dA, dB;
+            friction_dirs(M, Rw, dA, dB);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (j < cnt) {
+                    const int idx = base + j;
+                    st3(L.ccP[idx], wa[j]);
+                    L.ccdist[idx] = p[j].d;
+                    L.ccbody[idx] = b;
+                    st3(L.ccdir[idx][0], dA);
+                    st3(L.ccdir[idx][1], dB);
+                }
+            }
+        }
+        return total > 4 * N ? 4 * N : total;
+    }
+    const int slot = lane;
+    const int c = slot >> 1;
+    const int b = (c + 1) >> 1;
+    const float* Rb = L.R[b];
+    float Rw[9];
+    cyl_world_rot(Rb, M.cyl_R[c], Rw);
     f3 dl = mk3(-Rw[6], -Rw[7], -Rw[8]);
-    float rr = sqrtf(dl.x * dl.x + dl.y * dl.y);
-    float lx = 0.f, ly = 0.f;
-    if (rr > 1e-12f) { lx = M.cyl_r * dl.x / rr; ly = M.cyl_r * dl.y / rr; }
+    float lx, ly;
+    rim_point(M, dl, lx, ly);
     float lz = (slot & 1) ? M.cyl_hl : -M.cyl_hl;
     f3 loc = mk3(lx + M.margin * dl.x, ly + M.margin * dl.y, lz + M.margin * dl.z);
     f3 P = ld3(L.o[b]) + mulRv(Rb, ld3(M.cyl_c[c])) + mulRv(Rw, loc);
@@ -110,13 +345,15 @@ __device__ int find_contacts_v2(LT& L, const DevModel& M, int lane, unsigned lon
         st3(L.ccP[idx], P);
         L.ccdist[idx] = dist;
         L.ccbody[idx] = b;
-        f3 a = mk3(M.aniso[0], M.aniso[1], M.aniso[2]);
-        f3 l1 = mulRtv(Rw, mk3(0.f, -1.f, 0.f));
-        f3 l2 = mulRtv(Rw, mk3(1.f, 0.f, 0.f));
-        st3(L.ccdir[idx][0], mulRv(Rw, mk3(l1.x * a.x, l1.y * a.y, l1.z * a.z)));
-        st3(L.ccdir[idx][1], mulRv(Rw, mk3(l2.x * a.x, l2.y * a.y, l2.z * a.z)));
+        f3 dA, dB;
+        friction_dirs(M, Rw, dA, dB);
+        st3(L.ccdir[idx][0], dA);
+        st3(L.ccdir[idx][1], dB);
     }
-    active_slots = bal;
+    if (lane < 2 * N) {      // lane = cylinder: where its (up to two) contacts sit in the compact list
+        L.cylbase[lane] = __popcll(bal & ((1ull << (2 * lane)) - 1ull));
+        L.cyln[lane] = (int)((bal >> (2 * lane)) & 1ull) + (int)((bal >> (2 * lane + 1)) & 1ull);
+    }
     return __popcll(bal);
 }
 
@@ -562,7 +799,7 @@ __device__ __forceinline__ void contact_rows(float (&RJ)[kSlots], float (&RM)[kS
 
 template <class LT>
 __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane, float mu, int& iters, int& ncontacts,
-                                           const SensorHint& hint) {
+                                           const SensorHint& hint, float* __restrict__ mf) {
     constexpr int N = LT::kN;
     constexpr int ND = N + 6;
     static_assert(N == 16, "v2 is laid out for the 16-link chain");
@@ -572,8 +809,7 @@ __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane, f
 #endif
     SNK_STAMP(0)
     // (1) contacts of the current pose, (2) bias forces with gravity, joint damping torque
-    unsigned long long cslots;   // bit s: contact slot s (cylinder s/2, end cap s&1) is active
-    const int nc = __builtin_amdgcn_readfirstlane(find_contacts_v2(L, M, lane, cslots));
+    const int nc = __builtin_amdgcn_readfirstlane(find_contacts_v2(L, M, lane, mf));
     ncontacts = nc;
     SNK_STAMP(1)
     if (lane < N) {
@@ -808,7 +1044,8 @@ __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane, f
     float fz = L.fz();
     if (sensor) {
         // lane = contact: its force and its moment about the body's joint origin (staging rows are
-        // free now); then lane = body sums its <= 4 contacts (slots 4b-2 .. 4b+1) in contact order
+        // free now); then lane = body sums the contacts of its cylinders (2b-1 and 2b; body 0: cylinder 0) in
+        // contact order
         if (lane < nc) {
             const int ci = lane, k = L.ccbody[ci];
             f3 F = (mk3(0.f, 0.f, 1.f) * L.app[kAppNormal + ci] +
@@ -821,11 +1058,11 @@ __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane, f
         if (lane <= N) {
             const int b = lane;
             f3 eN = mk3(0, 0, 0), eF = mk3(0, 0, 0);
-    #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int sl = 4 * b - 2 + j;
-                if (sl >= 0 && sl < 64 && ((cslots >> sl) & 1ull)) {
-                    const int ci = __popcll(cslots & ((1ull << sl) - 1ull));
+            const int c0 = b == 0 ? 0 : 2 * b - 1;
+            const int ncyl = (b == 0 || b == N) ? 1 : 2;
+            for (int cc = c0; cc < c0 + ncyl; cc++) {
+                const int cb = L.cylbase[cc], cn = L.cyln[cc];
+                for (int ci = cb; ci < cb + cn; ci++) {
                     eN = eN + ld3(&L.stM[ci][0]);
                     eF = eF + ld3(&L.stM[ci][3]);
                 }

@@ -29,6 +29,13 @@ typedef struct snk_params {
                                    URDF_USE_INERTIA_FROM_FILE); 1: urdf:815,871 values       */
     double  default_mass;       /* links without <inertial> (urdf:7,14,818): mass 1 [U]       */
     double  collision_margin;   /* 0.001 [U]                                                  */
+    int32_t hull_sides;         /* 0: implicit cylinder (default here); 32: the 32-gon prism PyBullet
+                                   builds for a URDF <cylinder> unless URDF_USE_IMPLICIT_CYLINDER [U]
+                                   (snake.py:93 passes no such flag); at most 32                     */
+    int32_t contact_model;      /* 0: stateless -- both end-cap points of every cylinder, every step
+                                   (default here); 1: Bullet's persistent manifold [U] -- one new
+                                   support point per cylinder per step merged into a cache of <= 4,
+                                   refreshed / dropped at breaking_threshold            */
     /* pybullet world */
     double  dt;                 /* 1/240 [U]: setTimeSteps is never called (snake.py:271-272) */
     double  gravity_z;          /* snake.py:8,91   -9.8                                       */

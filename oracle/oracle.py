@@ -17,7 +17,7 @@ class OrcParams(C.Structure):
     _fields_ = [
         ("n_modules", C.c_int32), ("inertia_from_file", C.c_int32),
         ("default_mass", C.c_double), ("collision_margin", C.c_double),
-        ("hull_sides", C.c_int32),
+        ("hull_sides", C.c_int32), ("contact_model", C.c_int32), ("max_contacts", C.c_int32),
         ("dt", C.c_double), ("gravity_z", C.c_double),
         ("lin_damping", C.c_double), ("ang_damping", C.c_double),
         ("joint_damping", C.c_double), ("max_coord_vel", C.c_double),
@@ -75,6 +75,8 @@ def _load(f32=False):
         "orc_hard_reset": (None, [vp]), "orc_reset": (None, [vp, D]),
         "orc_get_obs": (None, [vp, D]), "orc_mean_height": (C.c_double, [vp]),
         "orc_substep": (None, [vp, D]),
+        "orc_manifold_floats": (C.c_int32, [vp]),
+        "orc_get_manifold": (None, [vp, D]), "orc_set_manifold": (None, [vp, D]),
         "orc_last_iterations": (C.c_int32, [vp]), "orc_last_num_contacts": (C.c_int32, [vp]),
         "orc_env_step": (None, [vp, D, C.c_int32, D, D, I, I]),
         "orc_link_com_world": (None, [vp, D]), "orc_joint_axes_world": (None, [vp, D, D]),
@@ -169,6 +171,17 @@ class OracleEnv:
 
     def hard_reset(self):
         self.lib.orc_hard_reset(self.h)
+
+    def get_manifold(self):
+        """Contact cache of contact_model 1: [2n, 25] = per cylinder [count, 4 x (local point 3, ground point 3)]."""
+        m = np.zeros((2 * self.n, 25))
+        self.lib.orc_get_manifold(self.h, _dp(m))
+        return m
+
+    def set_manifold(self, m):
+        m = np.ascontiguousarray(m, dtype=np.float64)
+        assert m.shape == (2 * self.n, 25)
+        self.lib.orc_set_manifold(self.h, _dp(m))
 
     def reset(self):
         o = np.zeros(self.obs_dim)

@@ -187,6 +187,16 @@ struct Contact {
     Real dist;
 };
 
+/* btPersistentManifold of one (ground, link collider) pair [U]: up to 4 cached points, each kept as the point
+ * on the link in link coordinates and the point on the ground in world coordinates (the ground does not move). */
+struct ManifoldPoint {
+    Real localA[3], worldB[3], dist;
+};
+struct Manifold {
+    int n;
+    ManifoldPoint p[4];
+};
+
 }  // namespace
 
 struct orc_env {
@@ -209,6 +219,7 @@ struct orc_env {
     int last_iters;
     std::vector<Contact> contacts;
     std::vector<Real> last_normal_impulse;
+    std::vector<Manifold> manifolds;   /* contact_model 1: one per link (used by the links that carry a cylinder) */
 };
 
 namespace {
@@ -608,12 +619,29 @@ void jac_row(const orc_env* e, int link, const Real* Pw, const Real* d, Real* J)
     }
 }
 
+/* Vertex k (0 <= k < 2 S) of the S-gon prism PyBullet builds for a URDF <cylinder> [U]
+ * (BulletUrdfImporter: for i < 32: (r sin(2 pi i/32), r cos(2 pi i/32), +len/2) then the same with -len/2), about the
+ * cylinder's own centre. */
+inline void hull_vertex(const orc_env* e, int k, Real* v) {
+    const int S = e->P.hull_sides;
+    double th = 2.0 * kPi * (k >> 1) / S;
+    v[0] = (Real)(e->cyl_r * sin(th));
+    v[1] = (Real)(e->cyl_r * cos(th));
+    v[2] = (k & 1) ? -e->cyl_len / 2 : e->cyl_len / 2;
+}
+
 /* ground contacts of the current pose [U]: plane z=0, normal +z; each URDF cylinder is a
- * 32-gon prism hull inflated by the collision margin; one candidate point per end cap
- * (the lowest rim vertex), kept when closer than the contact breaking threshold.  This is
- * the populated state of Bullet's persistent manifold (which adds one deepest point per
- * frame and caches up to four); see DESIGN.md §3 for the deviation. */
-void find_contacts(orc_env* e) {
+ * 32-gon prism hull (hull_sides = 32, PyBullet's default import) or the implicit cylinder (hull_sides = 0),
+ * inflated by the collision margin.
+ * contact_model 0 (stateless): one candidate point per end cap (the lowest rim vertex), kept when closer than the
+ *   contact breaking threshold.  This is the populated state of Bullet's persistent manifold.
+ * contact_model 1 (Bullet's own scheme [U], btConvexPlaneCollisionAlgorithm + btPersistentManifold): every step ONE
+ *   new point per cylinder -- the support vertex towards the plane -- is merged into a cache of up to four points
+ *   (replacing the nearest cached point within the breaking threshold, else appended, else replacing the point
+ *   whose removal keeps the deepest point and the largest area, sortCachedPoints), then every cached point is
+ *   refreshed from the current link pose and dropped when it has lifted off or drifted sideways by more than the
+ *   threshold (refreshContactPoints).  Rows are built for every cached point, in manifold order. */
+void find_contacts_stateless(orc_env* e) {
     const orc_params& P = e->P;
     e->contacts.clear();
     for (int i = 0; i < e->L; i++) {
@@ -651,6 +679,121 @@ void find_contacts(orc_env* e) {
             if (c.dist < (Real)P.breaking_threshold) e->contacts.push_back(c);
         }
     }
+}
+
+/* btPersistentManifold::sortCachedPoints with gContactCalcArea3Points [U]: index of the cached point the new one
+ * replaces -- never the deepest; of the others, the one whose replacement leaves the largest area. */
+int manifold_sort_cached(const Manifold& m, const ManifoldPoint& pt) {
+    int maxPenIdx = -1;
+    Real maxPen = pt.dist;
+    for (int i = 0; i < 4; i++)
+        if (m.p[i].dist < maxPen) { maxPenIdx = i; maxPen = m.p[i].dist; }
+    Real res[4] = {0, 0, 0, 0};
+    auto area = [&](const Real* a1, const Real* a0, const Real* b1, const Real* b0) {
+        Real a[3], b[3], c[3];
+        for (int r = 0; r < 3; r++) { a[r] = a1[r] - a0[r]; b[r] = b1[r] - b0[r]; }
+        cross3(a, b, c);
+        return dot3(c, c);
+    };
+    if (maxPenIdx != 0) res[0] = area(pt.localA, m.p[1].localA, m.p[3].localA, m.p[2].localA);
+    if (maxPenIdx != 1) res[1] = area(pt.localA, m.p[0].localA, m.p[3].localA, m.p[2].localA);
+    if (maxPenIdx != 2) res[2] = area(pt.localA, m.p[0].localA, m.p[3].localA, m.p[1].localA);
+    if (maxPenIdx != 3) res[3] = area(pt.localA, m.p[0].localA, m.p[2].localA, m.p[1].localA);
+    int best = -1;
+    Real bv = -std::numeric_limits<Real>::infinity();
+    for (int i = 0; i < 4; i++) {
+        Real v = std::fabs(res[i]);
+        if (v > bv) { bv = v; best = i; }     /* btVector4::closestAxis4: first maximum */
+    }
+    return best;
+}
+
+void find_contacts_manifold(orc_env* e) {
+    const orc_params& P = e->P;
+    const Real thr = (Real)P.breaking_threshold;
+    e->contacts.clear();
+    if ((int)e->manifolds.size() != e->L) {
+        Manifold z;
+        memset(&z, 0, sizeof(z));
+        e->manifolds.assign(e->L, z);
+    }
+    for (int i = 0; i < e->L; i++) {
+        const Link& k = e->links[i];
+        if (!k.has_cyl) continue;
+        Manifold& m = e->manifolds[i];
+        const Real* Rw = &e->Rw[9 * i];
+        const Real* o = &e->ow[3 * i];
+        Real dl[3] = {-Rw[6], -Rw[7], -Rw[8]};   /* plane normal, negated, in link coords (unit) */
+        /* support vertex towards the plane (localGetSupportingVertex: vertex + margin * direction) */
+        Real v[3];
+        if (P.hull_sides > 0) {
+            Real bestv = -std::numeric_limits<Real>::infinity();
+            for (int kk = 0; kk < 2 * P.hull_sides; kk++) {
+                Real c[3];
+                hull_vertex(e, kk, c);
+                Real val = dot3(dl, c);
+                if (val > bestv) { bestv = val; v[0] = c[0]; v[1] = c[1]; v[2] = c[2]; }
+            }
+        } else {
+            /* btCylinderShapeZ::localGetSupportingVertexWithoutMargin */
+            Real rr = std::sqrt(dl[0] * dl[0] + dl[1] * dl[1]);
+            if (rr != 0) { v[0] = e->cyl_r * dl[0] / rr; v[1] = e->cyl_r * dl[1] / rr; }
+            else { v[0] = e->cyl_r; v[1] = 0; }
+            v[2] = dl[2] < 0 ? -e->cyl_len / 2 : e->cyl_len / 2;
+        }
+        ManifoldPoint np;
+        for (int r = 0; r < 3; r++) np.localA[r] = v[r] + k.cyl_c[r] + (Real)P.collision_margin * dl[r];
+        Real w[3];
+        mat3_vec(Rw, np.localA, w);
+        np.dist = o[2] + w[2];
+        if (np.dist < thr) {
+            np.worldB[0] = o[0] + w[0]; np.worldB[1] = o[1] + w[1]; np.worldB[2] = 0;   /* projection onto the plane */
+            /* getCacheEntry: nearest cached point (in link coordinates) closer than the threshold */
+            int nearest = -1;
+            Real shortest = thr * thr;
+            for (int j = 0; j < m.n; j++) {
+                Real d[3] = {m.p[j].localA[0] - np.localA[0], m.p[j].localA[1] - np.localA[1], m.p[j].localA[2] - np.localA[2]};
+                Real dd = dot3(d, d);
+                if (dd < shortest) { shortest = dd; nearest = j; }
+            }
+            if (nearest >= 0) m.p[nearest] = np;
+            else if (m.n < 4) m.p[m.n++] = np;
+            else m.p[manifold_sort_cached(m, np)] = np;
+        }
+        /* refreshContactPoints: positions and distances from the current pose, then removal (last to first) */
+        Real wa[4][3];
+        for (int j = 0; j < m.n; j++) {
+            mat3_vec(Rw, m.p[j].localA, wa[j]);
+            for (int r = 0; r < 3; r++) wa[j][r] += o[r];
+            m.p[j].dist = wa[j][2] - m.p[j].worldB[2];
+        }
+        for (int j = m.n - 1; j >= 0; j--) {
+            bool drop = !(m.p[j].dist <= thr);
+            if (!drop) {
+                Real dx = m.p[j].worldB[0] - wa[j][0], dy = m.p[j].worldB[1] - wa[j][1];
+                Real dz = m.p[j].worldB[2] - (wa[j][2] - m.p[j].dist);
+                drop = dx * dx + dy * dy + dz * dz > thr * thr;
+            }
+            if (drop) {
+                int last = m.n - 1;
+                if (j != last) { m.p[j] = m.p[last]; for (int r = 0; r < 3; r++) wa[j][r] = wa[last][r]; }
+                m.n--;
+            }
+        }
+        for (int j = 0; j < m.n; j++) {
+            Contact c;
+            c.link = i;
+            for (int r = 0; r < 3; r++) c.P[r] = wa[j][r];
+            c.dist = m.p[j].dist;
+            e->contacts.push_back(c);
+        }
+    }
+}
+
+void find_contacts(orc_env* e) {
+    if (e->P.contact_model == 1) find_contacts_manifold(e);
+    else find_contacts_stateless(e);
+    if (e->P.max_contacts > 0 && (int)e->contacts.size() > e->P.max_contacts) e->contacts.resize(e->P.max_contacts);
 }
 
 void apply_dv(orc_env* e, const Real* dvec, Real mult) {
@@ -959,6 +1102,8 @@ void orc_default_params(orc_params* p) {
     p->default_mass = 1.0;
     p->collision_margin = 0.001;
     p->hull_sides = 0;   /* implicit cylinder: see find_contacts and DESIGN.md §3 */
+    p->max_contacts = 0;
+    p->contact_model = 0;/* stateless two-point manifold (default here); 1 = Bullet's persistent manifold [U] */
     p->dt = 1.0 / 240.0;
     p->gravity_z = -9.8;
     p->lin_damping = 0.04;
@@ -1044,6 +1189,37 @@ void orc_hard_reset(orc_env* e) {
     e->last_iters = 0;
     e->contacts.clear();
     e->last_normal_impulse.clear();
+    e->manifolds.clear();    /* resetSimulation + loadURDF: a new world (a soft reset keeps the contact cache [U]) */
+}
+
+/* contact cache, per cylinder in link order: [count, 4 x (point on the link in link coords 3, point on the ground 3)] */
+int32_t orc_manifold_floats(const orc_env* e) { return 2 * e->n * 25; }
+void orc_get_manifold(const orc_env* e, double* out) {
+    int c = 0;
+    for (int i = 0; i < e->L; i++) {
+        if (!e->links[i].has_cyl) continue;
+        double* o = out + 25 * c++;
+        for (int r = 0; r < 25; r++) o[r] = 0;
+        if ((int)e->manifolds.size() != e->L) continue;
+        const Manifold& m = e->manifolds[i];
+        o[0] = m.n;
+        for (int j = 0; j < m.n; j++)
+            for (int r = 0; r < 3; r++) { o[1 + 6 * j + r] = m.p[j].localA[r]; o[4 + 6 * j + r] = m.p[j].worldB[r]; }
+    }
+}
+void orc_set_manifold(orc_env* e, const double* in) {
+    Manifold z;
+    memset(&z, 0, sizeof(z));
+    e->manifolds.assign(e->L, z);
+    int c = 0;
+    for (int i = 0; i < e->L; i++) {
+        if (!e->links[i].has_cyl) continue;
+        const double* o = in + 25 * c++;
+        Manifold& m = e->manifolds[i];
+        m.n = (int)o[0];
+        for (int j = 0; j < m.n; j++)
+            for (int r = 0; r < 3; r++) { m.p[j].localA[r] = (Real)o[1 + 6 * j + r]; m.p[j].worldB[r] = (Real)o[4 + 6 * j + r]; }
+    }
 }
 
 void orc_reset(orc_env* e, double* obs) {

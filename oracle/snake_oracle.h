@@ -41,6 +41,11 @@ typedef struct orc_params {
     double  collision_margin; /* gUrdfDefaultCollisionMargin [U] = 0.001                 */
     int32_t hull_sides;       /* 0 = implicit cylinder (default here); 32 = PyBullet's
                                * default 32-gon hull import [U] (rocks with a 2-point manifold) */
+    int32_t contact_model;    /* 0 = stateless: both end-cap points of every cylinder, every step (default here);
+                               * 1 = Bullet's persistent manifold [U]: one new support point per cylinder per
+                               *     step merged into a cache of <= 4, refreshed / dropped at breaking_threshold */
+    int32_t max_contacts;     /* 0 = no limit; > 0: only the first max_contacts points (in manifold order) get
+                               * rows -- mirrors the product's structural limit of 4n contacts (tests only)   */
     /* world / integrator */
     double  dt;               /* PyBullet default fixedTimeStep 1/240 [U] (F2)           */
     double  gravity_z;        /* snake.py:8  -9.8                                        */
@@ -103,6 +108,12 @@ void     orc_hard_reset(orc_env* e);                  /* snake.py:88-95  */
 void     orc_reset(orc_env* e, double* obs);          /* SnakeGymEnv.py:28-31 (soft) */
 void     orc_get_obs(const orc_env* e, double* obs);  /* snake.py:209-217 */
 double   orc_mean_height(orc_env* e);                 /* snake.py:237-245 (value) */
+
+/* contact cache of contact_model 1, per cylinder in link order:
+ * [count, 4 x (point on the link in link coordinates 3, point on the ground in world coordinates 3)] */
+int32_t  orc_manifold_floats(const orc_env* e);                 /* 2n * 25 */
+void     orc_get_manifold(const orc_env* e, double* out);
+void     orc_set_manifold(orc_env* e, const double* in);
 
 /* one physics substep (pybullet.stepSimulation with POSITION_CONTROL targets) */
 void     orc_substep(orc_env* e, const double* targets_n);
