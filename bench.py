@@ -87,7 +87,7 @@ def env_friction(global_ids, seed):
     return 0.5 + (h >> np.uint64(11)).astype(np.float64) / float(1 << 53)
 
 
-def cpu_baseline(steps=2000, warmup=20, n_links=16, friction_seed=None):
+def cpu_baseline(steps=2000, warmup=20, n_links=16, friction_seed=None, hull_sides=0, contact_model=0):
     """BASELINE.md row B3 / SURVEY 8(d): the float64 C++ oracle on the configs[0] action stream, timed from C++
     (oracle/snake_oracle.cpp: orc_bench_gait -- no Python in the timed loop), 1 thread and all cores, `steps`
     env-steps after `warmup` warm-up steps each.  PyBullet itself is probed at run time and reported, never
@@ -111,7 +111,7 @@ def cpu_baseline(steps=2000, warmup=20, n_links=16, friction_seed=None):
     cores = max(1, min(nproc, quota) if quota else nproc)
     if quota is None and nproc > 64:
         cores = 64          # no quota visible: one thread per physical core of a 64-core socket at most
-    kw = dict(n_modules=n_links)
+    kw = dict(n_modules=n_links, hull_sides=hull_sides, contact_model=contact_model)
 
     def mu_of(ids):
         return None if friction_seed is None else env_friction(ids, friction_seed)
@@ -149,6 +149,10 @@ def main():
     ap.add_argument("--friction-seed", type=int, default=None,
                     help="BASELINE configs[4]: per-env ground friction mu_e ~ U[0.5, 1.5), counter-based generator with "
                          "this seed (the config says seed 1), keyed by the global env index")
+    ap.add_argument("--hull-sides", type=int, default=0,
+                    help="not a BASELINE config: 32 = cylinders as the 32-gon hulls PyBullet imports (DESIGN.md 3)")
+    ap.add_argument("--contact-model", type=int, default=0, choices=(0, 1),
+                    help="not a BASELINE config: 1 = Bullet's persistent <= 4-point contact manifold (DESIGN.md 3)")
     ap.add_argument("--cpu-steps", type=int, default=2000,
                     help="env-steps of the CPU baseline (BASELINE.md B3: 2000 after 20 warm-up steps)")
     ap.add_argument("--policy", action="store_true",
@@ -167,7 +171,8 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # C++ threads inside this process (no fork): safe before or after GPU initialisation, profiler or not
-        cpu = cpu_baseline(steps=args.cpu_steps, n_links=args.links, friction_seed=args.friction_seed)
+        cpu = cpu_baseline(steps=args.cpu_steps, n_links=args.links, friction_seed=args.friction_seed,
+                           hull_sides=args.hull_sides, contact_model=args.contact_model)
 
     import importlib
     import torch
@@ -190,7 +195,8 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    local = pkg.DeviceVecEnv(E, device_index=local_rank, n_modules=NL)
+    local = pkg.DeviceVecEnv(E, device_index=local_rank, n_modules=NL, hull_sides=args.hull_sides,
+                             contact_model=args.contact_model)
     if args.friction_seed is not None:      # configs[4]: this rank's shard of the per-env plane friction
         local.set_ground_friction(env_friction(np.arange(rank * E, (rank + 1) * E), args.friction_seed).astype(np.float32))
     env = pkg.ShardedVecEnv(local, root=0, device=dev) if world > 1 else None
@@ -279,7 +285,8 @@ def main():
         # WRITE_SIZE, calibrated on reset_kernel), run separately and committed under profiles/
         # rocprofv3 summaries of THIS configuration (profiles/README.md), replayed here -- they are measured in
         # separate --pmc runs of the same command, not in this run; the key names say so.
-        cfg_key = ("c%d" % NL) + ("_fric" if args.friction_seed is not None else "") + ("_policy" if args.policy else "")
+        cfg_key = ("c%d" % NL) + ("_fric" if args.friction_seed is not None else "") + ("_policy" if args.policy else "") + (
+            "_hull%d_cm%d" % (args.hull_sides, args.contact_model) if (args.hull_sides or args.contact_model) else "")
         traffic, traffic_src, valu = None, None, None
         try:
             import glob
@@ -322,6 +329,7 @@ def main():
                                                          "actions sampled from a random-init 2x256 actor-critic on the GPU"
                                                          if args.policy else "serpenoid gait actions", cfg_index)),
                 "envs_per_gpu": E, "n_links": NL, "friction_seed": args.friction_seed,
+                "hull_sides": args.hull_sides, "contact_model": args.contact_model,
                 "world_size": (dist.get_world_size() if dist is not None else 1),
                 "backend": (dist.get_backend() if dist is not None else None),
                 "parallelism": "envs sharded over %d GPU(s), no data-path collective; "

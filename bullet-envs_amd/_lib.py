@@ -61,6 +61,9 @@ SYMBOLS = {
     "snk_substep_host": (C.c_int, [_vp, _F, C.c_int32, _I32]),
     "snk_get_state": (C.c_int, [_vp, _F, _F]),
     "snk_set_state": (C.c_int, [_vp, _F, _F]),
+    "snk_manifold_floats": (C.c_int32, [_vp]),
+    "snk_get_manifold": (C.c_int, [_vp, _F]),
+    "snk_set_manifold": (C.c_int, [_vp, _F]),
     "snk_get_obs": (C.c_int, [_vp, _F]),
     "snk_mean_height": (C.c_int, [_vp, _F]),
     "snk_link_positions": (C.c_int, [_vp, _F]),
@@ -206,6 +209,19 @@ class Stepper:
             assert a.shape == (self.n_envs, self.n + 2)
         check(self.lib.snk_set_state(self.h, fptr(s) if s is not None else None, fptr(a) if a is not None else None),
               "snk_set_state")
+
+    def get_manifold(self):
+        """contact_model 1: [n_envs, 2n, 25] contact cache (see snk.h); None for a contact_model 0 handle."""
+        if self.lib.snk_manifold_floats(self.h) == 0:
+            return None
+        m = np.zeros((self.n_envs, 2 * self.n, 25), dtype=np.float32)
+        check(self.lib.snk_get_manifold(self.h, fptr(m)), "snk_get_manifold")
+        return m
+
+    def set_manifold(self, m):
+        m = np.ascontiguousarray(m, dtype=np.float32)
+        assert m.shape == (self.n_envs, 2 * self.n, 25)
+        check(self.lib.snk_set_manifold(self.h, fptr(m)), "snk_set_manifold")
 
     def get_obs(self):
         o = np.zeros((self.n_envs, self.obs_dim), dtype=np.float32)

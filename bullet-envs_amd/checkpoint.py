@@ -22,9 +22,11 @@ def save_state(env, path):
     st = _stepper(env)
     state, aux = st.get_state()
     # the EFFECTIVE friction, read back from the device (also covers values set through the C ABI directly)
+    mf = st.get_manifold()           # the contact cache is simulator state too (contact_model 1)
     np.savez_compressed(path, state=state, aux=aux, n_envs=np.int64(st.n_envs),
                         params=np.frombuffer(bytes(st.params), dtype=np.uint8),
-                        ground_friction=st.get_ground_friction())
+                        ground_friction=st.get_ground_friction(),
+                        manifold=np.zeros(0, np.float32) if mf is None else mf)
 
 
 def load_state(env, path):
@@ -39,3 +41,5 @@ def load_state(env, path):
         # always restored: a checkpoint of a default-friction world must also undo the target's custom friction
         st.set_ground_friction(mu if mu.size else np.ones(st.n_envs, np.float32))
         st.set_state(z["state"], z["aux"])
+        if "manifold" in z.files and z["manifold"].size:
+            st.set_manifold(z["manifold"])

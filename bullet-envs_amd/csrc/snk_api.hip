@@ -50,6 +50,7 @@ struct snk_handle {
     int32_t* d_info = nullptr;
     float* d_h = nullptr;
     float* d_linkpos = nullptr;   // allocated on first snk_link_positions
+    float* d_mf = nullptr;        // contact_model 1: the persistent contact manifolds, [n_envs][2n][kMfFloats]
     float* d_rows = nullptr;      // 32-link chains: constraint rows streamed from global memory (snk_device.hpp: pgs_v1)
     int32_t* d_order = nullptr;
     bool plan = true;
@@ -74,20 +75,20 @@ int launch_step(snk_handle* h, float* act, float* obs, float* rew, uint8_t* done
         hipLaunchKernelGGL((snk::plan_sched_kernel<N>), dim3(1), dim3(1024), 0, st, h->d_model, h->d_recs, act, h->sched,
                            h->n_envs);
         hipLaunchKernelGGL((snk::env_step_sched_kernel<N>), dim3(h->grid_waves), dim3(64), h->lds_bytes, st, h->model_slot,
-                           h->d_recs, h->d_mu, act, obs, rew, done, sub, vec_mode, h->n_envs, h->sched, h->d_rows);
+                           h->d_recs, h->d_mu, act, obs, rew, done, sub, vec_mode, h->n_envs, h->sched, h->d_rows, h->d_mf);
         return 0;
     }
     if (h->plan)
         hipLaunchKernelGGL((snk::plan_kernel<N>), dim3(1), dim3(1024), 0, st, h->d_model, h->d_recs, act, h->d_order,
                            h->n_envs);
     hipLaunchKernelGGL((snk::env_step_kernel<N>), dim3(h->n_envs), dim3(64), h->lds_bytes, st, h->d_model, h->d_recs,
-                       h->d_mu, act, obs, rew, done, sub, vec_mode, h->n_envs, h->plan ? h->d_order : nullptr, h->d_rows);
+                       h->d_mu, act, obs, rew, done, sub, vec_mode, h->n_envs, h->plan ? h->d_order : nullptr, h->d_rows, h->d_mf);
     return 0;
 }
 template <int N>
 int launch_substep(snk_handle* h, const float* tgt, int k, int32_t* info, hipStream_t st) {
     hipLaunchKernelGGL((snk::substep_kernel<N>), dim3(h->n_envs), dim3(64), h->lds_bytes, st, h->d_model, h->d_recs,
-                       h->d_mu, tgt, k, info, h->n_envs, h->d_rows);
+                       h->d_mu, tgt, k, info, h->n_envs, h->d_rows, h->d_mf);
     return 0;
 }
 template <int N>
@@ -249,6 +250,11 @@ int init_handle(snk_handle* h, const snk_params* p, int32_t n_envs, int32_t devi
         HIP_TRY(hipMalloc(&h->d_rows, bytes));
         HIP_TRY(hipMemset(h->d_rows, 0, bytes));     // the last three rows of every block stay zero for good
     }
+    if (p->contact_model == 1) {
+        const size_t bytes = ne * 2 * h->n * snk::kMfFloats * sizeof(float);
+        HIP_TRY(hipMalloc(&h->d_mf, bytes));
+        HIP_TRY(hipMemset(h->d_mf, 0, bytes));       // hard reset: empty manifolds
+    }
     h->plan = getenv("SNK_NO_PLAN") == nullptr;
     {
         // scheduler state (snk_device.hpp: Sched)
@@ -300,6 +306,8 @@ int snk_create(const snk_params* p, int32_t n_envs, int32_t device, snk_handle**
     if (p->n_modules != 16 && p->n_modules != 32) return fail("snk_create: n_modules must be 16 or 32");
     if (p->hull_sides < 0 || p->hull_sides > 32) return fail("snk_create: hull_sides must be 0 (implicit cylinder) .. 32");
     if (p->contact_model != 0 && p->contact_model != 1) return fail("snk_create: contact_model must be 0 or 1");
+    if (p->contact_model == 1 && p->n_modules != 16)
+        return fail("snk_create: contact_model 1 (persistent manifold) is built for n_modules 16");
     if (p->term_index < 0 || p->term_index >= 3 * p->n_modules + 8) return fail("snk_create: term_index out of range");
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
@@ -321,7 +329,7 @@ int snk_destroy(snk_handle* h) {
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
     void* bufs[] = {h->d_model, h->d_recs, h->d_mu, h->d_act, h->d_obs, h->d_rew, h->d_done,
-                    h->d_sub, h->d_mask, h->d_tgt, h->d_info, h->d_h, h->d_order, h->d_rows, h->d_linkpos,
+                    h->d_sub, h->d_mask, h->d_tgt, h->d_info, h->d_h, h->d_order, h->d_rows, h->d_linkpos, h->d_mf,
                     h->sched.head, h->sched.tail, h->sched.ent, h->sched.waiting, h->sched.counter, h->sched.finished};
     for (void* b : bufs) (void)hipFree(b);
     if (h->h_alarm) (void)hipHostFree(h->h_alarm);
@@ -474,6 +482,39 @@ int snk_set_state(snk_handle* h, const float* state, const float* aux) {
         if (aux) memcpy(&recs[e * h->rec + sd], aux + e * (n + 2), (n + 2) * sizeof(float));
     }
     HIP_TRY(hipMemcpy(h->d_recs, recs.data(), recs.size() * sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int32_t snk_manifold_floats(const snk_handle* h) { return h->d_mf ? 2 * h->n * 25 : 0; }
+
+// host layout per cylinder (same as the oracle's): [count, 4 x (point on the link in link coordinates 3, point on the
+// ground 3)] = 25 floats; device layout: [count, 3 pad, 4 x 6] = kMfFloats
+int snk_get_manifold(snk_handle* h, float* out) {
+    if (!h || !out) return fail("snk_get_manifold: null argument");
+    if (!h->d_mf) return fail("snk_get_manifold: this handle has contact_model 0 (no contact cache)");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipDeviceSynchronize());
+    const size_t ncyl = (size_t)h->n_envs * 2 * h->n;
+    std::vector<float> dev(ncyl * snk::kMfFloats);
+    HIP_TRY(hipMemcpy(dev.data(), h->d_mf, dev.size() * sizeof(float), hipMemcpyDeviceToHost));
+    for (size_t c = 0; c < ncyl; c++) {
+        out[25 * c] = dev[snk::kMfFloats * c];
+        memcpy(out + 25 * c + 1, &dev[snk::kMfFloats * c + 4], 24 * sizeof(float));
+    }
+    return 0;
+}
+int snk_set_manifold(snk_handle* h, const float* in) {
+    if (!h || !in) return fail("snk_set_manifold: null argument");
+    if (!h->d_mf) return fail("snk_set_manifold: this handle has contact_model 0 (no contact cache)");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipDeviceSynchronize());
+    const size_t ncyl = (size_t)h->n_envs * 2 * h->n;
+    std::vector<float> dev(ncyl * snk::kMfFloats, 0.f);
+    for (size_t c = 0; c < ncyl; c++) {
+        dev[snk::kMfFloats * c] = in[25 * c];
+        memcpy(&dev[snk::kMfFloats * c + 4], in + 25 * c + 1, 24 * sizeof(float));
+    }
+    HIP_TRY(hipMemcpy(h->d_mf, dev.data(), dev.size() * sizeof(float), hipMemcpyHostToDevice));
     return 0;
 }
 

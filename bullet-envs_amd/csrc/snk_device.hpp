@@ -356,6 +356,8 @@ __device__ void body_bias(LT& L, const DevModel& M, int lane) {
 // breaking threshold [U].  Friction directions (0,-1,0),(1,0,0) scaled anisotropically in
 // the cylinder link's axes: d' = Rc diag(aniso) Rc^T d  (snake.py:104-106).
 // ----------------------------------------------------------------------------------
+__device__ __forceinline__ void rim_point(const DevModel& M, f3 dl, float& lx, float& ly);     // snk_pgs_v2.hpp
+
 template <class LT>
 __device__ int find_contacts_v1(LT& L, const DevModel& M, int lane, float* __restrict__ rows) {
     constexpr int N = LT::kN;
@@ -375,9 +377,8 @@ __device__ int find_contacts_v1(LT& L, const DevModel& M, int lane, float* __res
                 for (int j = 0; j < 3; j++)
                     Rw[3 * i + j] = Rb[3 * i] * Rc[j] + Rb[3 * i + 1] * Rc[3 + j] + Rb[3 * i + 2] * Rc[6 + j];
             f3 dl = mk3(-Rw[6], -Rw[7], -Rw[8]);
-            float rr = sqrtf(dl.x * dl.x + dl.y * dl.y);
-            float lx = 0.f, ly = 0.f;
-            if (rr > 1e-12f) { lx = M.cyl_r * dl.x / rr; ly = M.cyl_r * dl.y / rr; }
+            float lx, ly;
+            rim_point(M, dl, lx, ly);
             float lz = (slot & 1) ? M.cyl_hl : -M.cyl_hl;
             f3 loc = mk3(lx + M.margin * dl.x, ly + M.margin * dl.y, lz + M.margin * dl.z);
             f3 P = ld3(L.o[b]) + mulRv(Rb, ld3(M.cyl_c[c])) + mulRv(Rw, loc);
@@ -1155,7 +1156,7 @@ namespace snk {
 
 template <class LT>
 __device__ __forceinline__ void substep(LT& L, const DevModel& M0, int lane_in, float mu, int& iters, int& ncontacts,
-                                        const SensorHint& hint, float* __restrict__ rows) {
+                                        const SensorHint& hint, float* __restrict__ rows, float* __restrict__ mf) {
     int lane = lane_in;
     // Launder the model pointer once per substep: otherwise ~100 per-lane model constants are
     // hoisted out of the substep loop and stay live (or spilled) across the whole solve.
@@ -1165,7 +1166,7 @@ __device__ __forceinline__ void substep(LT& L, const DevModel& M0, int lane_in, 
     // ... and the lane id: hundreds of per-lane LDS addresses are loop-invariant and would
     // otherwise be computed in the kernel prologue and spilled.
     asm volatile("" : "+v"(lane));
-    if constexpr (LT::kV2) substep_v2(L, M, lane, mu, iters, ncontacts, hint);
+    if constexpr (LT::kV2) substep_v2(L, M, lane, mu, iters, ncontacts, hint, mf);
     else substep_v1(L, M, lane, mu, iters, ncontacts, rows, hint);
 }
 
@@ -1227,7 +1228,8 @@ __global__ __launch_bounds__(64, 2) void env_step_kernel(const DevModel* __restr
                                                       float* __restrict__ actions, float* __restrict__ obs,
                                                       float* __restrict__ rew, uint8_t* __restrict__ done,
                                                       int32_t* __restrict__ substeps, int vec_mode, int n_envs,
-                                                      const int32_t* __restrict__ order, float* __restrict__ rows_all) {
+                                                      const int32_t* __restrict__ order, float* __restrict__ rows_all,
+                                                      float* __restrict__ mf_all) {
     extern __shared__ float4 smem_raw[];
     using LT = Lds<N, (N == 16)>;
     LT& L = *reinterpret_cast<LT*>(smem_raw);
@@ -1257,6 +1259,7 @@ __global__ __launch_bounds__(64, 2) void env_step_kernel(const DevModel* __restr
     float mu = fminf(M.mu_link * mu_plane[env], 10.0f);
     float* env_rows = nullptr;      // constraint rows of chains too long for the register-resident solve
     if constexpr (!LT::kV2) env_rows = rows_all + (size_t)env * LT::kRowFloats;
+    float* env_mf = mf_all ? mf_all + (size_t)env * (2 * N * kMfFloats) : nullptr;   // contact cache (contact_model 1)
     fk_vel(L, M, lane);
     // Snake.step servo loop (snake.py:283-304)
     int counter = 0;
@@ -1270,7 +1273,7 @@ __global__ __launch_bounds__(64, 2) void env_step_kernel(const DevModel* __restr
         float nrm = sqrtf(wave_sum<64>(e * e));
         if (!(nrm > M.servo_tol)) break;
         hint.counter_next = counter + 1;
-        substep(L, M, lane, mu, it_dummy, nc_dummy, hint, env_rows);
+        substep(L, M, lane, mu, it_dummy, nc_dummy, hint, env_rows, env_mf);
         counter++;
         hint.h_prev = mean_height(L, M, lane);
         if (hint.h_prev > M.height_thr) { end_height = true; break; }
@@ -1309,7 +1312,8 @@ template <int N>
 __global__ __launch_bounds__(64, 2) void substep_kernel(const DevModel* __restrict__ Mp, float* __restrict__ recs,
                                                      const float* __restrict__ mu_plane,
                                                      const float* __restrict__ targets, int k,
-                                                     int32_t* __restrict__ info, int n_envs, float* __restrict__ rows_all) {
+                                                     int32_t* __restrict__ info, int n_envs, float* __restrict__ rows_all,
+                                                     float* __restrict__ mf_all) {
     extern __shared__ float4 smem_raw[];
     using LT = Lds<N, (N == 16)>;
     LT& L = *reinterpret_cast<LT*>(smem_raw);
@@ -1327,7 +1331,8 @@ __global__ __launch_bounds__(64, 2) void substep_kernel(const DevModel* __restri
     hint.always = true; hint.counter_next = 0; hint.h_prev = 0.f;
     float* env_rows = nullptr;
     if constexpr (!LT::kV2) env_rows = rows_all + (size_t)env * LT::kRowFloats;
-    for (int s = 0; s < k; s++) substep(L, M, lane, mu, iters, nc, hint, env_rows);
+    float* env_mf = mf_all ? mf_all + (size_t)env * (2 * N * kMfFloats) : nullptr;
+    for (int s = 0; s < k; s++) substep(L, M, lane, mu, iters, nc, hint, env_rows, env_mf);
     if (info && lane == 0) { info[2 * env] = iters; info[2 * env + 1] = nc; }
     store_rec(L, recs + (size_t)env * LT::REC, lane);
 }
@@ -1644,7 +1649,8 @@ __global__ __launch_bounds__(64, 2) void env_step_sched_kernel(int model_slot, f
                                                             float* __restrict__ actions, float* __restrict__ obs,
                                                             float* __restrict__ rew, uint8_t* __restrict__ done,
                                                             int32_t* __restrict__ substeps, int vec_mode, int n_envs,
-                                                            Sched sc, float* __restrict__ rows_all) {
+                                                            Sched sc, float* __restrict__ rows_all,
+                                                            float* __restrict__ mf_all) {
     extern __shared__ float4 smem_raw[];
     using LT = Lds<N, (N == 16)>;
     LT& L = *reinterpret_cast<LT*>(smem_raw);
@@ -1702,6 +1708,7 @@ __global__ __launch_bounds__(64, 2) void env_step_sched_kernel(int model_slot, f
         }
         lds_sync();
         const float mu = fminf(M.mu_link * mu_plane[env], 10.0f);
+        float* env_mf = mf_all ? mf_all + (size_t)env * (2 * N * kMfFloats) : nullptr;   // contact cache (contact_model 1)
         fk_vel(L, M, lane);
         // Snake.step servo loop (snake.py:283-304), `quantum` substeps at a time
         bool end_height = false, complete = false;
@@ -1729,7 +1736,7 @@ __global__ __launch_bounds__(64, 2) void env_step_sched_kernel(int model_slot, f
                 in_slice = 0;
             }
             hint.counter_next = counter + 1;
-            substep(L, M, lane, mu, it_dummy, nc_dummy, hint, env_rows);
+            substep(L, M, lane, mu, it_dummy, nc_dummy, hint, env_rows, env_mf);
 #ifdef SNK_SCHED_DEBUG
             n_sub++;
 #endif

@@ -132,6 +132,13 @@ int snk_substep_host(snk_handle* h, const float* targets, int32_t k, int32_t* in
  * state [n_envs x state_dim]; aux [n_envs x (n+2)] = motor torques n, joint-0 Fz, prev obs x. */
 int snk_get_state(snk_handle* h, float* state, float* aux);
 int snk_set_state(snk_handle* h, const float* state, const float* aux);
+/* contact_model 1 only: the persistent contact manifolds (part of the simulator state, like Bullet's contact cache,
+ * which a soft reset does not clear [U]).  Host buffers [n_envs x 2n x 25]: per cylinder (in link order)
+ * [count, 4 x (point on the link in link coordinates 3, point on the ground in world coordinates 3)].
+ * snk_manifold_floats = 2n * 25, or 0 for a contact_model 0 handle (then get/set fail). */
+int32_t snk_manifold_floats(const snk_handle* h);
+int snk_get_manifold(snk_handle* h, float* out);
+int snk_set_manifold(snk_handle* h, const float* in);
 /* getObservation (snake.py:209-217) of every env, host buffer [n_envs x obs_dim]. */
 int snk_get_obs(snk_handle* h, float* obs);
 /* checkSnakeHeight's mean z (snake.py:237-245), host buffer [n_envs]. */

@@ -87,7 +87,7 @@ def _load(f32=False):
         "orc_contacts": (C.c_int32, [vp, D, C.c_int32]),
         "orc_last_normal_impulses": (C.c_int32, [vp, D, C.c_int32]),
         "orc_bench_gait": (C.c_double, [C.POINTER(OrcParams), C.c_int32, D, D, C.c_int32, C.c_int32, C.c_int32,
-                                        C.POINTER(C.c_int64)]),
+                                        C.POINTER(C.c_int64), D]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -113,15 +113,21 @@ def _dp(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
 
 
-def bench_gait(n_envs, phases, warmup, steps, n_threads, mu_plane=None, params=None, **over):
-    """Times the C++ gait driver (orc_bench_gait): returns (seconds for `steps` batched steps, physics substeps)."""
+def bench_gait(n_envs, phases, warmup, steps, n_threads, mu_plane=None, params=None, want_agg=False, **over):
+    """Times the C++ gait driver (orc_bench_gait): returns (seconds for `steps` batched steps, physics substeps)
+    and, with want_agg, a dict of rollout aggregates over the timed steps."""
     p = params if params is not None else default_params(**over)
     ph = np.ascontiguousarray(phases, dtype=np.float64)
     assert ph.shape == (n_envs,)
     mu = None if mu_plane is None else np.ascontiguousarray(mu_plane, dtype=np.float64)
     sub = C.c_int64()
+    agg = np.zeros(4)
     sec = _load().orc_bench_gait(C.byref(p), int(n_envs), _dp(ph), _dp(mu) if mu is not None else None,
-                                 int(warmup), int(steps), int(n_threads), C.byref(sub))
+                                 int(warmup), int(steps), int(n_threads), C.byref(sub), _dp(agg))
+    if want_agg:
+        tot = float(n_envs * steps)
+        return sec, sub.value, dict(mean_substeps=sub.value / tot, episode_end_rate=agg[0] / tot,
+                                    mean_reward=agg[1] / tot, mean_dx=agg[2] / tot, mean_contacts=agg[3] / tot)
     return sec, sub.value
 
 

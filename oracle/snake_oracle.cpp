@@ -210,6 +210,7 @@ struct orc_env {
     Real pos[3], quat[4], omega[3], vel[3];
     std::vector<Real> q, qd, tau_motor;
     Real fz, prev_x;
+    double last_terminal_x;   /* base x of the last env-step's terminal observation (before any reset) */
     /* workspace, per link */
     std::vector<Real> Rw, ow, E, X, v, c, I6, IA, pA, U, a, S;
     std::vector<Real> D, u;
@@ -1275,6 +1276,7 @@ void orc_env_step(orc_env* e, double* action, int32_t vec_mode, double* obs, dou
     get_obs(e, o.data());
     double energy = 0;
     for (int i = 0; i < n; i++) energy += o[n + i] * o[2 * n + i] * P.energy_dt;   /* snake.py:336-341 */
+    e->last_terminal_x = o[3 * n];
     double r_x = o[3 * n] - (double)e->prev_x;
     double r_y = fabs(o[3 * n + 1] - 0.0);
     double r_col = fabs(o[3 * n + 7]) > P.collision_force ? P.collision_penalty : 0.0;
@@ -1395,9 +1397,11 @@ int32_t orc_last_normal_impulses(const orc_env* e, double* out, int32_t maxc) {
  * SURVEY.md 8(d)) for warmup + steps batched env-steps with the worker's auto-reset, on n_threads threads
  * (static partition of the envs, one barrier per batched step like SubprocVecEnv.step_wait,
  * ppo/multiprocessing_env.py:125).  No Python in the timed loop.  Returns the wall time of the `steps` timed
- * batched steps in seconds; *substeps_out = physics substeps executed in them. */
+ * batched steps in seconds; *substeps_out = physics substeps executed in them; agg (optional, 4 doubles): episode
+ * ends, summed reward, summed x displacement of the env-steps (terminal x - x at the start of the step) and summed
+ * contact counts of the env-steps' last substeps, over the timed steps. */
 double orc_bench_gait(const orc_params* p, int32_t n_envs, const double* phases, const double* mu_plane_or_null,
-                      int32_t warmup, int32_t steps, int32_t n_threads, int64_t* substeps_out) {
+                      int32_t warmup, int32_t steps, int32_t n_threads, int64_t* substeps_out, double* agg_or_null) {
     if (n_threads < 1) n_threads = 1;
     if (n_threads > n_envs) n_threads = n_envs;
     std::vector<orc_env*> envs(n_envs);
@@ -1419,6 +1423,7 @@ double orc_bench_gait(const orc_params* p, int32_t n_envs, const double* phases,
         else cv.wait(lk, [&] { return generation != gen; });
     };
     std::vector<int64_t> sub(n_threads, 0);
+    std::vector<double> agg(4 * n_threads, 0.0);      /* per thread: episode ends, reward, net x displacement, contacts */
     std::chrono::steady_clock::time_point t0, t1;
     auto worker = [&](int t) {
         std::vector<double> act(A), obs(O);
@@ -1431,8 +1436,13 @@ double orc_bench_gait(const orc_params* p, int32_t n_envs, const double* phases,
                 for (int k = 0; k < A; k++) act[k] = -std::sin((2 * k + 1) * 4.0 + 2.0 * (0.1 * j) + phases[e]);
                 double rew;
                 int32_t done, cnt;
+                const double x0 = (double)envs[e]->pos[0];
                 orc_env_step(envs[e], act.data(), 1, obs.data(), &rew, &done, &cnt);
-                if (j >= warmup) sub[t] += cnt;
+                if (j >= warmup) {
+                    sub[t] += cnt;
+                    agg[4 * t] += done; agg[4 * t + 1] += rew; agg[4 * t + 2] += envs[e]->last_terminal_x - x0;
+                    agg[4 * t + 3] += (double)envs[e]->contacts.size();
+                }
             }
             barrier();
         }
@@ -1445,6 +1455,11 @@ double orc_bench_gait(const orc_params* p, int32_t n_envs, const double* phases,
     int64_t total = 0;
     for (int t = 0; t < n_threads; t++) total += sub[t];
     if (substeps_out) *substeps_out = total;
+    if (agg_or_null)
+        for (int k = 0; k < 4; k++) {
+            agg_or_null[k] = 0;
+            for (int t = 0; t < n_threads; t++) agg_or_null[k] += agg[4 * t + k];
+        }
     for (int e = 0; e < n_envs; e++) orc_destroy(envs[e]);
     return std::chrono::duration<double>(t1 - t0).count();
 }

@@ -148,10 +148,11 @@ int32_t  orc_last_normal_impulses(const orc_env* e, double* out, int32_t max_con
 
 /* CPU-baseline driver for bench.py: n_envs envs x (warmup + steps) batched env-steps of the
  * serpenoid-gait stream on n_threads threads, timed inside (no Python in the loop).  Returns seconds for the
- * `steps` timed batched steps; *substeps_out = physics substeps executed in them. */
+ * `steps` timed batched steps; *substeps_out = physics substeps executed in them; agg4 (optional) = episode ends,
+ * summed reward, summed per-step x displacement, summed contact counts over the timed steps. */
 double   orc_bench_gait(const orc_params* p, int32_t n_envs, const double* phases,
                         const double* mu_plane_or_null, int32_t warmup, int32_t steps,
-                        int32_t n_threads, int64_t* substeps_out);
+                        int32_t n_threads, int64_t* substeps_out, double* agg4_or_null);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,201 @@
+"""GPU tests of the contact-model switches: Bullet's default import of a URDF
+<cylinder> as a 32-gon hull (`hull_sides=32`, /root/reference/snake.py:93 passes no URDF_USE_IMPLICIT_CYLINDER) and
+its persistent <= 4-point contact manifold (`contact_model=1`), in the HIP kernels and in the oracle alike.
+
+* substep parity from random ground states under every switch (float32 GPU vs float64 oracle, tolerances as in
+  tests/test_gpu_parity.py's ground case: positions 5e-4, joint velocities 5e-2 relative after 3 substeps), the
+  manifold contents compared point by point;
+* the schedule (slices moving between waves) must not change results with a contact cache in global memory;
+* checkpoints carry the cache;
+* the ERROR BAR of the unpinnable parity: rollout aggregates of the bench gait under {default, hull, hull + manifold,
+  hull + manifold at Bullet's relative breaking threshold}, GPU against oracle, written to
+  gpurun_out/contact_models.json (DESIGN.md 3 quotes it)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import random_state
+
+pytestmark = pytest.mark.gpu
+
+SWITCHES = {
+    "default": dict(),
+    "hull": dict(hull_sides=32),
+    "manifold": dict(contact_model=1),
+    "hull+manifold": dict(hull_sides=32, contact_model=1),
+}
+
+
+def _ground_states(B, n=16, seed=0):
+    rng = np.random.default_rng(seed)
+    S = np.zeros((B, 13 + 2 * n), np.float32)
+    for i in range(B):
+        s = random_state(rng, n, z=0.0, qamp=0.35, vamp=0.3, flat=True)
+        s[0:3] = [rng.uniform(-0.1, 0.1), rng.uniform(-0.1, 0.1), rng.uniform(-0.002, 0.004)]
+        s[7:13] *= 0.3
+        S[i] = s
+    return S
+
+
+@pytest.mark.parametrize("name", ["hull", "manifold", "hull+manifold"])
+def test_substep_parity_under_contact_switch(pkg, oracle_mod, name):
+    over = SWITCHES[name]
+    B, n, K = 48, 16, 3
+    st = pkg.Stepper(B, residual_threshold=0.0, **over)
+    S = _ground_states(B, n, seed=3)
+    st.set_state(S, np.zeros((B, n + 2), np.float32))
+    rng = np.random.default_rng(5)
+    T = rng.uniform(-0.4, 0.4, (B, n)).astype(np.float32)
+    manifold = over.get("contact_model") == 1
+    refs = []
+    for i in range(B):
+        e = oracle_mod.OracleEnv(residual_threshold=0.0, max_contacts=64, **over)
+        e.set_state(S[i].astype(np.float64))
+        refs.append(e)
+    bad = 0
+    worst_p, worst_v = 0.0, 0.0
+    alive = np.ones(B, bool)
+    for k in range(K):
+        info = st.substep(T, 1)
+        G, _ = st.get_state()
+        M = st.get_manifold() if manifold else None
+        for i in range(B):
+            e = refs[i]
+            e.substep(T[i].astype(np.float64))
+            if not alive[i]:
+                continue
+            if e.last_num_contacts != info[i, 1]:
+                alive[i] = False          # a threshold decision (breaking distance / cache merge) fell the other way
+                bad += 1
+                continue
+            ref = e.get_state()
+            worst_p = max(worst_p, np.abs(G[i, :7] - ref[:7]).max(), np.abs(G[i, 13:13 + n] - ref[13:13 + n]).max())
+            worst_v = max(worst_v, (np.abs(G[i, 13 + n:] - ref[13 + n:]) / (1 + np.abs(ref[13 + n:]))).max())
+            if manifold:
+                mo = e.get_manifold()
+                assert np.array_equal(M[i, :, 0], mo[:, 0]), (i, k)
+                for c in range(2 * n):
+                    cnt = int(mo[c, 0])
+                    assert np.abs(M[i, c, 1:1 + 6 * cnt] - mo[c, 1:1 + 6 * cnt]).max(initial=0.0) < 2e-4, (i, k, c)
+    print(name, "substep parity: worst pos", worst_p, "worst rel qd", worst_v, "threshold flips", bad, "of", B)
+    assert bad <= B // 6
+    assert worst_p < 5e-4 and worst_v < 5e-2
+    if manifold:
+        counts = st.get_manifold()[:, :, 0]
+        assert counts.max() <= 4 and counts.sum() > 0
+    st.close()
+
+
+def test_manifold_accumulates_and_drops_points(pkg, oracle_mod):
+    """Known-answer behaviour of the cache: from an empty manifold every resting cylinder gains one point per step
+    (its deepest vertex), the second end cap follows once the first has settled; a soft reset keeps the cache [U], the
+    first step after it drops the points that have drifted more than the breaking threshold from the teleported links."""
+    B, n = 4, 16
+    st = pkg.Stepper(B, hull_sides=32, contact_model=1)
+    st.reset()
+    T = np.zeros((B, n), np.float32)
+    st.substep(T, 1)
+    c1 = st.get_manifold()[:, :, 0]
+    assert np.all(c1 == 1)                                  # one new point per cylinder per step
+    st.substep(T, 30)
+    c2 = st.get_manifold()[:, :, 0]
+    assert c2.max() <= 4 and c2.mean() > 1.2                # both end caps of most cylinders by now
+    # drive away, then soft-reset: cached ground points are now far from the links' points
+    import bench
+    for j in range(4):
+        st.step(bench.gait_actions(np.arange(B), j).astype(np.float32))
+    S, X = st.get_state()
+    S[:, 0] += 0.5                                          # teleport 0.5 m: every cached point has drifted
+    st.set_state(S, X)
+    before = st.get_manifold()[:, :, 0].sum()
+    st.substep(T, 1)
+    after = st.get_manifold()[:, :, 0]
+    assert before > 0 and np.all(after <= 1)                # all old points dropped, at most the new one kept
+    st.close()
+
+
+def test_schedule_and_checkpoint_with_contact_cache(pkg, monkeypatch, tmp_path):
+    """The contact cache lives in global memory and moves between waves with the env-step's slices: results must not
+    depend on the schedule (SNK_QUANTUM 0 = unscheduled, 1, 3), and a checkpoint must carry it."""
+    import bench
+    B = 3000
+    ids = np.arange(B)
+
+    def run(quantum, ckpt=None):
+        monkeypatch.setenv("SNK_QUANTUM", str(quantum))
+        st = pkg.Stepper(B, hull_sides=32, contact_model=1)
+        st.reset()
+        outs = []
+        for j in range(4):
+            if ckpt is not None and j == 2:
+                pkg.save_state(st, ckpt)
+            o, r, d, s = st.step((bench.gait_actions(ids, j) * 1.1).astype(np.float32))
+            outs.append((o.copy(), r.copy(), d.copy(), s.copy()))
+        S, X = st.get_state()
+        M = st.get_manifold()
+        st.close()
+        return outs, S, X, M
+
+    path = str(tmp_path / "mf.npz")
+    ref, S0, X0, M0 = run(0, ckpt=path)
+    assert M0[:, :, 0].sum() > B * 16
+    for quantum in (1, 3):
+        got, S, X, M = run(quantum)
+        for g, w in zip(got, ref):
+            for x, y in zip(g, w):
+                assert np.array_equal(x, y)
+        assert np.array_equal(S, S0) and np.array_equal(X, X0) and np.array_equal(M, M0)
+    # resume from the checkpoint taken before step 2 in a fresh handle
+    monkeypatch.setenv("SNK_QUANTUM", "1")
+    st = pkg.Stepper(B, hull_sides=32, contact_model=1)
+    pkg.load_state(st, path)
+    for j in (2, 3):
+        o, r, d, s = st.step((bench.gait_actions(ids, j) * 1.1).astype(np.float32))
+        assert np.array_equal(o, ref[j][0]) and np.array_equal(r, ref[j][1]) and np.array_equal(s, ref[j][3])
+    st.close()
+
+
+def test_contact_model_error_bar(pkg, oracle_mod):
+    """What the three contact models do to what a trainer sees: bench gait, 32 envs x 200 env-steps, auto-reset on.
+    GPU (float32, free running) against the oracle (float64, free running) under each switch; the spread BETWEEN the
+    switches is the error bar on the parity that cannot be pinned without PyBullet."""
+    import bench
+    B, T = 32, 200
+    ids = np.arange(B)
+    switches = dict(SWITCHES)
+    switches.pop("manifold")
+    switches["hull+manifold@1.2mm"] = dict(hull_sides=32, contact_model=1, breaking_threshold=0.0012)
+    threads = min(16, len(os.sched_getaffinity(0)))
+    report = {}
+    for name, over in switches.items():
+        st = pkg.Stepper(B, **over)
+        st.reset()
+        g = np.zeros(5)
+        for j in range(T):
+            x0 = st.get_state()[0][:, 0].astype(np.float64)
+            a = bench.gait_actions(ids, j).astype(np.float32)
+            o, r, d, s = st.step(a, vec_mode=False)              # terminal obs: x at the end of the step
+            g += [s.sum(), d.sum(), r.sum(), (o[:, 48] - x0).sum(), 0]
+            if d.any():        # the SubprocVecEnv worker's extra reset() (multiprocessing_env.py:14-15): _observation
+                S, X = st.get_state()                            # = reset obs, so the next reward starts from x = 0
+                X[d, 16 + 1] = 0.0
+                st.set_state(S, X)
+        st.close()
+        g /= B * T
+        _, _, agg = oracle_mod.bench_gait(B, bench.env_phases(ids), 0, T, threads, want_agg=True, max_contacts=64, **over)
+        report[name] = dict(gpu=dict(mean_substeps=g[0], episode_end_rate=g[1], mean_reward=g[2], mean_dx=g[3]),
+                            oracle={k: float(v) for k, v in agg.items()})
+        print("%-22s GPU substeps %.3f ends %.4f reward %.5f dx %.5f | oracle substeps %.3f ends %.4f reward %.5f dx %.5f contacts %.1f"
+              % (name, g[0], g[1], g[2], g[3], agg["mean_substeps"], agg["episode_end_rate"], agg["mean_reward"],
+                 agg["mean_dx"], agg["mean_contacts"]))
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(os.path.join("gpurun_out", "contact_models.json"), "w") as f:
+        json.dump(report, f, indent=1)
+    for name, r in report.items():
+        g, o = r["gpu"], r["oracle"]
+        assert abs(g["mean_substeps"] - o["mean_substeps"]) < 0.02 * o["mean_substeps"], (name, g, o)
+        assert abs(g["episode_end_rate"] - o["episode_end_rate"]) < 0.02, (name, g, o)
+        assert abs(g["mean_dx"] - o["mean_dx"]) < 0.15 * abs(o["mean_dx"]) + 2e-4, (name, g, o)
+        assert abs(g["mean_reward"] - o["mean_reward"]) < 0.05 * abs(o["mean_reward"]) + 0.01, (name, g, o)
