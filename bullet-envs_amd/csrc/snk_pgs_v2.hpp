@@ -669,6 +669,99 @@ __device__ __forceinline__ void cone_step(float& RJ, const float RM, const float
     if (RES) asm volatile("v_max3_f32 %[lsq], %[lsq], |%[r2]|, |%[c2]|" : [lsq] "+v"(lsq) : [r2] "v"(r2), [c2] "v"(c2));
 }
 
+// TWO consecutive friction pairs (contacts c0, c0+1) in one step, hand-written, 52 VALU against 2 x 28: the two
+// reductions run interleaved (each DPP step is the other's wait state, no s_nop at all), and the second pair still
+// sees the first pair's update exactly as in the sequential sweep: its two sums are corrected by
+//     c(X2,A1) dI_A1 + c(X2,B1) dI_B1,   c(X2,Y1) = RJ_X2 . RM_Y1   (X, Y in {A, B}),
+// four scalars per pair of contacts, computed once per substep (cone2_couplings) and kept in spare lanes of RJ2
+// (d = 30: coupling with A1, d = 29: with B1) so that two v_fmac_f32_dpp (row_shr:1 / row_shr:2) add them to lanes
+// 31 / 63 of the partial sums without any scalar traffic.  Same arithmetic per row as cone_step; what changes is
+// the dependency chain (one reduction + one scalar round trip per two pairs instead of two).
+#define SNK_RED2(MODE)                                        \
+    "v_add_f32_dpp %[t1], %[t1], %[t1] " MODE "\n\t"           \
+    "v_add_f32_dpp %[t2], %[t2], %[t2] " MODE "\n\t"
+template <bool RES>
+__device__ __forceinline__ void cone2_step(float& RJ1, const float RM1, float& RJ2, const float RM2, const float RJnorm,
+                                           float& dv, float EPS, float E3163, unsigned long long lowmask, float& lsq) {
+    float t1, t2, x1A, x1B, x2A, x2B;
+    float a1A, a1B, a2A, a2B, l1, l2, s1A, s1B, s2A, s2B;
+    asm volatile(
+        "v_mul_f32 %[t1], %[RJ1], %[dv]\n\t"
+        "v_mul_f32 %[t2], %[RJ2], %[dv]\n\t"
+        "v_readlane_b32 %[a1A], %[RJ1], 31\n\t"
+        "v_readlane_b32 %[a1B], %[RJ1], 63\n\t"
+        SNK_RED2("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1")
+        "v_readlane_b32 %[a2A], %[RJ2], 31\n\t"
+        "v_readlane_b32 %[a2B], %[RJ2], 63\n\t"
+        SNK_RED2("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1")
+        "v_readlane_b32 %[l1], %[RJn], 31\n\t"
+        "v_readlane_b32 %[l2], %[RJn], 63\n\t"
+        SNK_RED2("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+        "v_mov_b32 %[x1A], %[a1A]\n\t"
+        "v_mov_b32 %[x1B], %[a1B]\n\t"
+        SNK_RED2("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+        "v_mov_b32 %[x2A], %[a2A]\n\t"
+        "v_mov_b32 %[x2B], %[a2B]\n\t"
+        SNK_RED2("row_bcast:15 row_mask:0xa bank_mask:0xf")
+        "v_readlane_b32 %[s1A], %[t1], 31\n\t"
+        "v_readlane_b32 %[s1B], %[t1], 63\n\t"
+        "s_nop 0\n\t"
+        // first pair: radial projection onto the disc of radius lambda_n (rows are in units of mu)
+        "v_fma_f32 %[t1], %[s1A], %[s1A], %[EPS]\n\t"
+        "v_fma_f32 %[t1], %[s1B], %[s1B], %[t1]\n\t"
+        "v_rsq_f32 %[t1], %[t1]\n\t"
+        "s_nop 0\n\t"
+        "v_mul_f32_e64 %[t1], %[l1], %[t1] clamp\n\t"
+        "v_fma_f32 %[x1A], %[t1], -%[s1A], -%[x1A]\n\t"
+        "v_fma_f32 %[x1B], %[t1], -%[s1B], -%[x1B]\n\t"
+        // the second pair sees it: lanes 31 / 63 of t2 += RJ2[30 / 62] dI_A1 + RJ2[29 / 61] dI_B1
+        "v_fmac_f32_dpp %[t2], %[RJ2], %[x1A] row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_fmac_f32_dpp %[t2], %[RJ2], %[x1B] row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_cndmask_b32_e64 %[x1A], %[x1B], %[x1A], %[lowmask]\n\t"
+        "v_readlane_b32 %[s2A], %[t2], 31\n\t"
+        "v_readlane_b32 %[s2B], %[t2], 63\n\t"
+        "v_mul_f32 %[x1B], %[RM1], %[x1A]\n\t"
+        "v_fmac_f32 %[RJ1], %[E], %[x1A]\n\t"
+        // second pair
+        "v_fma_f32 %[t1], %[s2A], %[s2A], %[EPS]\n\t"
+        "v_fma_f32 %[t1], %[s2B], %[s2B], %[t1]\n\t"
+        "v_rsq_f32 %[t1], %[t1]\n\t"
+        "s_nop 0\n\t"
+        "v_mul_f32_e64 %[t1], %[l2], %[t1] clamp\n\t"
+        "v_fma_f32 %[x2A], %[t1], -%[s2A], -%[x2A]\n\t"
+        "v_fma_f32 %[x2B], %[t1], -%[s2B], -%[x2B]\n\t"
+        "v_cndmask_b32_e64 %[x2A], %[x2B], %[x2A], %[lowmask]\n\t"
+        "v_mul_f32 %[x2B], %[RM2], %[x2A]\n\t"
+        "v_fmac_f32 %[RJ2], %[E], %[x2A]\n\t"
+        : [t1] "=&v"(t1), [t2] "=&v"(t2), [x1A] "=&v"(x1A), [x1B] "=&v"(x1B), [x2A] "=&v"(x2A), [x2B] "=&v"(x2B),
+          [a1A] "=&s"(a1A), [a1B] "=&s"(a1B), [a2A] "=&s"(a2A), [a2B] "=&s"(a2B), [l1] "=&s"(l1), [l2] "=&s"(l2),
+          [s1A] "=&s"(s1A), [s1B] "=&s"(s1B), [s2A] "=&s"(s2A), [s2B] "=&s"(s2B), [RJ1] "+v"(RJ1), [RJ2] "+v"(RJ2)
+        : [RM1] "v"(RM1), [RM2] "v"(RM2), [RJn] "v"(RJnorm), [dv] "v"(dv), [EPS] "v"(EPS), [E] "v"(E3163),
+          [lowmask] "s"(lowmask));
+    // x1B = RM1 dI_1, x2B = RM2 dI_2 (lane 24 / 56: den dI of the A / B rows: the residual)
+    if (RES) asm volatile("v_max3_f32 %[lsq], %[lsq], |%[p1]|, |%[p2]|" : [lsq] "+v"(lsq) : [p1] "v"(x1B), [p2] "v"(x2B));
+    asm volatile(
+        "v_add_f32 %[p1], %[p1], %[p2]\n\t"
+        "v_mov_b32 %[p2], %[p1]\n\t"
+        "s_nop 1\n\t"
+        "v_permlane32_swap_b32 %[p1], %[p2]\n\t"
+        "v_add_f32 %[dv], %[dv], %[p1]\n\t"
+        "v_add_f32 %[dv], %[dv], %[p2]\n\t"
+        : [p1] "+v"(x1B), [p2] "+v"(x2B), [dv] "+v"(dv));
+}
+
+// The four coupling scalars of cone2_step for the friction slots (S, S+1) of two consecutive contacts, written into
+// lanes d = 30 (with A1) and d = 29 (with B1) of both halves of RJ[S+1].
+__device__ __forceinline__ void cone2_coupling(const float RM1, float& RJ2, int lane) {
+    const swap2 sw = half_swap(RM1, RM1);                 // a = [RM_A1, RM_A1], b = [RM_B1, RM_B1]
+    const float tA = half_reduce(RJ2 * sw.a);             // lane 31: c(A2,A1), lane 63: c(B2,A1)
+    const float tB = half_reduce(RJ2 * sw.b);             // lane 31: c(A2,B1), lane 63: c(B2,B1)
+    const float mA = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(tA), 0x101, 0xf, 0xf, true));   // row_shl:1
+    const float mB = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(tB), 0x102, 0xf, 0xf, true));   // row_shl:2
+    const int d = lane & 31;
+    RJ2 = d == 30 ? mA : (d == 29 ? mB : RJ2);
+}
+
 // A motor row has a unit Jacobian (J = e_{6+j}), so its dot is just delta-v of that joint, and
 // with the row written in units of 1/den (impulse variable y = dI * den; RMm = M^-1[:, 6+j] / den)
 // every lane 6+j evaluates its own motor's candidate  y = target - dv  (Bullet's
@@ -720,16 +813,16 @@ __device__ __forceinline__ void duos4(float (&RJ)[kSlots], float (&RM)[kSlots], 
     for (int s = BASE; s < BASE + 4; s++) duo_step<RES, false>(RJ[s], RM[s], dv, 0.f, E3163, kLowMask, lsq);
 }
 
-// eight consecutive friction pairs (contacts 8G..8G+7); the normal impulse of contact ci sits
-// in slot kSlotNormal + ci/2, lane 31 (even ci) or 63 (odd ci)
+// eight consecutive friction pairs (contacts 8G..8G+7), two contacts per step; the normal impulses of contacts
+// c0, c0+1 sit in slot kSlotNormal + c0/2, lanes 31 and 63
 template <bool RES, int G>
 __device__ __forceinline__ void cones8(float (&RJ)[kSlots], float (&RM)[kSlots], float& dv, float EPS,
                                        float E3163, float& lsq) {
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const int c0 = 8 * G + 2 * i;
-        cone_step<31, RES>(RJ[kSlotFric + c0], RM[kSlotFric + c0], RJ[kSlotNormal + (c0 >> 1)], dv, EPS, E3163, kLowMask, lsq);
-        cone_step<63, RES>(RJ[kSlotFric + c0 + 1], RM[kSlotFric + c0 + 1], RJ[kSlotNormal + (c0 >> 1)], dv, EPS, E3163, kLowMask, lsq);
+        cone2_step<RES>(RJ[kSlotFric + c0], RM[kSlotFric + c0], RJ[kSlotFric + c0 + 1], RM[kSlotFric + c0 + 1],
+                        RJ[kSlotNormal + (c0 >> 1)], dv, EPS, E3163, kLowMask, lsq);
     }
 }
 
@@ -922,6 +1015,19 @@ __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane, f
                 swap2 sw = half_swap(RM[s], RM[s]);
                 float t = half_reduce(RJ[s] * sw.a);
                 RJ[s] = wrlane(RJ[s], rdlane(t, 63), 57);
+            }
+        } else {
+            // cone friction resolves two contacts per step (cone2_step): the 2 x 2 coupling block of each pair of
+            // contacts, groups of 8 contacts behind one scalar branch (rows past the active count are zero anyway)
+#pragma unroll
+            for (int g = 0; g < 8; g++) {
+                if (nc > 8 * g) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const int s = kSlotFric + 8 * g + 2 * i;
+                        cone2_coupling(RM[s], RJ[s + 1], lane);
+                    }
+                }
             }
         }
     }

@@ -37,6 +37,7 @@ def test_c5_env_step_parity_friction_config(pkg, oracle_mod):
     err = {b: dict(q=[], qd=[], r=[]) for b in ("low", "high")}
     cal = {b: dict(q=[], qd=[], r=[]) for b in ("low", "high")}
     mism = 0
+    cal_mism = 0
     dones = 0
     for j in range(J):
         S, X = st.get_state()
@@ -59,6 +60,8 @@ def test_c5_env_step_parity_friction_config(pkg, oracle_mod):
             if k32 == k and d32 == d:
                 for key, v in zip(("q", "qd", "r"), errs(o32, r32)):
                     cal[band][key].append(v)
+            else:
+                cal_mism += 1
             if k != sub[i] or d != bool(done[i]):
                 mism += 1
                 assert abs(k - sub[i]) <= 1, (i, j, k, sub[i], d, done[i], mu32[i])
@@ -76,7 +79,10 @@ def test_c5_env_step_parity_friction_config(pkg, oracle_mod):
             assert g50 <= 2 * c50 + floors[key], (band, key, g50, c50)
             assert g90 <= 2 * c90 + floors[key], (band, key, g90, c90)
             assert gmx <= 3 * cmx + 10 * floors[key], (band, key, gmx, cmx)
-    assert mism <= max(1, B * J // 20), mism
+    # substep counts / done flags that differ by one at a decision boundary (servo tolerance, height, angle): as many
+    # as the float32 oracle itself shows against float64 on these steps, within a factor of two
+    print("configs[4] boundary mismatches: GPU-f32", mism, "oracle-f32", cal_mism, "of", B * J)
+    assert mism <= max(B * J // 20, 2 * cal_mism + 2), (mism, cal_mism)
     assert dones > 0            # resets happened under varied friction inside the compared steps
     st.close()
 
