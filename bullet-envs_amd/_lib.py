@@ -19,6 +19,7 @@ class SnkParams(C.Structure):
         ("n_modules", C.c_int32), ("inertia_from_file", C.c_int32),
         ("default_mass", C.c_double), ("collision_margin", C.c_double),
         ("hull_sides", C.c_int32), ("contact_model", C.c_int32),
+        ("self_collision", C.c_int32), ("reserved0", C.c_int32),
         ("dt", C.c_double), ("gravity_z", C.c_double),
         ("lin_damping", C.c_double), ("ang_damping", C.c_double),
         ("joint_damping", C.c_double), ("max_coord_vel", C.c_double),

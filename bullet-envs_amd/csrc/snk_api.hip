@@ -178,6 +178,7 @@ void snk_default_params(snk_params* p) {
     p->collision_margin = 0.001;
     p->hull_sides = 0;
     p->contact_model = 0;
+    p->self_collision = 1;      // the reference loads the snake with URDF_USE_SELF_COLLISION (snake.py:93)
     p->dt = 1.0 / 240.0;
     p->gravity_z = -9.8;
     p->lin_damping = 0.04;

@@ -148,23 +148,30 @@ struct Lds<N, false> : LdsCommon<N> {
     // to anything else; they live in a per-environment block of global memory that the solve
     // streams once per iteration (see pgs_v1): kRows rows of J, then kRows rows of M^-1 J^T.
     static constexpr int kRing = 32;                       // contacts per loop trip of the solve
-    static constexpr int kRows = NR + 6 * kRing + 3;       // + inert padding, the refill's over-read, 3 rows always zero
+    // link-link (self-collision) contacts follow the ground contacts in the compact list: at most kMaxSelf of them,
+    // geometry slots NC .. NC + kMaxSelf - 1; the per-contact scalars cN / cF already have kRing entries of padding
+    static constexpr int kMaxSelf = kRing;
+    static constexpr int NCT = NC + kMaxSelf;              // contact slots in all
+    static constexpr int kRows = 3 * NCT + 6 * kRing + 3;  // + inert padding, the refill's over-read, 3 rows always zero
     // a row of the block: [J (ND floats), pad, M^-1 J^T (ND floats), pad], 320 B = five aligned 64-B
     // sectors for 304 useful bytes (separate, unaligned 152-B rows fetched 1.4x their size)
     static constexpr int kRS = 80;                         // floats per row of the block
     static constexpr int kMO = 40;                         // float offset of the M^-1 J^T half
     static_assert(ND <= kMO, "row layout");
-    // behind the rows: the contact geometry of the NC slots, 12 floats each: P[3], distance, friction
-    // direction A[3], B[3], pad[2] (written lane = slot by find_contacts_v1, read by the row builder
-    // and the sensor pass)
-    static constexpr int kGeo = 12;
+    // behind the rows: the contact geometry of the NCT slots, 20 floats each: P[3] (point on body kA), distance,
+    // friction direction A[3], B[3], normal[3], PB[3] (point on body kB), kA, kB (-1: the ground), friction scale,
+    // pad (written lane = slot by find_contacts_v1 / find_self_contacts_v1, read by the row builder and the
+    // sensor pass)
+    static constexpr int kGeo = 20;
     static constexpr size_t kGeoOff = (size_t)kRows * kRS;
-    static constexpr size_t kRowFloats = kGeoOff + (size_t)NC * kGeo;
+    static constexpr size_t kRowFloats = kGeoOff + (size_t)NCT * kGeo;
     // per-contact scalars of the rows, grouped the way the solve reads them (one ds_read_b128 each):
     //   cN[ci] = {rhs, den, accumulated impulse, 1/den} of the normal row 3ci
     //   cF[ci] = {rhsA, rhsB, denA, denB | accA, accB, 1/denA, 1/denB} of the friction rows 3ci+1, 3ci+2
     alignas(16) float cN[NC + kRing + 1][4];
     alignas(16) float cF[NC + kRing + 1][8];
+    static_assert(NCT <= NC + kRing, "the scalars of the link-link contacts live in the ring's padding entries");
+    int nplane;                  // ground contacts of this substep (the link-link contacts follow them)
 };
 
 // v2: rows live in VGPRs during the solve; LDS only stages one 64-row batch while they are built
@@ -392,6 +399,9 @@ __device__ int find_contacts_v1(LT& L, const DevModel& M, int lane, float* __res
             f3 l2 = mulRtv(Rw, mk3(1.f, 0.f, 0.f));
             st3(geo + 4, mulRv(Rw, mk3(l1.x * a.x, l1.y * a.y, l1.z * a.z)));
             st3(geo + 7, mulRv(Rw, mk3(l2.x * a.x, l2.y * a.y, l2.z * a.z)));
+            st3(geo + 10, mk3(0.f, 0.f, 1.f));
+            st3(geo + 13, mk3(0.f, 0.f, 0.f));
+            geo[16] = (float)b; geo[17] = -1.0f; geo[18] = 1.0f;
         }
         unsigned long long bal = __ballot(active);
         if (slot < 4 * N) L.cidx[slot] = -1;
@@ -404,6 +414,10 @@ __device__ int find_contacts_v1(LT& L, const DevModel& M, int lane, float* __res
     }
     return total;
 }
+
+}  // namespace snk
+#include "snk_selfcol.hpp"
+namespace snk {
 
 // ----------------------------------------------------------------------------------
 // S3: ABA sweeps, evaluated uniformly by the wave (serial recurrence over the chain).
@@ -602,9 +616,9 @@ __device__ void build_rows_v1(LT& L, const DevModel& M, int lane, int nc, int& n
     const float* gb = L.base() + 7;   // omega_w, v_w (after the unconstrained update)
     for (int rid = lane; rid < nrows; rid += 64) {
         const bool motor = rid < N;
-        int k, slot = 0, kind = 0;
-        f3 P = mk3(0, 0, 0), d = mk3(0, 0, 0);
-        float cdist_slot = 0.f;
+        int k, slot = 0, kind = 0, kB = -1;
+        f3 P = mk3(0, 0, 0), d = mk3(0, 0, 0), PB = mk3(0, 0, 0);
+        float cdist_slot = 0.f, fscale = 1.0f;
         float* Mrow;             // final row of M^-1 J^T: LDS for a motor, global memory for a contact row
         float* Jrow = nullptr;   // final J row (contact rows only)
         float uu[N];             // joint-space residuals between the two sweeps, in registers (both sweeps are fully unrolled)
@@ -614,12 +628,16 @@ __device__ void build_rows_v1(LT& L, const DevModel& M, int lane, int nc, int& n
         } else {
             const int ci = (rid - N) / 3;
             kind = (rid - N) - 3 * ci;
-            slot = L.clist[ci];
-            k = ((slot >> 1) + 1) >> 1;
+            // ground contacts first (slot = cylinder end cap), then the link-link contacts (slots NC ...)
+            slot = ci < L.nplane ? L.clist[ci] : LT::NC + (ci - L.nplane);
             const float* geo = rows + LT::kGeoOff + (size_t)slot * LT::kGeo;
             P = ld3(geo);
-            d = kind == 0 ? mk3(0.f, 0.f, 1.f) : (kind == 1 ? ld3(geo + 4) : ld3(geo + 7));
+            d = kind == 0 ? ld3(geo + 10) : (kind == 1 ? ld3(geo + 4) : ld3(geo + 7));
             cdist_slot = geo[3];
+            k = (int)geo[16];
+            kB = (int)geo[17];                  // -1: the ground
+            PB = ld3(geo + 13);
+            if (kind != 0) fscale = geo[18];    // friction rows of a link-link contact: see find_self_contacts_v1
             Jrow = rows + (size_t)(rid - N) * LT::kRS;
             Mrow = Jrow + LT::kMO;
         }
@@ -631,6 +649,10 @@ __device__ void build_rows_v1(LT& L, const DevModel& M, int lane, int nc, int& n
             if (!motor && b == k) {
                 pN = pN - cross(P - ld3(L.o[b]), d);
                 pF = pF - d;
+            }
+            if (!motor && b == kB) {          // the opposite unit impulse on the other body of a link-link contact
+                pN = pN + cross(PB - ld3(L.o[b]), d);
+                pF = pF + d;
             }
             float u = -dot(ax, pN);
             if (motor && b == k) u += 1.0f;
@@ -645,6 +667,12 @@ __device__ void build_rows_v1(LT& L, const DevModel& M, int lane, int nc, int& n
             J0 = cross(P - ld3(L.o[0]), d);
             J1 = d;
             if (k == 0) { pN = pN - J0; pF = pF - d; }
+            if (kB >= 0) {
+                const f3 JB = cross(PB - ld3(L.o[0]), d);
+                if (kB == 0) { pN = pN + JB; pF = pF + d; }
+                J0 = J0 - JB;                 // both bodies ride on the base: its rows see the pair's net wrench only
+                J1 = mk3(0.f, 0.f, 0.f);
+            }
         }
         float p0[6] = {pN.x, pN.y, pN.z, pF.x, pF.y, pF.z}, a0[6];
 #pragma unroll
@@ -653,7 +681,7 @@ __device__ void build_rows_v1(LT& L, const DevModel& M, int lane, int nc, int& n
 #pragma unroll
             for (int j = 0; j < 6; j++) s -= L.Inv0[6 * i + j] * p0[j];
             a0[i] = s;
-            Mrow[i] = s;
+            Mrow[i] = s * fscale;
         }
         f3 al = mk3(a0[0], a0[1], a0[2]), a = mk3(a0[3], a0[4], a0[5]);
         float den = dot(J0, al) + dot(J1, a);
@@ -666,9 +694,10 @@ __device__ void build_rows_v1(LT& L, const DevModel& M, int lane, int nc, int& n
             float qdd = (u - (dot(ld3(L.Ua[b]), al) + dot(ld3(L.Ub[b]), a))) * L.Dinv[b];
             f3 ax = ld3(L.ax[b]);
             al = al + ax * qdd;
-            Mrow[6 + b - 1] = qdd;
+            Mrow[6 + b - 1] = qdd * fscale;
             if (!motor) {
                 float Jb = (b <= k) ? dot(ax, cross(P - ld3(L.o[b]), d)) : 0.f;
+                if (b <= kB) Jb -= dot(ax, cross(PB - ld3(L.o[b]), d));
                 Jrow[6 + b - 1] = Jb;
                 den += Jb * qdd;
                 rv += Jb * L.qd()[b - 1];
@@ -678,6 +707,7 @@ __device__ void build_rows_v1(LT& L, const DevModel& M, int lane, int nc, int& n
         }
         if (!motor) {
             const int row = rid - N;
+            den *= fscale;
             float dinv = den > 1.1920929e-7f ? 1.0f / den : 0.f;
             float target;
             if (kind == 0) {
@@ -1023,9 +1053,13 @@ __device__ void substep_v1(LT& L, const DevModel& M, int lane, float mu, int& it
     constexpr int ND = N + 6;
     const float dt = M.dt;
     // (1) contacts of the current pose, (2) bias forces with gravity, joint damping torque
-    const int nc = find_contacts_v1(L, M, lane, rows);
+    int nc = find_contacts_v1(L, M, lane, rows);
+    if (lane == 0) L.nplane = nc;
+    const int nplane = nc;
+    if (M.self_collision) nc += find_self_contacts_v1(L, M, lane, mu, rows);   // link-link contacts follow the ground's
     ncontacts = nc;
     __threadfence();      // contact geometry: written lane = slot, read lane = row
+    lds_sync();
     if (lane < N) {
         float qd = L.qd()[lane];
         L.qd_old[lane] = qd;
@@ -1073,6 +1107,17 @@ __device__ void substep_v1(LT& L, const DevModel& M, int lane, float mu, int& it
                     eF = eF + F;
                     eN = eN + cross(ld3(geo) - ld3(L.o[b]), F);
                 }
+            }
+            // link-link contacts: equal and opposite forces on the two bodies (friction back from the solve's units)
+            for (int ci = nplane; ci < nc; ci++) {
+                const float* geo = rows + LT::kGeoOff + (size_t)(LT::NC + ci - nplane) * LT::kGeo;
+                const int kA = (int)geo[16], kB2 = (int)geo[17];
+                if (kA != b && kB2 != b) continue;
+                const float fs = geo[18];
+                const f3 F = (ld3(geo + 10) * L.cN[ci][2] + ld3(geo + 4) * (L.cF[ci][4] * fs) +
+                              ld3(geo + 7) * (L.cF[ci][5] * fs)) * M.inv_dt;
+                if (kA == b) { eF = eF + F; eN = eN + cross(ld3(geo) - ld3(L.o[b]), F); }
+                if (kB2 == b) { eF = eF - F; eN = eN - cross(ld3(geo + 13) - ld3(L.o[b]), F); }
             }
             st3(&L.ext[b][0], eN);
             st3(&L.ext[b][3], eF);

@@ -55,7 +55,7 @@ struct DevModel {
     // contact model: hull_sides > 0 = the prism PyBullet imports a URDF <cylinder> as [U]; hull_xy[s] =
     // r (sin, cos)(2 pi s / hull_sides), the importer's vertex order; contact_model 1 = persistent manifold;
     // cyl_zoff = cylinder centre in its link's frame (snake.urdf:807,863), the manifold keeps link coordinates
-    int hull_sides, contact_model;
+    int hull_sides, contact_model, self_collision;
     float cyl_zoff;
     float hull_xy[32][2];
     // sensors
@@ -219,6 +219,7 @@ inline void build_dev_model(const snk_params& P, const HostModel& H, DevModel& D
     D.break_thr = (float)P.breaking_threshold; D.margin = (float)P.collision_margin;
     D.cyl_r = 0.026f; D.cyl_hl = 0.0165f;                               // snake.urdf:809
     D.hull_sides = P.hull_sides; D.contact_model = P.contact_model;
+    D.self_collision = (P.self_collision && n == 32) ? 1 : 0;    // only the streamed-row solve builds link-link rows
     D.cyl_zoff = 0.0183f;                                               // snake.urdf:807,863
     for (int s = 0; s < P.hull_sides && s < 32; s++) {
         const double th = 2.0 * 3.14159265358979323846 * s / P.hull_sides;

@@ -1,0 +1,286 @@
+// snk_selfcol.hpp -- link-link (self) collision of the snake's cylinders: what URDF_USE_SELF_COLLISION
+// (/root/reference/snake.py:93) switches on in PyBullet [U].  SURVEY.md 8(f)-2.
+//
+// Every pair of cylinder links except direct parent-child pairs (consecutive cylinders of the chain; the flag's
+// default excludes a link's parent) is tested each substep:
+//   broad phase   lane = cylinder a, one pass per offset b - a = 2, 3, ...: bounding spheres
+//   narrow phase  distance between the two convex CORE shapes (the 32-gon hull PyBullet imports a URDF <cylinder> as,
+//                 or the implicit cylinder; without margin) by GJK, as btGjkPairDetector does; the collision margins
+//                 come off the distance and the witness points move onto the inflated surfaces.  Cores that overlap
+//                 (more than both margins deep, where Bullet switches to EPA): a second GJK on cores shrunk by
+//                 kShrink with the margin enlarged by as much; if even those overlap, the line of centres.
+// One point per pair per step (stateless; Bullet caches up to four per pair), kept when closer than the breaking
+// threshold, at most kMaxSelf per environment, ordered by (b - a, a) -- the same rules as oracle/snake_oracle.cpp
+// (find_self_contacts), restated independently here in float32.
+//
+// Only the streamed-row solve (32-link chains) builds rows for these contacts: for the 16-link snake they can never
+// act inside the joint limits (tools/self_collision_clearance.py), and its register-resident solve has no slot left.
+#pragma once
+
+namespace snk {
+
+constexpr float kShrink = 0.006f;
+
+struct Cvx {
+    f3 c;           // world centre of the cylinder
+    float R[9];     // world rotation of the cylinder's link frame
+};
+
+// support point of the core shape (radius and half length reduced by `shrink`) in world direction dw
+__device__ __forceinline__ f3 support_core(const DevModel& M, const Cvx& s, f3 dw, float shrink) {
+    const f3 dl = mulRtv(s.R, dw);
+    const float rad = M.cyl_r - shrink, hl = M.cyl_hl - shrink;
+    f3 v;
+    if (M.hull_sides > 0) {
+        const float sc = rad / M.cyl_r;
+        float best = -3.0e38f;
+        v = mk3(0.f, 0.f, 0.f);
+        for (int k = 0; k < 2 * M.hull_sides; k++) {
+            const f3 c = mk3(M.hull_xy[k >> 1][0] * sc, M.hull_xy[k >> 1][1] * sc, (k & 1) ? -hl : hl);
+            const float val = dot(dl, c);
+            if (val > best) { best = val; v = c; }
+        }
+    } else {
+        const float rr = sqrtf(dl.x * dl.x + dl.y * dl.y);
+        v = rr != 0.f ? mk3(rad * dl.x / rr, rad * dl.y / rr, 0.f) : mk3(rad, 0.f, 0.f);
+        v.z = dl.z < 0.f ? -hl : hl;
+    }
+    return s.c + mulRv(s.R, v);
+}
+
+struct Simplex {
+    int n;
+    f3 W[4], A[4], B[4];
+    float lam[4];
+};
+
+__device__ __forceinline__ void closest_segment(f3 a, f3 b, float* l2) {
+    const f3 ab = b - a;
+    const float t = -dot(a, ab), dd = dot(ab, ab);
+    if (t <= 0.f || dd <= 0.f) { l2[0] = 1.f; l2[1] = 0.f; }
+    else if (t >= dd) { l2[0] = 0.f; l2[1] = 1.f; }
+    else { l2[1] = t / dd; l2[0] = 1.f - l2[1]; }
+}
+// closest point of triangle abc to the origin, barycentric (Ericson, Real-Time Collision Detection 5.1.5)
+__device__ __forceinline__ void closest_triangle(f3 a, f3 b, f3 c, float* l3) {
+    const f3 ab = b - a, ac = c - a, ap = -a, bp = -b, cp = -c;
+    const float d1 = dot(ab, ap), d2 = dot(ac, ap);
+    if (d1 <= 0.f && d2 <= 0.f) { l3[0] = 1.f; l3[1] = 0.f; l3[2] = 0.f; return; }
+    const float d3 = dot(ab, bp), d4 = dot(ac, bp);
+    if (d3 >= 0.f && d4 <= d3) { l3[0] = 0.f; l3[1] = 1.f; l3[2] = 0.f; return; }
+    const float vc = d1 * d4 - d3 * d2;
+    if (vc <= 0.f && d1 >= 0.f && d3 <= 0.f) { const float v = d1 / (d1 - d3); l3[0] = 1.f - v; l3[1] = v; l3[2] = 0.f; return; }
+    const float d5 = dot(ab, cp), d6 = dot(ac, cp);
+    if (d6 >= 0.f && d5 <= d6) { l3[0] = 0.f; l3[1] = 0.f; l3[2] = 1.f; return; }
+    const float vb = d5 * d2 - d1 * d6;
+    if (vb <= 0.f && d2 >= 0.f && d6 <= 0.f) { const float w = d2 / (d2 - d6); l3[0] = 1.f - w; l3[1] = 0.f; l3[2] = w; return; }
+    const float va = d3 * d6 - d5 * d4;
+    if (va <= 0.f && (d4 - d3) >= 0.f && (d5 - d6) >= 0.f) {
+        const float w = (d4 - d3) / ((d4 - d3) + (d5 - d6));
+        l3[0] = 0.f; l3[1] = 1.f - w; l3[2] = w; return;
+    }
+    const float den = 1.0f / (va + vb + vc);
+    const float v = vb * den, w = vc * den;
+    l3[0] = 1.f - v - w; l3[1] = v; l3[2] = w;
+}
+
+// keeps the vertices idx[0..m-1] of S that carry positive weight
+__device__ __forceinline__ void simplex_keep(Simplex& S, const int* idx, const float* lam, int m) {
+    const Simplex T = S;
+    int k = 0;
+    for (int i = 0; i < m; i++) {
+        if (lam[i] <= 0.f) continue;
+        S.W[k] = T.W[idx[i]]; S.A[k] = T.A[idx[i]]; S.B[k] = T.B[idx[i]];
+        S.lam[k++] = lam[i];
+    }
+    S.n = k;
+}
+
+// closest point v of the simplex to the origin, the simplex reduced to the supporting sub-simplex; false when the
+// origin lies inside the tetrahedron
+__device__ __forceinline__ bool simplex_closest(Simplex& S, f3& v) {
+    if (S.n == 1) {
+        S.lam[0] = 1.f;
+    } else if (S.n == 2) {
+        float l[2];
+        closest_segment(S.W[0], S.W[1], l);
+        const int idx[2] = {0, 1};
+        simplex_keep(S, idx, l, 2);
+    } else if (S.n == 3) {
+        float l[3];
+        closest_triangle(S.W[0], S.W[1], S.W[2], l);
+        const int idx[3] = {0, 1, 2};
+        simplex_keep(S, idx, l, 3);
+    } else {
+        const int F[4][4] = {{0, 1, 2, 3}, {0, 2, 3, 1}, {0, 3, 1, 2}, {1, 3, 2, 0}};
+        float best = 3.0e38f, bl[3] = {0.f, 0.f, 0.f};
+        int bf = -1;
+        bool outside_any = false;
+        for (int f = 0; f < 4; f++) {
+            const f3 a = S.W[F[f][0]], b = S.W[F[f][1]], c = S.W[F[f][2]], d = S.W[F[f][3]];
+            const f3 nn = cross(b - a, c - a);
+            const float sp = -dot(a, nn), sd = dot(d - a, nn);
+            if (sp * sd >= 0.f && sd != 0.f) continue;
+            outside_any = true;
+            float l[3];
+            closest_triangle(a, b, c, l);
+            const f3 q = a * l[0] + b * l[1] + c * l[2];
+            const float dd = dot(q, q);
+            if (dd < best) { best = dd; bf = f; bl[0] = l[0]; bl[1] = l[1]; bl[2] = l[2]; }
+        }
+        if (!outside_any) { v = mk3(0.f, 0.f, 0.f); return false; }
+        const int idx[3] = {F[bf][0], F[bf][1], F[bf][2]};
+        simplex_keep(S, idx, bl, 3);
+    }
+    v = mk3(0.f, 0.f, 0.f);
+    for (int i = 0; i < S.n; i++) v = v + S.W[i] * S.lam[i];
+    return true;
+}
+
+// distance between the (shrunk) cores, witness points pa / pb; -1 when they overlap
+__device__ __noinline__ float gjk_distance(const DevModel& M, const Cvx& a, const Cvx& b, float shrink, f3& pa, f3& pb) {
+    Simplex S;
+    S.n = 0;
+    f3 v = a.c - b.c;
+    if (dot(v, v) == 0.f) v.x = 1.f;
+    // relative duality gap on the squared distance: 1e-5 leaves the distance of a 15-mm gap good to 1e-7 m; smooth
+    // (implicit) cylinders converge linearly, hulls terminate on a vertex after a handful of steps
+    const float eps = 1e-5f;
+    for (int it = 0; it < 32; it++) {
+        const f3 sa = support_core(M, a, -v, shrink), sb = support_core(M, b, v, shrink);
+        const f3 w = sa - sb;
+        const float vv = dot(v, v), vw = dot(v, w);
+        if (S.n > 0 && vv - vw <= eps * vv) break;
+        bool dup = false;
+        for (int i = 0; i < S.n; i++) {
+            const f3 d = S.W[i] - w;
+            if (dot(d, d) <= 1e-12f) dup = true;
+        }
+        if (dup) break;
+        S.W[S.n] = w; S.A[S.n] = sa; S.B[S.n] = sb;
+        S.n++;
+        if (!simplex_closest(S, v)) return -1.0f;
+        if (dot(v, v) <= 1e-12f) return -1.0f;
+    }
+    pa = mk3(0.f, 0.f, 0.f);
+    pb = mk3(0.f, 0.f, 0.f);
+    for (int i = 0; i < S.n; i++) { pa = pa + S.A[i] * S.lam[i]; pb = pb + S.B[i] * S.lam[i]; }
+    return sqrtf(dot(v, v));
+}
+
+// btPlaneSpace1 [U]: two unit directions orthogonal to n
+__device__ __forceinline__ void plane_space(f3 n, f3& p, f3& q) {
+    if (fabsf(n.z) > 0.7071067811865475244f) {
+        const float a = n.y * n.y + n.z * n.z, k = 1.0f / sqrtf(a);
+        p = mk3(0.f, -n.z * k, n.y * k);
+        q = mk3(a * k, -n.x * p.z, n.x * p.y);
+    } else {
+        const float a = n.x * n.x + n.y * n.y, k = 1.0f / sqrtf(a);
+        p = mk3(-n.y * k, n.x * k, 0.f);
+        q = mk3(-n.z * p.y, n.z * p.x, a * k);
+    }
+}
+__device__ __forceinline__ f3 aniso_scale(const DevModel& M, const float* Rw, f3 d) {
+    const f3 l = mulRtv(Rw, d);
+    return mulRv(Rw, mk3(l.x * M.aniso[0], l.y * M.aniso[1], l.z * M.aniso[2]));
+}
+
+// Link-link contacts of the current pose, appended behind the ground contacts: geometry records at slots
+// NC .. NC + count - 1 of the environment's global block.  Returns their number (<= kMaxSelf).
+template <class LT>
+__device__ int find_self_contacts_v1(LT& L, const DevModel& M, int lane, float mu_ground, float* __restrict__ rows) {
+    constexpr int N = LT::kN;
+    constexpr int NCYL = 2 * N;
+    const float rb = sqrtf(M.cyl_r * M.cyl_r + M.cyl_hl * M.cyl_hl) + M.margin;
+    const float reach = 2.0f * rb + M.break_thr;
+    const float mu_self = fminf(M.mu_link * M.mu_link, 10.0f);
+    // the solve bounds every friction pair by mu_ground * lambda_n; rows of a link-link contact are written in
+    // units that make that the right bound for its own coefficient (build_rows_v1 scales by geo[18])
+    const float rho = mu_ground > 0.f ? mu_self / mu_ground : 0.f;
+    auto frame = [&](int c, Cvx& s) {
+        const int b = (c + 1) >> 1;
+        const float* Rb = L.R[b];
+        const float* Rc = M.cyl_R[c];
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++)
+                s.R[3 * i + j] = Rb[3 * i] * Rc[j] + Rb[3 * i + 1] * Rc[3 + j] + Rb[3 * i + 2] * Rc[6 + j];
+        s.c = ld3(L.o[b]) + mulRv(Rb, ld3(M.cyl_c[c]));
+    };
+    // lane = cylinder a; pass = offset delta: the pairs (a, a + delta).  The other cylinder's centre comes from lane
+    // a + delta through the LDS crossbar (ds_bpermute: no LDS memory).  All the neighbours-across-one-joint
+    // (delta = 2, always inside each other's bounding spheres) share one pass, so their GJK runs lane-parallel.
+    static_assert(NCYL <= 64, "one cylinder per lane");
+    const int a = lane < NCYL ? lane : NCYL - 1;
+    const int ba = (a + 1) >> 1;
+    const f3 ca = ld3(L.o[ba]) + mulRv(L.R[ba], ld3(M.cyl_c[a]));
+    int nself = 0;
+    for (int delta = 2; delta < NCYL; delta++) {
+        const int bc = a + delta;
+        const bool valid = lane < NCYL && bc < NCYL;
+        const int src = (bc < NCYL ? bc : NCYL - 1) << 2;
+        const f3 cb = mk3(__int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(ca.x))),
+                          __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(ca.y))),
+                          __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(ca.z))));
+        bool cand = false;
+        if (valid) {
+            const f3 d = ca - cb;
+            cand = dot(d, d) <= reach * reach;
+        }
+        if (!__any(cand)) continue;
+        bool hit = false;
+        f3 P = mk3(0, 0, 0), PB = mk3(0, 0, 0), nrm = mk3(0, 0, 1);
+        float dist = 0.f;
+        Cvx A, B;
+        if (cand) {
+            frame(a, A);
+            frame(bc, B);
+            f3 pa, pb;
+            float mg = M.margin;
+            float dd = gjk_distance(M, A, B, 0.f, pa, pb);
+            if (dd < 0.f) {
+                dd = gjk_distance(M, A, B, kShrink, pa, pb);
+                mg = M.margin + kShrink;
+            }
+            if (dd < 0.f) {
+                const f3 d = A.c - B.c;
+                const float nn = sqrtf(dot(d, d));
+                nrm = nn > 0.f ? d * (1.0f / nn) : mk3(0.f, 0.f, 1.f);
+                P = (A.c + B.c) * 0.5f;
+                PB = P;
+                dist = -2.0f * mg;
+            } else {
+                nrm = (pa - pb) * (1.0f / dd);
+                dist = dd - 2.0f * mg;
+                P = pa - nrm * mg;
+                PB = pb + nrm * mg;
+            }
+            hit = dist < M.break_thr;
+        }
+        const unsigned long long bal = __ballot(hit);
+        if (hit) {
+            const int idx = nself + __popcll(bal & ((1ull << lane) - 1ull));
+            if (idx < LT::kMaxSelf) {
+                float* geo = rows + LT::kGeoOff + (size_t)(LT::NC + idx) * LT::kGeo;
+                f3 dA, dB;
+                plane_space(nrm, dA, dB);
+                dA = aniso_scale(M, B.R, aniso_scale(M, A.R, dA));
+                dB = aniso_scale(M, B.R, aniso_scale(M, A.R, dB));
+                st3(geo, P);
+                geo[3] = dist;
+                st3(geo + 4, dA);
+                st3(geo + 7, dB);
+                st3(geo + 10, nrm);
+                st3(geo + 13, PB);
+                geo[16] = (float)((a + 1) >> 1);
+                geo[17] = (float)((bc + 1) >> 1);
+                geo[18] = rho;
+            }
+        }
+        nself += __popcll(bal);
+    }
+    return nself > LT::kMaxSelf ? LT::kMaxSelf : nself;
+}
+
+}  // namespace snk

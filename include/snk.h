@@ -36,6 +36,11 @@ typedef struct snk_params {
                                    (default here); 1: Bullet's persistent manifold [U] -- one new
                                    support point per cylinder per step merged into a cache of <= 4,
                                    refreshed / dropped at breaking_threshold            */
+    int32_t self_collision;     /* 1 (default): link-link contacts between non-adjacent cylinder links, what
+                                   URDF_USE_SELF_COLLISION (snake.py:93) switches on [U].  Evaluated for
+                                   n_modules 32; for the 16-link snake they can never act inside the joint
+                                   limits and no rows are built                               */
+    int32_t reserved0;          /* keeps the doubles behind it 8-byte aligned; must be 0                    */
     /* pybullet world */
     double  dt;                 /* 1/240 [U]: setTimeSteps is never called (snake.py:271-272) */
     double  gravity_z;          /* snake.py:8,91   -9.8                                       */

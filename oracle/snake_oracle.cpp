@@ -185,6 +185,11 @@ struct Contact {
     int link;
     Real P[3];   /* world point on the link */
     Real dist;
+    /* link-link contacts (self-collision): the other link (-1: the ground), its point, the normal from it towards
+     * `link`; ground contacts have linkB = -1, n = (0,0,1) */
+    int linkB;
+    Real PB[3], n[3];
+    Real mu;     /* combined friction coefficient of the pair */
 };
 
 /* btPersistentManifold of one (ground, link collider) pair [U]: up to 4 cached points, each kept as the point
@@ -578,7 +583,8 @@ void joint0_wrench(const orc_env* e, Real* w6) {
 
 /* y = M^-1 J^T for a unit force along d at world point Pw on link `link` (or a unit
  * generalized force when link < 0: x given in generalized coordinates) */
-void minv_apply(orc_env* e, int link, const Real* Pw, const Real* d, const Real* xgen, Real* y) {
+void minv_apply(orc_env* e, int link, const Real* Pw, const Real* d, const Real* xgen, Real* y,
+                int linkB = -1, const Real* PwB = nullptr) {
     int L = e->L, n = e->n;
     for (int i = 0; i < 6 * L; i++) e->pA[i] = 0;
     std::vector<Real> tau(n, 0);
@@ -590,6 +596,14 @@ void minv_apply(orc_env* e, int link, const Real* Pw, const Real* d, const Real*
         mat3T_vec(&e->Rw[9 * link], d, fl);
         Real* p = &e->pA[6 * link];
         for (int r = 0; r < 3; r++) { p[r] = -nl[r]; p[3 + r] = -fl[r]; }
+        if (linkB >= 0) {      /* the opposite unit force on the other link of a link-link contact */
+            for (int r = 0; r < 3; r++) rel[r] = PwB[r] - e->ow[3 * linkB + r];
+            cross3(rel, d, nw);
+            mat3T_vec(&e->Rw[9 * linkB], nw, nl);
+            mat3T_vec(&e->Rw[9 * linkB], d, fl);
+            Real* pb = &e->pA[6 * linkB];
+            for (int r = 0; r < 3; r++) { pb[r] += nl[r]; pb[3 + r] += fl[r]; }
+        }
     } else {
         Real nl[3], fl[3];
         mat3T_vec(&e->Rw[0], &xgen[0], nl);
@@ -674,7 +688,8 @@ void find_contacts_stateless(orc_env* e) {
             Real w[3];
             mat3_vec(Rw, loc, w);
             Contact c;
-            c.link = i;
+            c.link = i; c.linkB = -1; c.mu = 0;
+            c.n[0] = 0; c.n[1] = 0; c.n[2] = 1; c.PB[0] = c.PB[1] = c.PB[2] = 0;
             for (int r = 0; r < 3; r++) c.P[r] = e->ow[3 * i + r] + w[r];
             c.dist = c.P[2];
             if (c.dist < (Real)P.breaking_threshold) e->contacts.push_back(c);
@@ -783,7 +798,8 @@ void find_contacts_manifold(orc_env* e) {
         }
         for (int j = 0; j < m.n; j++) {
             Contact c;
-            c.link = i;
+            c.link = i; c.linkB = -1; c.mu = 0;
+            c.n[0] = 0; c.n[1] = 0; c.n[2] = 1; c.PB[0] = c.PB[1] = c.PB[2] = 0;
             for (int r = 0; r < 3; r++) c.P[r] = wa[j][r];
             c.dist = m.p[j].dist;
             e->contacts.push_back(c);
@@ -791,10 +807,223 @@ void find_contacts_manifold(orc_env* e) {
     }
 }
 
+/* ---------- link-link (self) collision: URDF_USE_SELF_COLLISION (snake.py:93) [U] ----------
+ * Every pair of cylinder links except direct parent-child pairs (consecutive cylinders of the chain: the flag's
+ * default excludes a link's parent) is tested.  Narrow phase = the distance between the two convex CORE shapes
+ * (hull or implicit cylinder, without margin) by GJK, as btGjkPairDetector does; the collision margins are then
+ * taken off the distance and the witness points moved onto the inflated surfaces.  One point per pair per step
+ * (stateless -- Bullet caches up to four per pair), kept when closer than the breaking threshold.
+ * Cores that overlap (penetration beyond both margins, 2 mm) would go to Bullet's EPA.  Here: a second GJK on cores
+ * shrunk by kShrink (6 mm) with the margin enlarged by as much -- exact where flat faces or straight generators meet,
+ * rounded at the rims -- and, if even those overlap (> 14 mm deep), a contact along the line of centres at that
+ * depth (documented deviation; position motors of unlimited force can push links this deep). */
+const double kShrink = 0.006;
+struct Convex { const orc_env* e; int link; Real c[3]; const Real* R; Real shrink; };
+
+void support_core(const Convex& s, const Real* dw, Real* out) {
+    const orc_env* e = s.e;
+    Real dl[3], v[3];
+    mat3T_vec(s.R, dw, dl);
+    /* s.shrink > 0: the same shape with radius and half length reduced by that much (second tier, see below) */
+    const Real rad = e->cyl_r - s.shrink, hl = e->cyl_len / 2 - s.shrink;
+    if (e->P.hull_sides > 0) {
+        Real best = -std::numeric_limits<Real>::infinity();
+        v[0] = v[1] = v[2] = 0;
+        for (int k = 0; k < 2 * e->P.hull_sides; k++) {
+            Real c[3];
+            hull_vertex(e, k, c);
+            c[0] *= rad / e->cyl_r; c[1] *= rad / e->cyl_r; c[2] = c[2] > 0 ? hl : -hl;
+            Real val = dot3(dl, c);
+            if (val > best) { best = val; v[0] = c[0]; v[1] = c[1]; v[2] = c[2]; }
+        }
+    } else {
+        Real rr = std::sqrt(dl[0] * dl[0] + dl[1] * dl[1]);
+        if (rr != 0) { v[0] = rad * dl[0] / rr; v[1] = rad * dl[1] / rr; }
+        else { v[0] = rad; v[1] = 0; }
+        v[2] = dl[2] < 0 ? -hl : hl;
+    }
+    Real w[3];
+    mat3_vec(s.R, v, w);
+    for (int r = 0; r < 3; r++) out[r] = s.c[r] + w[r];
+}
+
+/* closest point to the origin on the simplex W[0..n-1] (n <= 4), barycentric weights in lam, the simplex reduced to
+ * the supporting sub-simplex (Ericson, Real-Time Collision Detection 5.1; tetrahedron by its faces) */
+struct Simplex { int n; Real W[4][3], A[4][3], B[4][3], lam[4]; };
+
+void closest_segment(const Real* a, const Real* b, Real* lam2) {
+    Real ab[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]};
+    Real t = -dot3(a, ab);
+    Real dd = dot3(ab, ab);
+    if (t <= 0 || dd <= 0) { lam2[0] = 1; lam2[1] = 0; }
+    else if (t >= dd) { lam2[0] = 0; lam2[1] = 1; }
+    else { lam2[1] = t / dd; lam2[0] = 1 - lam2[1]; }
+}
+void closest_triangle(const Real* a, const Real* b, const Real* c, Real* l3) {
+    Real ab[3], ac[3], ap[3], bp[3], cp[3];
+    for (int r = 0; r < 3; r++) { ab[r] = b[r] - a[r]; ac[r] = c[r] - a[r]; ap[r] = -a[r]; bp[r] = -b[r]; cp[r] = -c[r]; }
+    Real d1 = dot3(ab, ap), d2 = dot3(ac, ap);
+    if (d1 <= 0 && d2 <= 0) { l3[0] = 1; l3[1] = 0; l3[2] = 0; return; }
+    Real d3 = dot3(ab, bp), d4 = dot3(ac, bp);
+    if (d3 >= 0 && d4 <= d3) { l3[0] = 0; l3[1] = 1; l3[2] = 0; return; }
+    Real vc = d1 * d4 - d3 * d2;
+    if (vc <= 0 && d1 >= 0 && d3 <= 0) { Real v = d1 / (d1 - d3); l3[0] = 1 - v; l3[1] = v; l3[2] = 0; return; }
+    Real d5 = dot3(ab, cp), d6 = dot3(ac, cp);
+    if (d6 >= 0 && d5 <= d6) { l3[0] = 0; l3[1] = 0; l3[2] = 1; return; }
+    Real vb = d5 * d2 - d1 * d6;
+    if (vb <= 0 && d2 >= 0 && d6 <= 0) { Real w = d2 / (d2 - d6); l3[0] = 1 - w; l3[1] = 0; l3[2] = w; return; }
+    Real va = d3 * d6 - d5 * d4;
+    if (va <= 0 && (d4 - d3) >= 0 && (d5 - d6) >= 0) {
+        Real w = (d4 - d3) / ((d4 - d3) + (d5 - d6));
+        l3[0] = 0; l3[1] = 1 - w; l3[2] = w; return;
+    }
+    Real den = 1 / (va + vb + vc);
+    Real v = vb * den, w = vc * den;
+    l3[0] = 1 - v - w; l3[1] = v; l3[2] = w;
+}
+/* returns false when the origin is inside the tetrahedron */
+bool simplex_closest(Simplex& S, Real* v) {
+    auto comb = [&](Real* out) {
+        for (int r = 0; r < 3; r++) { out[r] = 0; for (int i = 0; i < S.n; i++) out[r] += S.lam[i] * S.W[i][r]; }
+    };
+    auto keep = [&](const int* idx, const Real* lam, int m) {
+        Simplex T = S;
+        int k = 0;
+        for (int i = 0; i < m; i++) {
+            if (lam[i] <= 0) continue;
+            for (int r = 0; r < 3; r++) { S.W[k][r] = T.W[idx[i]][r]; S.A[k][r] = T.A[idx[i]][r]; S.B[k][r] = T.B[idx[i]][r]; }
+            S.lam[k++] = lam[i];
+        }
+        S.n = k;
+    };
+    if (S.n == 1) { S.lam[0] = 1; }
+    else if (S.n == 2) {
+        Real l[2]; closest_segment(S.W[0], S.W[1], l);
+        int idx[2] = {0, 1}; keep(idx, l, 2);
+    } else if (S.n == 3) {
+        Real l[3]; closest_triangle(S.W[0], S.W[1], S.W[2], l);
+        int idx[3] = {0, 1, 2}; keep(idx, l, 3);
+    } else {
+        /* tetrahedron: inside, or the closest of the faces the origin is outside of */
+        static const int F[4][4] = {{0, 1, 2, 3}, {0, 2, 3, 1}, {0, 3, 1, 2}, {1, 3, 2, 0}};
+        Real best = std::numeric_limits<Real>::infinity();
+        int bf = -1; Real bl[3] = {0, 0, 0};
+        bool outside_any = false;
+        for (int f = 0; f < 4; f++) {
+            const Real *a = S.W[F[f][0]], *b = S.W[F[f][1]], *c = S.W[F[f][2]], *d = S.W[F[f][3]];
+            Real ab[3], ac[3], nn[3], ad[3];
+            for (int r = 0; r < 3; r++) { ab[r] = b[r] - a[r]; ac[r] = c[r] - a[r]; ad[r] = d[r] - a[r]; }
+            cross3(ab, ac, nn);
+            Real sp = -dot3(a, nn), sd = dot3(ad, nn);     /* origin and the opposite vertex relative to the face */
+            if (sp * sd >= 0 && sd != 0) continue;         /* same side: the origin is not outside this face */
+            outside_any = true;
+            Real l[3]; closest_triangle(a, b, c, l);
+            Real q[3];
+            for (int r = 0; r < 3; r++) q[r] = l[0] * a[r] + l[1] * b[r] + l[2] * c[r];
+            Real dd = dot3(q, q);
+            if (dd < best) { best = dd; bf = f; bl[0] = l[0]; bl[1] = l[1]; bl[2] = l[2]; }
+        }
+        if (!outside_any) { v[0] = v[1] = v[2] = 0; return false; }
+        int idx[3] = {F[bf][0], F[bf][1], F[bf][2]};
+        keep(idx, bl, 3);
+    }
+    comb(v);
+    return true;
+}
+
+/* distance between the cores of two convex shapes; witness points pa, pb; returns -1 when they overlap */
+Real gjk_distance(const Convex& a, const Convex& b, Real* pa, Real* pb) {
+    Simplex S;
+    S.n = 0;
+    Real v[3] = {a.c[0] - b.c[0], a.c[1] - b.c[1], a.c[2] - b.c[2]};
+    if (dot3(v, v) == 0) v[0] = 1;
+    const Real eps = sizeof(Real) == 8 ? Real(1e-10) : Real(1e-6);
+    for (int it = 0; it < 40; it++) {
+        Real nv[3] = {-v[0], -v[1], -v[2]}, sa[3], sb[3], w[3];
+        support_core(a, nv, sa);
+        support_core(b, v, sb);
+        for (int r = 0; r < 3; r++) w[r] = sa[r] - sb[r];
+        Real vv = dot3(v, v), vw = dot3(v, w);
+        if (S.n > 0 && vv - vw <= eps * vv) break;                 /* no progress possible: v is the closest point */
+        bool dup = false;
+        for (int i = 0; i < S.n; i++) {
+            Real d[3] = {S.W[i][0] - w[0], S.W[i][1] - w[1], S.W[i][2] - w[2]};
+            if (dot3(d, d) <= eps * eps) dup = true;
+        }
+        if (dup) break;
+        for (int r = 0; r < 3; r++) { S.W[S.n][r] = w[r]; S.A[S.n][r] = sa[r]; S.B[S.n][r] = sb[r]; }
+        S.n++;
+        if (!simplex_closest(S, v)) return -1;
+        if (dot3(v, v) <= eps * eps) return -1;
+    }
+    for (int r = 0; r < 3; r++) {
+        pa[r] = 0; pb[r] = 0;
+        for (int i = 0; i < S.n; i++) { pa[r] += S.lam[i] * S.A[i][r]; pb[r] += S.lam[i] * S.B[i][r]; }
+    }
+    return std::sqrt(dot3(v, v));
+}
+
+void find_self_contacts(orc_env* e) {
+    const orc_params& P = e->P;
+    std::vector<int> cyl;
+    for (int i = 0; i < e->L; i++)
+        if (e->links[i].has_cyl) cyl.push_back(i);
+    const Real mg = (Real)P.collision_margin, thr = (Real)P.breaking_threshold;
+    const Real rb = std::sqrt(e->cyl_r * e->cyl_r + e->cyl_len * e->cyl_len / 4) + mg;
+    Real mu = (Real)(P.mu_link * P.mu_link);
+    if (mu > 10) mu = 10;
+    std::vector<Convex> cv(cyl.size());
+    for (size_t a = 0; a < cyl.size(); a++) {
+        int i = cyl[a];
+        cv[a].e = e; cv[a].link = i; cv[a].R = &e->Rw[9 * i]; cv[a].shrink = 0;
+        Real w[3];
+        mat3_vec(cv[a].R, e->links[i].cyl_c, w);
+        for (int r = 0; r < 3; r++) cv[a].c[r] = e->ow[3 * i + r] + w[r];
+    }
+    /* pair order [U] (Bullet's is its broad phase's): by offset b - a = 2, 3, ..., then by a */
+    for (size_t delta = 2; delta < cyl.size(); delta++)      /* delta = 1 is a parent-child pair: excluded */
+        for (size_t a = 0; a + delta < cyl.size(); a++) {
+            const size_t b = a + delta;
+            Real d[3] = {cv[a].c[0] - cv[b].c[0], cv[a].c[1] - cv[b].c[1], cv[a].c[2] - cv[b].c[2]};
+            Real reach = 2 * rb + thr;
+            if (dot3(d, d) > reach * reach) continue;         /* bounding spheres */
+            Real pa[3], pb[3];
+            Real dist = gjk_distance(cv[a], cv[b], pa, pb);
+            Real mgx = mg;
+            if (dist < 0) {
+                Convex sa = cv[a], sb = cv[b];
+                sa.shrink = sb.shrink = (Real)kShrink;
+                dist = gjk_distance(sa, sb, pa, pb);
+                mgx = mg + (Real)kShrink;
+            }
+            Contact c;
+            c.link = cv[a].link; c.linkB = cv[b].link; c.mu = mu;
+            if (dist < 0) {
+                Real nn = std::sqrt(dot3(d, d));
+                for (int r = 0; r < 3; r++) {
+                    c.n[r] = nn > 0 ? d[r] / nn : (r == 2 ? 1 : 0);
+                    c.P[r] = c.PB[r] = (cv[a].c[r] + cv[b].c[r]) / 2;
+                }
+                c.dist = -2 * mgx;
+            } else {
+                for (int r = 0; r < 3; r++) c.n[r] = (pa[r] - pb[r]) / dist;
+                c.dist = dist - 2 * mgx;
+                for (int r = 0; r < 3; r++) { c.P[r] = pa[r] - mgx * c.n[r]; c.PB[r] = pb[r] + mgx * c.n[r]; }
+            }
+            if (c.dist < thr) e->contacts.push_back(c);
+        }
+}
+
 void find_contacts(orc_env* e) {
     if (e->P.contact_model == 1) find_contacts_manifold(e);
     else find_contacts_stateless(e);
     if (e->P.max_contacts > 0 && (int)e->contacts.size() > e->P.max_contacts) e->contacts.resize(e->P.max_contacts);
+    if (e->P.self_collision) {
+        size_t before = e->contacts.size();
+        find_self_contacts(e);
+        if (e->P.max_self_contacts > 0 && e->contacts.size() > before + (size_t)e->P.max_self_contacts)
+            e->contacts.resize(before + e->P.max_self_contacts);
+    }
 }
 
 void apply_dv(orc_env* e, const Real* dvec, Real mult) {
@@ -925,15 +1154,25 @@ void substep(orc_env* e, const Real* targets) {
     int nc = (int)e->contacts.size();
     Real mu = (Real)(P.mu_link * e->mu_plane);
     if (mu > 10) mu = 10;   /* MAX_FRICTION */
+    std::vector<Real> Jtmp(nd);
+    /* J of a contact row: link A's point along d, minus the other link's point along d (link-link contacts) */
+    auto contact_jac = [&](const Contact& c, const Real* d, Real* J) {
+        jac_row(e, c.link, c.P, d, J);
+        if (c.linkB >= 0) {
+            jac_row(e, c.linkB, c.PB, d, Jtmp.data());
+            for (int i = 0; i < nd; i++) J[i] -= Jtmp[i];
+        }
+    };
     for (int ci = 0; ci < nc; ci++) {
-        const Contact& c = e->contacts[ci];
-        Real nrm[3] = {0, 0, 1};
+        Contact& c = e->contacts[ci];
+        if (c.linkB < 0) c.mu = mu;
+        Real nrm[3] = {c.n[0], c.n[1], c.n[2]};
         Row row;
         row.kind = 2; row.joint = -1; row.contact = ci;
         row.J.assign(nd, 0); row.M.assign(nd, 0);
         memcpy(row.dir, nrm, sizeof(nrm));
-        jac_row(e, c.link, c.P, nrm, row.J.data());
-        minv_apply(e, c.link, c.P, nrm, nullptr, row.M.data());
+        contact_jac(c, nrm, row.J.data());
+        minv_apply(e, c.link, c.P, nrm, nullptr, row.M.data(), c.linkB, c.PB);
         Real rel_vel = 0;
         for (int i = 0; i < nd; i++) rel_vel += row.J[i] * g[i];
         Real pen = c.dist + (Real)P.linear_slop;
@@ -943,21 +1182,36 @@ void substep(orc_env* e, const Real* targets) {
         finish_row(row, velerr + poserr);
         row.lo = 0; row.hi = Real(1e10);
         normals.push_back(row);
-        /* two friction directions from btPlaneSpace1(n=(0,0,1)) = (0,-1,0), (1,0,0),
+        /* two friction directions from btPlaneSpace1(n) ((0,-1,0), (1,0,0) for the ground's n = (0,0,1)),
          * each scaled by the link's anisotropic friction in link axes:
-         * d' = R diag(aniso) R^T d  (applyAnisotropicFriction [U]) */
-        const Real fd[2][3] = {{0, -1, 0}, {1, 0, 0}};
+         * d' = R diag(aniso) R^T d  (applyAnisotropicFriction [U]; for a link-link contact first by link A's
+         * frame, then by link B's) */
+        Real fd[2][3];
+        if (std::fabs(nrm[2]) > Real(0.7071067811865475244)) {
+            Real a = nrm[1] * nrm[1] + nrm[2] * nrm[2], k = 1 / std::sqrt(a);
+            fd[0][0] = 0; fd[0][1] = -nrm[2] * k; fd[0][2] = nrm[1] * k;
+            fd[1][0] = a * k; fd[1][1] = -nrm[0] * fd[0][2]; fd[1][2] = nrm[0] * fd[0][1];
+        } else {
+            Real a = nrm[0] * nrm[0] + nrm[1] * nrm[1], k = 1 / std::sqrt(a);
+            fd[0][0] = -nrm[1] * k; fd[0][1] = nrm[0] * k; fd[0][2] = 0;
+            fd[1][0] = -nrm[2] * fd[0][1]; fd[1][1] = nrm[2] * fd[0][0]; fd[1][2] = a * k;
+        }
         for (int f = 0; f < 2; f++) {
             Real loc[3], dsc[3];
             mat3T_vec(&e->Rw[9 * c.link], fd[f], loc);
             for (int r = 0; r < 3; r++) loc[r] *= (Real)P.aniso[r];
             mat3_vec(&e->Rw[9 * c.link], loc, dsc);
+            if (c.linkB >= 0) {
+                mat3T_vec(&e->Rw[9 * c.linkB], dsc, loc);
+                for (int r = 0; r < 3; r++) loc[r] *= (Real)P.aniso[r];
+                mat3_vec(&e->Rw[9 * c.linkB], loc, dsc);
+            }
             Row fr;
             fr.kind = 3; fr.joint = -1; fr.contact = ci;
             fr.J.assign(nd, 0); fr.M.assign(nd, 0);
             memcpy(fr.dir, dsc, sizeof(dsc));
-            jac_row(e, c.link, c.P, dsc, fr.J.data());
-            minv_apply(e, c.link, c.P, dsc, nullptr, fr.M.data());
+            contact_jac(c, dsc, fr.J.data());
+            minv_apply(e, c.link, c.P, dsc, nullptr, fr.M.data(), c.linkB, c.PB);
             Real rv = 0;
             for (int i = 0; i < nd; i++) rv += fr.J[i] * g[i];
             finish_row(fr, -rv);
@@ -982,7 +1236,7 @@ void substep(orc_env* e, const Real* targets) {
             if (r * r > lsq) lsq = r * r;
         }
         for (int ci = 0; ci < nc; ci++) {
-            Real lim = mu * normals[ci].applied;
+            Real lim = e->contacts[ci].mu * normals[ci].applied;
             Row& A = frictions[2 * ci];
             Row& B = frictions[2 * ci + 1];
             if (P.cone_friction) {
@@ -1038,6 +1292,12 @@ void substep(orc_env* e, const Real* targets) {
                       frictions[2 * ci + 1].dir[r] * frictions[2 * ci + 1].applied) / dt;
         }
         ext.push_back(f);
+        if (c.linkB >= 0) {
+            ExtForce fb;
+            fb.link = c.linkB;
+            for (int r = 0; r < 3; r++) { fb.P[r] = c.PB[r]; fb.F[r] = -f.F[r]; }
+            ext.push_back(fb);
+        }
         e->last_normal_impulse[ci] = normals[ci].applied;
     }
     velocities(e, e->omega, e->vel, e->qd.data());
@@ -1104,6 +1364,8 @@ void orc_default_params(orc_params* p) {
     p->collision_margin = 0.001;
     p->hull_sides = 0;   /* implicit cylinder: see find_contacts and DESIGN.md §3 */
     p->max_contacts = 0;
+    p->self_collision = 0;   /* 1 = link-link contacts (URDF_USE_SELF_COLLISION, snake.py:93); tests switch it on */
+    p->max_self_contacts = 0;
     p->contact_model = 0;/* stateless two-point manifold (default here); 1 = Bullet's persistent manifold [U] */
     p->dt = 1.0 / 240.0;
     p->gravity_z = -9.8;

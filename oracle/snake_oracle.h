@@ -46,6 +46,12 @@ typedef struct orc_params {
                                *     step merged into a cache of <= 4, refreshed / dropped at breaking_threshold */
     int32_t max_contacts;     /* 0 = no limit; > 0: only the first max_contacts points (in manifold order) get
                                * rows -- mirrors the product's structural limit of 4n contacts (tests only)   */
+    int32_t self_collision;   /* 1: link-link contacts of non-adjacent cylinder links (URDF_USE_SELF_COLLISION,
+                               * snake.py:93 [U]) for any chain length; 0 (default of this test tool): none.
+                               * For the 16-link snake the rows are speculative only and never carry an impulse
+                               * inside the joint limits (tools/self_collision_clearance.py, and a test);
+                               * the 32-link tests switch it on (the product evaluates it for 32 links)        */
+    int32_t max_self_contacts;/* 0 = no limit; > 0 mirrors the product's cap on link-link contacts (tests)    */
     /* world / integrator */
     double  dt;               /* PyBullet default fixedTimeStep 1/240 [U] (F2)           */
     double  gravity_z;        /* snake.py:8  -9.8                                        */

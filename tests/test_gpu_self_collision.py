@@ -1,0 +1,146 @@
+"""GPU tests of link-link (self) collision, SURVEY 8(f)-2: what URDF_USE_SELF_COLLISION (/root/reference/snake.py:93)
+adds in PyBullet [U].  It matters for the 32-link snake, whose coil can reach itself (twelve yaw joints at 27.5 deg
+bring modules 1-3 against modules 24-26); for the 16-link snake the rows exist but can never carry an impulse inside the
+joint limits (tools/self_collision_clearance.py) -- checked here on the oracle, which can evaluate them for any chain.
+
+Tolerances: contact geometry of the coil pose (float32 GJK against the oracle's float64 GJK) 2e-5 m on points and
+distances, 1e-3 on normals (two hull facets can tie); states after K substeps of a tightening coil as in
+tests/test_gpu_parity.py's ground case (5e-4 on positions and angles, 5e-2 relative on velocities)."""
+import numpy as np
+import pytest
+
+gpu = pytest.mark.gpu
+
+N = 32
+
+
+def coil(ang_deg=27.5, m=12):
+    """Yaw joints (odd indices) of the first m yaw modules, alternating sign: the snake curls in the plane."""
+    q = np.zeros(N)
+    yaw = np.arange(1, N, 2)[:m]
+    q[yaw] = np.radians(ang_deg) * np.where(np.arange(m) % 2 == 0, 1.0, -1.0)
+    return q
+
+
+def _coiled_states(B, seed=0):
+    rng = np.random.default_rng(seed)
+    S = np.zeros((B, 13 + 2 * N), np.float32)
+    for i in range(B):
+        S[i, 6] = 1.0
+        S[i, 13:13 + N] = coil(27.5 + 0.2 * rng.uniform(-1, 1)) + rng.uniform(-0.01, 0.01, N) * (np.arange(N) % 2 == 1)
+    return S
+
+
+@gpu
+@pytest.mark.parametrize("hull", [0, 32])
+def test_coil_self_contacts_match_oracle(pkg, oracle_mod, hull):
+    B, K = 6, 4
+    over = dict(n_modules=N, hull_sides=hull, residual_threshold=0.0)
+    st = pkg.Stepper(B, **over)
+    S = _coiled_states(B, seed=hull)
+    st.set_state(S, np.zeros((B, N + 2), np.float32))
+    T = np.tile(coil(30.0).astype(np.float32), (B, 1))          # the motors tighten the coil: the head pushes the tail
+    refs, plain, refs32 = [], [], []
+    for i in range(B):
+        e = oracle_mod.OracleEnv(self_collision=1, max_self_contacts=32, **over)
+        e.set_state(S[i].astype(np.float64))
+        refs.append(e)
+        e32 = oracle_mod.OracleEnv(self_collision=1, max_self_contacts=32, f32=True, **over)
+        e32.set_state(S[i].astype(np.float64))
+        refs32.append(e32)
+        p = oracle_mod.OracleEnv(self_collision=0, **over)
+        p.set_state(S[i].astype(np.float64))
+        plain.append(p)
+    worst_p = worst_v = cal_p = cal_v = 0.0
+    flips = 0
+    acted = 0
+    alive = np.ones(B, bool)
+    for k in range(K):
+        info = st.substep(T, 1)
+        G, _ = st.get_state()
+        for i in range(B):
+            refs[i].substep(T[i].astype(np.float64))
+            refs32[i].substep(T[i].astype(np.float64))
+            plain[i].substep(T[i].astype(np.float64))
+            if not alive[i]:
+                continue
+            if refs[i].last_num_contacts != info[i, 1]:
+                alive[i] = False          # a pair at the breaking threshold counted on one side only
+                flips += 1
+                continue
+            assert info[i, 1] > 128                                   # ground contacts + link-link contacts
+            imp = refs[i].last_normal_impulses(512)
+            if imp[128:].max() > 1e-4:
+                acted += 1
+            ref = refs[i].get_state()
+            worst_p = max(worst_p, np.abs(G[i, :7] - ref[:7]).max(), np.abs(G[i, 13:13 + N] - ref[13:13 + N]).max())
+            worst_v = max(worst_v, (np.abs(G[i, 13 + N:] - ref[13 + N:]) / (1 + np.abs(ref[13 + N:]))).max())
+            if refs32[i].last_num_contacts == refs[i].last_num_contacts:       # calibration: the float32 oracle
+                r32 = refs32[i].get_state()
+                cal_p = max(cal_p, np.abs(r32[:7] - ref[:7]).max(), np.abs(r32[13:13 + N] - ref[13:13 + N]).max())
+                cal_v = max(cal_v, (np.abs(r32[13 + N:] - ref[13 + N:]) / (1 + np.abs(ref[13 + N:]))).max())
+    print("hull", hull, "coil parity: worst pos", worst_p, "rel qd", worst_v, "| oracle-f32", cal_p, cal_v,
+          "| threshold flips", flips, "acted", acted)
+    assert acted >= B            # the link-link rows carried impulses
+    assert flips <= 1
+    # stiff pushing contact between unlimited-force motors: float32 round-off in the GJK witness points is
+    # amplified; the GPU must be no worse than three times the float32 build of the oracle on the same steps
+    assert worst_p < max(5e-4, 3 * cal_p) and worst_v < max(5e-2, 3 * cal_v)
+    # and they matter: without them the oracle's coil closes further
+    with_sc = np.array([r.get_state()[13:13 + N] for r in refs])
+    without = np.array([p.get_state()[13:13 + N] for p in plain])
+    assert np.abs(with_sc - without).max() > 1e-3
+    st.close()
+
+
+@gpu
+def test_self_collision_switch_and_gait_invariance(pkg):
+    """self_collision = 0 removes the rows; on the bench gait (alternating bends, never closer than the speculative
+    margin lets act) both settings give the same observations bit for bit, at 32 links and trivially at 16."""
+    import bench
+    B = 64
+    ids = np.arange(B)
+    for n in (32, 16):
+        A = n // 2
+        on = pkg.Stepper(B, n_modules=n, self_collision=1)
+        off = pkg.Stepper(B, n_modules=n, self_collision=0)
+        on.reset(); off.reset()
+        for j in range(3):
+            a = bench.gait_actions(ids, j, A).astype(np.float32)
+            o1, r1, d1, s1 = on.step(a.copy())
+            o0, r0, d0, s0 = off.step(a.copy())
+            assert np.array_equal(o1, o0) and np.array_equal(r1, r0) and np.array_equal(s1, s0)
+        on.close(); off.close()
+    # the coil, by contrast, differs
+    S = _coiled_states(4)
+    T = np.tile(coil(30.0).astype(np.float32), (4, 1))
+    out = []
+    for sc in (1, 0):
+        st = pkg.Stepper(4, n_modules=N, self_collision=sc)
+        st.set_state(S, np.zeros((4, N + 2), np.float32))
+        info = st.substep(T, 6)
+        out.append((st.get_state()[0], info))
+        st.close()
+    assert np.all(out[0][1][:, 1] > out[1][1][:, 1])                  # more contacts with the flag on
+    assert np.abs(out[0][0] - out[1][0]).max() > 1e-3
+
+
+def test_sixteen_link_self_contacts_are_inert_in_the_oracle(oracle_mod):
+    """The product builds no link-link rows for 16 links.  The oracle can: over a gait rollout with the flag on, the
+    rows exist (bends above ~18 deg bring neighbouring cylinders within the breaking threshold) and every one of them
+    keeps a zero impulse, so the results equal those without the flag."""
+    import bench
+    a_env = oracle_mod.OracleEnv(self_collision=1)
+    b_env = oracle_mod.OracleEnv(self_collision=0)
+    a_env.reset(); b_env.reset()
+    seen = 0
+    for j in range(12):
+        act = bench.gait_actions([3], j)[0]
+        oa, ra, da, ka, _ = a_env.env_step(act.copy(), vec_mode=True)
+        ob, rb, db, kb, _ = b_env.env_step(act.copy(), vec_mode=True)
+        assert ka == kb and da == db and np.allclose(oa, ob, rtol=0, atol=1e-12) and abs(ra - rb) < 1e-12
+        if a_env.last_num_contacts > b_env.last_num_contacts:
+            seen += 1
+            extra = a_env.last_normal_impulses(512)[b_env.last_num_contacts:]
+            assert np.all(extra == 0.0)
+    assert seen > 0
