@@ -307,8 +307,6 @@ int snk_create(const snk_params* p, int32_t n_envs, int32_t device, snk_handle**
     if (p->n_modules != 16 && p->n_modules != 32) return fail("snk_create: n_modules must be 16 or 32");
     if (p->hull_sides < 0 || p->hull_sides > 32) return fail("snk_create: hull_sides must be 0 (implicit cylinder) .. 32");
     if (p->contact_model != 0 && p->contact_model != 1) return fail("snk_create: contact_model must be 0 or 1");
-    if (p->contact_model == 1 && p->n_modules != 16)
-        return fail("snk_create: contact_model 1 (persistent manifold) is built for n_modules 16");
     if (p->term_index < 0 || p->term_index >= 3 * p->n_modules + 8) return fail("snk_create: term_index out of range");
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));

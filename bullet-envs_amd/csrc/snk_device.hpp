@@ -363,11 +363,22 @@ __device__ void body_bias(LT& L, const DevModel& M, int lane) {
 // breaking threshold [U].  Friction directions (0,-1,0),(1,0,0) scaled anisotropically in
 // the cylinder link's axes: d' = Rc diag(aniso) Rc^T d  (snake.py:104-106).
 // ----------------------------------------------------------------------------------
-__device__ __forceinline__ void rim_point(const DevModel& M, f3 dl, float& lx, float& ly);     // snk_pgs_v2.hpp
+// defined in snk_pgs_v2.hpp (shared by both solves)
+__device__ __forceinline__ void rim_point(const DevModel& M, f3 dl, float& lx, float& ly);
+struct MPt;
+constexpr int kMfFloats = 28;      // per cylinder: [count, 3 pad, 4 x (a3, b3)]
+__device__ __forceinline__ int manifold_update(const DevModel& M, float* __restrict__ mfc, const float* Rw, f3 centre, f3 dl,
+                                               MPt (&p)[4], f3 (&wa)[4]);
+__device__ __forceinline__ int lane_prefix3(int cnt, int lane, int& total);
+__device__ __forceinline__ void friction_dirs(const DevModel& M, const float* Rw, f3& dA, f3& dB);
+__device__ __forceinline__ void cyl_world_rot(const float* Rb, const float* Rc, float* Rw);
+template <class LT>
+__device__ int find_contacts_manifold_v1(LT& L, const DevModel& M, int lane, float* __restrict__ rows, float* __restrict__ mf);
 
 template <class LT>
-__device__ int find_contacts_v1(LT& L, const DevModel& M, int lane, float* __restrict__ rows) {
+__device__ int find_contacts_v1(LT& L, const DevModel& M, int lane, float* __restrict__ rows, float* __restrict__ mf) {
     constexpr int N = LT::kN;
+    if (M.contact_model == 1) return find_contacts_manifold_v1(L, M, lane, rows, mf);
     int total = 0;
     for (int base = 0; base < 4 * N; base += 64) {
         const int slot = base + lane;
@@ -1048,12 +1059,12 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
 // ----------------------------------------------------------------------------------
 template <class LT>
 __device__ void substep_v1(LT& L, const DevModel& M, int lane, float mu, int& iters, int& ncontacts, float* __restrict__ rows,
-                           const SensorHint& hint) {
+                           const SensorHint& hint, float* __restrict__ mf) {
     constexpr int N = LT::kN;
     constexpr int ND = N + 6;
     const float dt = M.dt;
     // (1) contacts of the current pose, (2) bias forces with gravity, joint damping torque
-    int nc = find_contacts_v1(L, M, lane, rows);
+    int nc = find_contacts_v1(L, M, lane, rows, mf);
     if (lane == 0) L.nplane = nc;
     const int nplane = nc;
     if (M.self_collision) nc += find_self_contacts_v1(L, M, lane, mu, rows);   // link-link contacts follow the ground's
@@ -1212,7 +1223,7 @@ __device__ __forceinline__ void substep(LT& L, const DevModel& M0, int lane_in, 
     // otherwise be computed in the kernel prologue and spilled.
     asm volatile("" : "+v"(lane));
     if constexpr (LT::kV2) substep_v2(L, M, lane, mu, iters, ncontacts, hint, mf);
-    else substep_v1(L, M, lane, mu, iters, ncontacts, rows, hint);
+    else substep_v1(L, M, lane, mu, iters, ncontacts, rows, hint, mf);
 }
 
 // ----------------------------------------------------------------------------------

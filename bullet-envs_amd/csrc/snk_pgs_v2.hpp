@@ -131,7 +131,6 @@ struct MPt {
     float d;
 };
 typedef float mf_v4 __attribute__((ext_vector_type(4)));
-constexpr int kMfFloats = 28;      // per cylinder: [count, 3 pad, 4 x (a3, b3)]
 
 // btPersistentManifold::sortCachedPoints with gContactCalcArea3Points [U]: which cached point the new one replaces
 __device__ __forceinline__ int manifold_sort_cached(const MPt (&p)[4], const MPt& np) {
@@ -355,6 +354,51 @@ __device__ int find_contacts_v2(LT& L, const DevModel& M, int lane, float* __res
         L.cyln[lane] = (int)((bal >> (2 * lane)) & 1ull) + (int)((bal >> (2 * lane + 1)) & 1ull);
     }
     return __popcll(bal);
+}
+
+// The same persistent-manifold contacts for the streamed-row solve (chains up to 32 links: one cylinder per lane):
+// geometry records written at the COMPACT index (clist is the identity), at most NC ground contacts.
+template <class LT>
+__device__ int find_contacts_manifold_v1(LT& L, const DevModel& M, int lane, float* __restrict__ rows, float* __restrict__ mf) {
+    constexpr int N = LT::kN;
+    static_assert(2 * N <= 64, "one cylinder per lane");
+    int cnt = 0;
+    MPt p[4];
+    f3 wa[4];
+    float Rw[9];
+    const int c = lane < 2 * N ? lane : 0;
+    const int b = (c + 1) >> 1;
+    if (lane < 2 * N) {
+        const float* Rb = L.R[b];
+        cyl_world_rot(Rb, M.cyl_R[c], Rw);
+        const f3 dl = mk3(-Rw[6], -Rw[7], -Rw[8]);
+        const f3 centre = ld3(L.o[b]) + mulRv(Rb, ld3(M.cyl_c[c]));
+        cnt = manifold_update(M, mf + (size_t)c * kMfFloats, Rw, centre, dl, p, wa);
+    }
+    int total;
+    int base = lane_prefix3(cnt, lane, total);
+    if (lane < 2 * N) {
+        if (base > LT::NC) base = LT::NC;
+        if (base + cnt > LT::NC) cnt = LT::NC - base;
+        f3 dA, dB;
+        friction_dirs(M, Rw, dA, dB);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (j < cnt) {
+                const int idx = base + j;
+                float* geo = rows + LT::kGeoOff + (size_t)idx * LT::kGeo;
+                st3(geo, wa[j]);
+                geo[3] = p[j].d;
+                st3(geo + 4, dA);
+                st3(geo + 7, dB);
+                st3(geo + 10, mk3(0.f, 0.f, 1.f));
+                st3(geo + 13, mk3(0.f, 0.f, 0.f));
+                geo[16] = (float)b; geo[17] = -1.0f; geo[18] = 1.0f;
+                L.clist[idx] = idx;
+            }
+        }
+    }
+    return total > LT::NC ? LT::NC : total;
 }
 
 // ------------------------------------------------------------------------------------
