@@ -111,7 +111,8 @@ def cpu_baseline(steps=2000, warmup=20, n_links=16, friction_seed=None, hull_sid
     cores = max(1, min(nproc, quota) if quota else nproc)
     if quota is None and nproc > 64:
         cores = 64          # no quota visible: one thread per physical core of a 64-core socket at most
-    kw = dict(n_modules=n_links, hull_sides=hull_sides, contact_model=contact_model)
+    kw = dict(n_modules=n_links, hull_sides=hull_sides, contact_model=contact_model,
+              self_collision=1 if n_links == 32 else 0)     # what the GPU side evaluates (inert for 16 links)
 
     def mu_of(ids):
         return None if friction_seed is None else env_friction(ids, friction_seed)
@@ -153,6 +154,9 @@ def main():
                     help="not a BASELINE config: 32 = cylinders as the 32-gon hulls PyBullet imports (DESIGN.md 3)")
     ap.add_argument("--contact-model", type=int, default=0, choices=(0, 1),
                     help="not a BASELINE config: 1 = Bullet's persistent <= 4-point contact manifold (DESIGN.md 3)")
+    ap.add_argument("--self-collision", type=int, default=1, choices=(0, 1),
+                    help="link-link contacts (the reference's URDF_USE_SELF_COLLISION load flag, snake.py:93): evaluated by "
+                         "the 32-link kernels; 0 switches them off (round-1 state of configs[3])")
     ap.add_argument("--cpu-steps", type=int, default=2000,
                     help="env-steps of the CPU baseline (BASELINE.md B3: 2000 after 20 warm-up steps)")
     ap.add_argument("--policy", action="store_true",
@@ -196,7 +200,7 @@ def main():
             dist.init_process_group(backend)
 
     local = pkg.DeviceVecEnv(E, device_index=local_rank, n_modules=NL, hull_sides=args.hull_sides,
-                             contact_model=args.contact_model)
+                             contact_model=args.contact_model, self_collision=args.self_collision)
     if args.friction_seed is not None:      # configs[4]: this rank's shard of the per-env plane friction
         local.set_ground_friction(env_friction(np.arange(rank * E, (rank + 1) * E), args.friction_seed).astype(np.float32))
     env = pkg.ShardedVecEnv(local, root=0, device=dev) if world > 1 else None
@@ -286,7 +290,8 @@ def main():
         # rocprofv3 summaries of THIS configuration (profiles/README.md), replayed here -- they are measured in
         # separate --pmc runs of the same command, not in this run; the key names say so.
         cfg_key = ("c%d" % NL) + ("_fric" if args.friction_seed is not None else "") + ("_policy" if args.policy else "") + (
-            "_hull%d_cm%d" % (args.hull_sides, args.contact_model) if (args.hull_sides or args.contact_model) else "")
+            "_hull%d_cm%d" % (args.hull_sides, args.contact_model) if (args.hull_sides or args.contact_model) else "") + (
+            "_nosc" if (NL == 32 and not args.self_collision) else "")
         traffic, traffic_src, valu = None, None, None
         try:
             import glob
@@ -330,6 +335,7 @@ def main():
                                                          if args.policy else "serpenoid gait actions", cfg_index)),
                 "envs_per_gpu": E, "n_links": NL, "friction_seed": args.friction_seed,
                 "hull_sides": args.hull_sides, "contact_model": args.contact_model,
+                "self_collision": args.self_collision if NL == 32 else "flag on, inert and not evaluated for 16 links",
                 "world_size": (dist.get_world_size() if dist is not None else 1),
                 "backend": (dist.get_backend() if dist is not None else None),
                 "parallelism": "envs sharded over %d GPU(s), no data-path collective; "
