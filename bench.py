@@ -313,6 +313,8 @@ def main():
                     valu = {"wave_insts_per_launch": sq["SQ_INSTS_VALU"], "achieved_G_wave_insts_per_s": rate,
                             "measured_ceiling_G_wave_insts_per_s": peak, "frac": rate / peak,
                             "valu_active_per_wave": pm.get("derived", {}).get("valu_active_fraction_of_wave_cycles"),
+                            # two waves per SIMD share one VALU pipe: its busy fraction is what bounds this kernel
+                            "simd_valu_busy": 2.0 * (pm.get("derived", {}).get("valu_active_fraction_of_wave_cycles") or 0.0),
                             "profiled_kernel_ms": pm["kernel_trace_average_ms"]}
         except Exception:  # noqa: BLE001
             pass
