@@ -909,7 +909,10 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
     // the end of the last trip are zeroed: resolving them changes nothing (dI = 0 exactly).
     constexpr int kRing = LT::kRing;
     constexpr int kRows = LT::kRows;
-    const int nc_pad = (nc + kRing - 1) / kRing * kRing;
+    // contacts are resolved in groups of 8 behind one scalar branch: the rows between nc and the next multiple of 8
+    // are zeroed (inert), a ring trip ends at that multiple instead of running its full kRing steps (round 1 padded
+    // to a whole trip: 144 contacts -- 128 on the ground + 16 link-link -- cost 160)
+    const int nc_pad = (nc + 7) / 8 * 8;
     {
         float* z = rows + (size_t)3 * nc * LT::kRS;
         const int nz = 3 * (nc_pad - nc) * LT::kRS;
@@ -985,6 +988,7 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
                 off += kRing * ostep;
 #pragma unroll
                 for (int k = 0; k < kRing; k++) {
+                    if ((k & 7) == 0 && k > 0 && base + k >= nc_pad) break;      // wave-uniform
                     const float4 sc = sn;
                     sn = *reinterpret_cast<const float4*>(L.cN[base + k + 1]);
                     const float jv = jr[k], mv = mr[k];
@@ -1010,6 +1014,7 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
                     off += kC * ostep;
 #pragma unroll
                     for (int k = 0; k < kC; k++) {
+                        if ((k & 7) == 0 && k > 0 && base + k >= nc_pad) break;  // wave-uniform
                         const float4 c0 = f0, c1 = f1;
                         const float lim = ln;
                         f0 = *reinterpret_cast<const float4*>(L.cF[base + k + 1]);

@@ -9,7 +9,8 @@
 //       d == 22 : -rhs impulse               (RJ)        delta-v register holds +1 there
 //       d == 31 : accumulated impulse a      (RJ)        delta-v register holds -1 there
 //       d == 24 : row denominator J M^-1 J^T (RM; delta-v collects dI*den there: the residual)
-//       lane 57 : coupling scalar of the slot's two rows (RJ of a duo; delta-v is 0 there)
+//       lane 62 : coupling scalar of the slot's two rows (RJ of a duo, d = 30 of the upper half; delta-v is 0 there)
+//       d = 30, 29 of a friction slot: the 2 x 2 coupling block with the previous contact's pair (cone2_step)
 //     RJ = J / den (pre-scaled), RM = M^-1 J^T, both halves of `dv` carry the same delta-v.
 //     Then   sum_d RJ[d] dv[d] = (J.dv)/den - rhs - a   and the new accumulated impulse of
 //     the row is simply clamp(-sum): no per-row scalar is fetched from memory.
@@ -606,24 +607,26 @@ __device__ __forceinline__ float wrlane(float old, float v_uniform, int l) {
 // Two consecutive single rows living in the two halves of one slot (hand-written, 25 VALU):
 // lower-half row first, then the upper-half row.  One multiply and one reduction give both
 // sums  -(rhs - J.dv/den + a)  in lanes 31 / 63; they, the accumulated impulses (lanes 31 / 63
-// of RJ) and the coupling scalar c (lane 57 of RJ; delta-v is 0 there) are read into SGPRs and the clamps run on
+// of RJ) are read into SGPRs (the coupling scalar c stays in lane 62 of RJ, see below) and the clamps run on
 // wave-uniform values:  a' = med3(-sum, LO, HI), dI = a' - a;  the upper row's sum first
 // receives c * dI_lower.  v_cndmask gives every lane its own half's dI; the two contributions
 // to delta-v cross halves with v_permlane32_swap.  RES: also max |dI * den| (den: lane 24 / 56
 // of RM) into lsq.
+// 22 VALU (round 2; 25 before): the coupling scalar sits in lane d = 30 of RJ (lanes 30 / 62) and reaches the upper
+// row's partial sum through ONE v_fmac_f32_dpp (row_shr:1 puts RJ[62] under lane 63) -- no v_readlane of the scalar,
+// no v_mov of the upper sum into a VGPR; the price is that the upper sum is read after the lower row's clamp
+// (one scalar round trip longer, irrelevant: the kernel is VALU-issue-bound).
 #define SNK_DUO_HEAD                                     \
     "v_mul_f32 %[t], %[RJ], %[dv]\n\t"                    \
     "v_readlane_b32 %[s2], %[RJ], 31\n\t"                 \
     "v_readlane_b32 %[s3], %[RJ], 63\n\t"                 \
     SNK_REDUCE_12                                          \
-    "v_readlane_b32 %[s4], %[RJ], 57\n\t"                 \
-    "s_nop 0\n\t"                                         \
+    "s_nop 1\n\t"                                         \
     SNK_REDUCE_22                                          \
     "s_nop 1\n\t"                                         \
     SNK_REDUCE_345                                         \
     "v_readlane_b32 %[s0], %[t], 31\n\t"                  \
-    "v_readlane_b32 %[s1], %[t], 63\n\t"                  \
-    "s_nop 0\n\t"
+    "s_nop 1\n\t"
 #define SNK_DUO_TAIL                                     \
     "v_cndmask_b32_e64 %[t], %[dS], %[dF], %[lowmask]\n\t" \
     "v_mul_f32 %[x], %[RM], %[t]\n\t"                     \
@@ -638,32 +641,38 @@ template <bool RES, bool BOX>
 __device__ __forceinline__ void duo_step(float& RJ, const float RM, float& dv, float HI, float E3163,
                                          unsigned long long lowmask, float& lsq) {
     float t, x, dF, dS, c2;
-    float s0, s1, s2, s3, s4;
+    float s0, s1, s2, s3;
     if (!BOX) {
         asm volatile(
             SNK_DUO_HEAD
             "v_max_f32_e64 %[dF], -%[s0], 0\n\t"
-            "v_mov_b32 %[x], %[s1]\n\t"
             "v_subrev_f32 %[dF], %[s2], %[dF]\n\t"
-            "v_fmac_f32 %[x], %[s4], %[dF]\n\t"
-            "v_max_f32_e64 %[x], -%[x], 0\n\t"
+            "s_nop 0\n\t"
+            "v_fmac_f32_dpp %[t], %[RJ], %[dF] row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "s_nop 0\n\t"
+            "v_readlane_b32 %[s1], %[t], 63\n\t"
+            "s_nop 1\n\t"
+            "v_max_f32_e64 %[x], -%[s1], 0\n\t"
             "v_subrev_f32 %[dS], %[s3], %[x]\n\t"
             SNK_DUO_TAIL
             : [t] "=&v"(t), [x] "=&v"(x), [dF] "=&v"(dF), [dS] "=&v"(dS), [c2] "=&v"(c2), [s0] "=&s"(s0), [s1] "=&s"(s1),
-              [s2] "=&s"(s2), [s3] "=&s"(s3), [s4] "=&s"(s4), [RJ] "+v"(RJ), [dv] "+v"(dv)
+              [s2] "=&s"(s2), [s3] "=&s"(s3), [RJ] "+v"(RJ), [dv] "+v"(dv)
             : [RM] "v"(RM), [E] "v"(E3163), [lowmask] "s"(lowmask));
     } else
     asm volatile(
         SNK_DUO_HEAD
         "v_med3_f32 %[dF], -%[s0], -%[HI], %[HI]\n\t"
-        "v_mov_b32 %[x], %[s1]\n\t"
         "v_subrev_f32 %[dF], %[s2], %[dF]\n\t"
-        "v_fmac_f32 %[x], %[s4], %[dF]\n\t"
-        "v_med3_f32 %[x], -%[x], -%[HI], %[HI]\n\t"
+        "s_nop 0\n\t"
+        "v_fmac_f32_dpp %[t], %[RJ], %[dF] row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 0\n\t"
+        "v_readlane_b32 %[s1], %[t], 63\n\t"
+        "s_nop 1\n\t"
+        "v_med3_f32 %[x], -%[s1], -%[HI], %[HI]\n\t"
         "v_subrev_f32 %[dS], %[s3], %[x]\n\t"
         SNK_DUO_TAIL
         : [t] "=&v"(t), [x] "=&v"(x), [dF] "=&v"(dF), [dS] "=&v"(dS), [c2] "=&v"(c2), [s0] "=&s"(s0), [s1] "=&s"(s1),
-          [s2] "=&s"(s2), [s3] "=&s"(s3), [s4] "=&s"(s4), [RJ] "+v"(RJ), [dv] "+v"(dv)
+          [s2] "=&s"(s2), [s3] "=&s"(s3), [RJ] "+v"(RJ), [dv] "+v"(dv)
         : [RM] "v"(RM), [HI] "v"(HI), [E] "v"(E3163), [lowmask] "s"(lowmask));
     if (RES) asm volatile("v_max3_f32 %[lsq], %[lsq], |%[x]|, |%[c2]|" : [lsq] "+v"(lsq) : [x] "v"(x), [c2] "v"(c2));
 }
@@ -1043,7 +1052,7 @@ __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane, f
     }
 
     SNK_STAMP(10)
-    // coupling scalar of each duo, once per substep:  lane 57 of RJ <- RJ_upper . RM_lower
+    // coupling scalar of each duo, once per substep:  lane 62 of RJ <- RJ_upper . RM_lower
     // (the upper row is resolved after the lower one).  Pyramid friction resolves the two
     // directions of a contact one after the other, so its slots are duos as well.
     {
@@ -1051,14 +1060,14 @@ __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane, f
         for (int s = 0; s < kSlotFric; s++) {
             swap2 sw = half_swap(RM[s], RM[s]);             // a = [RM_lower, RM_lower], b = [RM_upper, RM_upper]
             float t = half_reduce(RJ[s] * sw.a);
-            RJ[s] = wrlane(RJ[s], rdlane(t, 63), 57);
+            RJ[s] = wrlane(RJ[s], rdlane(t, 63), 62);       // d = 30 of the upper half: duo_step's row_shr:1 source
         }
         if (M.cone == 0) {
 #pragma unroll
             for (int s = kSlotFric; s < kSlots; s++) {
                 swap2 sw = half_swap(RM[s], RM[s]);
                 float t = half_reduce(RJ[s] * sw.a);
-                RJ[s] = wrlane(RJ[s], rdlane(t, 63), 57);
+                RJ[s] = wrlane(RJ[s], rdlane(t, 63), 62);
             }
         } else {
             // cone friction resolves two contacts per step (cone2_step): the 2 x 2 coupling block of each pair of
