@@ -19,7 +19,8 @@ class SnkParams(C.Structure):
         ("n_modules", C.c_int32), ("inertia_from_file", C.c_int32),
         ("default_mass", C.c_double), ("collision_margin", C.c_double),
         ("hull_sides", C.c_int32), ("contact_model", C.c_int32),
-        ("self_collision", C.c_int32), ("reserved0", C.c_int32),
+        ("self_collision", C.c_int32), ("obstacle", C.c_int32),
+        ("obstacle_pos", C.c_double * 3), ("obstacle_half", C.c_double * 3), ("mu_obstacle", C.c_double),
         ("dt", C.c_double), ("gravity_z", C.c_double),
         ("lin_damping", C.c_double), ("ang_damping", C.c_double),
         ("joint_damping", C.c_double), ("max_coord_vel", C.c_double),
@@ -68,6 +69,7 @@ SYMBOLS = {
     "snk_get_obs": (C.c_int, [_vp, _F]),
     "snk_mean_height": (C.c_int, [_vp, _F]),
     "snk_link_positions": (C.c_int, [_vp, _F]),
+    "snk_joint3_reaction_fz": (C.c_int, [_vp, _F]),
     "snk_set_ground_friction": (C.c_int, [_vp, _F]),
     "snk_get_ground_friction": (C.c_int, [_vp, _F]),
     "snk_debug_set_tickets": (C.c_int, [_vp, C.c_uint32]),
@@ -123,9 +125,9 @@ def default_params(**over):
     p = SnkParams()
     load().snk_default_params(C.byref(p))
     for k, v in over.items():
-        if k == "aniso":
+        if k in ("aniso", "obstacle_pos", "obstacle_half"):
             for i in range(3):
-                p.aniso[i] = v[i]
+                getattr(p, k)[i] = v[i]
         else:
             if not hasattr(p, k):
                 raise AttributeError("snk_params has no field %r" % k)
@@ -238,6 +240,12 @@ class Stepper:
         """[n_envs, 3(n+1)]: getLinkPositions of every env ([x.., y.., z..] of links 0,3,...,3n)."""
         o = np.zeros((self.n_envs, 3 * (self.n + 1)), dtype=np.float32)
         check(self.lib.snk_link_positions(self.h, fptr(o)), "snk_link_positions")
+        return o
+
+    def joint3_reaction_fz(self):
+        """Fz of the first motor joint's reaction (Bullet joint 3) after the last substep, [n_envs]."""
+        o = np.zeros(self.n_envs, dtype=np.float32)
+        check(self.lib.snk_joint3_reaction_fz(self.h, fptr(o)), "snk_joint3_reaction_fz")
         return o
 
     def set_ground_friction(self, mu):

@@ -36,6 +36,7 @@ struct snk_handle {
     snk::HostModel H;
     snk::DevModel D;
     int n_envs, device, n, rec;
+    bool v2 = true;               // register-resident solve (16 links without an obstacle); else streamed rows
     snk::DevModel* d_model = nullptr;
     float* d_recs = nullptr;
     float* d_mu = nullptr;
@@ -68,38 +69,38 @@ struct snk_handle {
 
 namespace {
 
-template <int N>
+template <int N, bool V2>
 int launch_step(snk_handle* h, float* act, float* obs, float* rew, uint8_t* done, int32_t* sub, int vec_mode,
                 hipStream_t st) {
     if (h->use_sched) {
         hipLaunchKernelGGL((snk::plan_sched_kernel<N>), dim3(1), dim3(1024), 0, st, h->d_model, h->d_recs, act, h->sched,
                            h->n_envs);
-        hipLaunchKernelGGL((snk::env_step_sched_kernel<N>), dim3(h->grid_waves), dim3(64), h->lds_bytes, st, h->model_slot,
+        hipLaunchKernelGGL((snk::env_step_sched_kernel<N, V2>), dim3(h->grid_waves), dim3(64), h->lds_bytes, st, h->model_slot,
                            h->d_recs, h->d_mu, act, obs, rew, done, sub, vec_mode, h->n_envs, h->sched, h->d_rows, h->d_mf);
         return 0;
     }
     if (h->plan)
         hipLaunchKernelGGL((snk::plan_kernel<N>), dim3(1), dim3(1024), 0, st, h->d_model, h->d_recs, act, h->d_order,
                            h->n_envs);
-    hipLaunchKernelGGL((snk::env_step_kernel<N>), dim3(h->n_envs), dim3(64), h->lds_bytes, st, h->d_model, h->d_recs,
+    hipLaunchKernelGGL((snk::env_step_kernel<N, V2>), dim3(h->n_envs), dim3(64), h->lds_bytes, st, h->d_model, h->d_recs,
                        h->d_mu, act, obs, rew, done, sub, vec_mode, h->n_envs, h->plan ? h->d_order : nullptr, h->d_rows, h->d_mf);
     return 0;
 }
-template <int N>
+template <int N, bool V2>
 int launch_substep(snk_handle* h, const float* tgt, int k, int32_t* info, hipStream_t st) {
-    hipLaunchKernelGGL((snk::substep_kernel<N>), dim3(h->n_envs), dim3(64), h->lds_bytes, st, h->d_model, h->d_recs,
+    hipLaunchKernelGGL((snk::substep_kernel<N, V2>), dim3(h->n_envs), dim3(64), h->lds_bytes, st, h->d_model, h->d_recs,
                        h->d_mu, tgt, k, info, h->n_envs, h->d_rows, h->d_mf);
     return 0;
 }
-template <int N>
+template <int N, bool V2>
 int launch_reset(snk_handle* h, const uint8_t* mask, float* obs, int hard, hipStream_t st) {
-    hipLaunchKernelGGL((snk::reset_kernel<N>), dim3(h->n_envs), dim3(64), h->lds_bytes, st, h->d_recs, mask, obs, hard,
+    hipLaunchKernelGGL((snk::reset_kernel<N, V2>), dim3(h->n_envs), dim3(64), h->lds_bytes, st, h->d_recs, mask, obs, hard,
                        h->n_envs);
     return 0;
 }
-template <int N>
-int launch_obs(snk_handle* h, float* obs, float* height, hipStream_t st, float* linkpos = nullptr) {
-    hipLaunchKernelGGL((snk::obs_kernel<N>), dim3(h->n_envs), dim3(64), h->lds_bytes, st, h->d_model, h->d_recs, obs,
+template <int N, bool V2>
+int launch_obs(snk_handle* h, float* obs, float* height, hipStream_t st, float* linkpos) {
+    hipLaunchKernelGGL((snk::obs_kernel<N, V2>), dim3(h->n_envs), dim3(64), h->lds_bytes, st, h->d_model, h->d_recs, obs,
                        height, linkpos, h->n_envs);
     return 0;
 }
@@ -117,24 +118,27 @@ int resident_waves(size_t bytes, int device, int* out) {
     *out = per_cu * prop.multiProcessorCount;
     return 0;
 }
-template <int N>
+template <int N, bool V2>
 int set_lds_attr(size_t bytes) {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&snk::env_step_kernel<N>),
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&snk::env_step_kernel<N, V2>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&snk::env_step_sched_kernel<N>),
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&snk::env_step_sched_kernel<N, V2>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&snk::substep_kernel<N>),
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&snk::substep_kernel<N, V2>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&snk::reset_kernel<N>),
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&snk::reset_kernel<N, V2>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&snk::obs_kernel<N>),
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&snk::obs_kernel<N, V2>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     return 0;
 }
 
 // Kernels are instantiated for the chain lengths the BASELINE configs use.
-#define SNK_DISPATCH(h, CALL16, CALL32)                                       \
-    ((h)->n == 16 ? (CALL16) : ((h)->n == 32 ? (CALL32) : fail("unsupported n_modules (16 or 32)")))
+// (chain length, solve) pairs the kernels are instantiated for: 16 links with the register-resident solve, 16 and 32
+// links with the streamed-row solve (32: always; 16: when the world holds an obstacle, whose contacts need it)
+#define SNK_DISPATCH(h, FN, ...)                                                                            \
+    ((h)->n == 16 ? ((h)->v2 ? FN<16, true>(__VA_ARGS__) : FN<16, false>(__VA_ARGS__))                      \
+                  : ((h)->n == 32 ? FN<32, false>(__VA_ARGS__) : fail("unsupported n_modules (16 or 32)")))
 
 // slots of snk::g_models, shared by the handles of this process
 std::mutex g_slot_mutex;
@@ -179,6 +183,10 @@ void snk_default_params(snk_params* p) {
     p->hull_sides = 0;
     p->contact_model = 0;
     p->self_collision = 1;      // the reference loads the snake with URDF_USE_SELF_COLLISION (snake.py:93)
+    p->obstacle = 0;            // snake.py:94 has add_obstacle commented out; snake_gait_test.py:51 loads it
+    p->obstacle_pos[0] = 2.0; p->obstacle_pos[1] = 0.0; p->obstacle_pos[2] = 0.1;
+    p->obstacle_half[0] = 0.1; p->obstacle_half[1] = 0.4; p->obstacle_half[2] = 0.1;      // snake/block.urdf:16
+    p->mu_obstacle = 0.5;       // [U]
     p->dt = 1.0 / 240.0;
     p->gravity_z = -9.8;
     p->lin_damping = 0.04;
@@ -225,8 +233,9 @@ int init_handle(snk_handle* h, const snk_params* p, int32_t n_envs, int32_t devi
     snk::build_host_model(*p, h->H);
     snk::build_dev_model(*p, h->H, h->D);
     h->rec = h->D.rec_floats;
-    h->lds_bytes = h->n == 16 ? sizeof(snk::Lds<16, true>) : sizeof(snk::Lds<32, false>);
-    int rc = h->n == 16 ? set_lds_attr<16>(h->lds_bytes) : set_lds_attr<32>(h->lds_bytes);
+    h->v2 = h->n == 16 && !p->obstacle;        // the register-resident solve has no slot for obstacle contacts
+    h->lds_bytes = h->n == 16 ? (h->v2 ? sizeof(snk::Lds<16, true>) : sizeof(snk::Lds<16, false>)) : sizeof(snk::Lds<32, false>);
+    int rc = SNK_DISPATCH(h, set_lds_attr, h->lds_bytes);
     if (rc) return rc;
     const size_t ne = (size_t)n_envs;
     HIP_TRY(hipMalloc(&h->d_model, sizeof(snk::DevModel)));
@@ -246,8 +255,8 @@ int init_handle(snk_handle* h, const snk_params* p, int32_t n_envs, int32_t devi
     HIP_TRY(hipMalloc(&h->d_info, ne * 2 * sizeof(int32_t)));
     HIP_TRY(hipMalloc(&h->d_h, ne * sizeof(float)));
     HIP_TRY(hipMalloc(&h->d_order, ne * sizeof(int32_t)));
-    if (h->n == 32) {
-        const size_t bytes = ne * snk::Lds<32, false>::kRowFloats * sizeof(float);
+    if (!h->v2) {
+        const size_t bytes = ne * (h->n == 32 ? snk::Lds<32, false>::kRowFloats : snk::Lds<16, false>::kRowFloats) * sizeof(float);
         HIP_TRY(hipMalloc(&h->d_rows, bytes));
         HIP_TRY(hipMemset(h->d_rows, 0, bytes));     // the last three rows of every block stay zero for good
     }
@@ -293,7 +302,7 @@ int init_handle(snk_handle* h, const snk_params* p, int32_t n_envs, int32_t devi
 #endif
     }
     // hard reset (snake.py:88-95)
-    SNK_DISPATCH(h, launch_reset<16>(h, nullptr, nullptr, 1, nullptr), launch_reset<32>(h, nullptr, nullptr, 1, nullptr));
+    SNK_DISPATCH(h, launch_reset, h, nullptr, nullptr, 1, nullptr);
     if (check_launch()) return 1;
     HIP_TRY(hipDeviceSynchronize());
     return 0;
@@ -357,7 +366,7 @@ int snk_reset(snk_handle* h, const uint8_t* mask_dev, float* obs_dev, void* stre
     if (!h) return fail("snk_reset: null handle");
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t st = (hipStream_t)stream;
-    SNK_DISPATCH(h, launch_reset<16>(h, mask_dev, obs_dev, 0, st), launch_reset<32>(h, mask_dev, obs_dev, 0, st));
+    SNK_DISPATCH(h, launch_reset, h, mask_dev, obs_dev, 0, st);
     return check_launch();
 }
 
@@ -370,8 +379,7 @@ int snk_step(snk_handle* h, float* actions_dev, float* obs_dev, float* rew_dev, 
     hipStream_t st = (hipStream_t)stream;
     const bool timed = 2 * h->ev_used + 1 < (int)h->ev.size();
     if (timed) HIP_TRY(hipEventRecord(h->ev[2 * h->ev_used], st));
-    SNK_DISPATCH(h, launch_step<16>(h, actions_dev, obs_dev, rew_dev, done_dev, substeps_dev, vec_mode, st),
-                 launch_step<32>(h, actions_dev, obs_dev, rew_dev, done_dev, substeps_dev, vec_mode, st));
+    SNK_DISPATCH(h, launch_step, h, actions_dev, obs_dev, rew_dev, done_dev, substeps_dev, vec_mode, st);
     if (timed) {
         HIP_TRY(hipEventRecord(h->ev[2 * h->ev_used + 1], st));
         h->ev_used++;
@@ -446,7 +454,7 @@ int snk_substep_host(snk_handle* h, const float* targets, int32_t k, int32_t* in
     HIP_TRY(hipSetDevice(h->device));
     const size_t ne = (size_t)h->n_envs;
     HIP_TRY(hipMemcpy(h->d_tgt, targets, ne * h->n * sizeof(float), hipMemcpyHostToDevice));
-    SNK_DISPATCH(h, launch_substep<16>(h, h->d_tgt, k, h->d_info, nullptr), launch_substep<32>(h, h->d_tgt, k, h->d_info, nullptr));
+    SNK_DISPATCH(h, launch_substep, h, h->d_tgt, k, h->d_info, nullptr);
     if (check_launch()) return 1;
     HIP_TRY(hipDeviceSynchronize());
     if (info) HIP_TRY(hipMemcpy(info, h->d_info, ne * 2 * sizeof(int32_t), hipMemcpyDeviceToHost));
@@ -521,7 +529,7 @@ int snk_get_obs(snk_handle* h, float* obs) {
     if (!h || !obs) return fail("snk_get_obs: null argument");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipDeviceSynchronize());      // a step enqueued on a non-blocking stream may still be running
-    SNK_DISPATCH(h, launch_obs<16>(h, h->d_obs, nullptr, nullptr), launch_obs<32>(h, h->d_obs, nullptr, nullptr));
+    SNK_DISPATCH(h, launch_obs, h, h->d_obs, nullptr, nullptr, nullptr);
     if (check_launch()) return 1;
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(obs, h->d_obs, (size_t)h->n_envs * h->D.obs_dim * sizeof(float), hipMemcpyDeviceToHost));
@@ -532,7 +540,7 @@ int snk_mean_height(snk_handle* h, float* out) {
     if (!h || !out) return fail("snk_mean_height: null argument");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipDeviceSynchronize());      // a step enqueued on a non-blocking stream may still be running
-    SNK_DISPATCH(h, launch_obs<16>(h, nullptr, h->d_h, nullptr), launch_obs<32>(h, nullptr, h->d_h, nullptr));
+    SNK_DISPATCH(h, launch_obs, h, nullptr, h->d_h, nullptr, nullptr);
     if (check_launch()) return 1;
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(out, h->d_h, (size_t)h->n_envs * sizeof(float), hipMemcpyDeviceToHost));
@@ -545,8 +553,7 @@ int snk_link_positions(snk_handle* h, float* out) {
     HIP_TRY(hipDeviceSynchronize());      // a step enqueued on a non-blocking stream may still be running
     const size_t bytes = (size_t)h->n_envs * 3 * (h->n + 1) * sizeof(float);
     if (!h->d_linkpos) HIP_TRY(hipMalloc(&h->d_linkpos, bytes));
-    SNK_DISPATCH(h, launch_obs<16>(h, nullptr, nullptr, nullptr, h->d_linkpos),
-                 launch_obs<32>(h, nullptr, nullptr, nullptr, h->d_linkpos));
+    SNK_DISPATCH(h, launch_obs, h, nullptr, nullptr, nullptr, h->d_linkpos);
     if (check_launch()) return 1;
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(out, h->d_linkpos, bytes, hipMemcpyDeviceToHost));
@@ -558,6 +565,18 @@ int snk_set_ground_friction(snk_handle* h, const float* mu) {
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipDeviceSynchronize());      // a step enqueued on a non-blocking stream may still be running
     HIP_TRY(hipMemcpy(h->d_mu, mu, (size_t)h->n_envs * sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int snk_joint3_reaction_fz(snk_handle* h, float* out) {
+    if (!h || !out) return fail("snk_joint3_reaction_fz: null argument");
+    if (h->v2) return fail("snk_joint3_reaction_fz: evaluated by the streamed-row solve only (32 links, or an obstacle)");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipDeviceSynchronize());
+    const size_t ne = (size_t)h->n_envs;
+    std::vector<float> recs(ne * h->rec);
+    HIP_TRY(hipMemcpy(recs.data(), h->d_recs, recs.size() * sizeof(float), hipMemcpyDeviceToHost));
+    for (size_t e = 0; e < ne; e++) out[e] = recs[e * h->rec + 15 + 3 * h->n];      // behind prev_x in the record
     return 0;
 }
 

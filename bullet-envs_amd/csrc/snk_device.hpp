@@ -132,6 +132,7 @@ struct LdsCommon {
     __device__ __forceinline__ float* taum() { return rec + 13 + 2 * N; }
     __device__ __forceinline__ float& fz() { return rec[13 + 3 * N]; }
     __device__ __forceinline__ float& prev_x() { return rec[14 + 3 * N]; }
+    __device__ __forceinline__ float& fz3() { return rec[15 + 3 * N]; }   // reaction Fz of the first motor joint (streamed-row solve)
 };
 
 template <int N, bool V2>
@@ -883,7 +884,7 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
                         float* __restrict__ rows) {
     constexpr int N = LT::kN;
     constexpr int ND = N + 6;
-    static_assert(ND > 32 && ND <= 64, "this solve is laid out for one row per 64-lane register");
+    static_assert(ND <= 64, "this solve is laid out for one row per 64-lane register");
     constexpr int NR = LT::NR;
     const bool act = lane < ND;
     const int nlim = nn - N;                       // violated joint limits come first in the non-contact list
@@ -1072,7 +1073,8 @@ __device__ void substep_v1(LT& L, const DevModel& M, int lane, float mu, int& it
     int nc = find_contacts_v1(L, M, lane, rows, mf);
     if (lane == 0) L.nplane = nc;
     const int nplane = nc;
-    if (M.self_collision) nc += find_self_contacts_v1(L, M, lane, mu, rows);   // link-link contacts follow the ground's
+    if (M.self_collision || M.obstacle)
+        nc += find_self_contacts_v1(L, M, lane, mu, rows);   // link-link and obstacle contacts follow the ground's
     ncontacts = nc;
     __threadfence();      // contact geometry: written lane = slot, read lane = row
     lds_sync();
@@ -1090,6 +1092,14 @@ __device__ void substep_v1(LT& L, const DevModel& M, int lane, float mu, int& it
     float nv0 = sqrtf(dot(v_old, v_old));
     f3 a1 = ld3(&L.acc0[3]);
     float fz = -dot(zb, (a1 - mk3(0.f, 0.f, M.gz)) * M.m_root + v_old * (M.m_root * (M.lin_damp + M.lin_damp * nv0)));
+    // reaction through the first motor joint (Bullet joint 3, snake_gait_test.py:33-40): what body 0 does not use up
+    // of the forces on it, Newton on body 0 alone:  F = -(m_0 (a_0 + alpha_0 x c_0) + own force bias), z of body 1
+    auto joint1_fz = [&]() {
+        const f3 al0 = ld3(&L.acc0[0]), a0l = ld3(&L.acc0[3]);
+        const f3 F = -((a0l + cross(al0, ld3(L.cw[0]))) * M.mass[0] + ld3(&L.p[0][3]));
+        return F.x * L.R[1][2] + F.y * L.R[1][5] + F.z * L.R[1][8];
+    };
+    float fz3 = joint1_fz();
     // (3) v += a dt (clamped)
     if (lane < 6) {
         float x = L.base()[7 + lane] + L.acc0[lane] * dt;
@@ -1166,6 +1176,7 @@ __device__ void substep_v1(LT& L, const DevModel& M, int lane, float mu, int& it
             float nv1 = sqrtf(dot(v1, v1));
             f3 a2 = ld3(&L.acc0[3]);
             fz += -dot(zb, a2 * M.m_root + v1 * (M.m_root * (M.lin_damp + M.lin_damp * nv1)));
+            fz3 += joint1_fz();
         }
     }
     // (7) apply the solver's delta-v (clamped), motor torques, integrate positions
@@ -1204,6 +1215,7 @@ __device__ void substep_v1(LT& L, const DevModel& M, int lane, float mu, int& it
             bs[0] += dt * vl.x; bs[1] += dt * vl.y; bs[2] += dt * vl.z;
             bs[3] = nx * inv; bs[4] = ny * inv; bs[5] = nz * inv; bs[6] = nw * inv;
             L.fz() = fz;
+            L.fz3() = fz3;
         }
     }
     lds_sync();
@@ -1283,7 +1295,7 @@ __device__ __forceinline__ void soft_reset(LT& L, int lane) {
 // ----------------------------------------------------------------------------------
 // kernels
 // ----------------------------------------------------------------------------------
-template <int N>
+template <int N, bool V2>
 __global__ __launch_bounds__(64, 2) void env_step_kernel(const DevModel* __restrict__ Mp, float* __restrict__ recs,
                                                       const float* __restrict__ mu_plane,
                                                       float* __restrict__ actions, float* __restrict__ obs,
@@ -1292,7 +1304,7 @@ __global__ __launch_bounds__(64, 2) void env_step_kernel(const DevModel* __restr
                                                       const int32_t* __restrict__ order, float* __restrict__ rows_all,
                                                       float* __restrict__ mf_all) {
     extern __shared__ float4 smem_raw[];
-    using LT = Lds<N, (N == 16)>;
+    using LT = Lds<N, V2>;
     LT& L = *reinterpret_cast<LT*>(smem_raw);
     const DevModel& M = *Mp;
     if ((int)blockIdx.x >= n_envs) return;
@@ -1369,14 +1381,14 @@ __global__ __launch_bounds__(64, 2) void env_step_kernel(const DevModel* __restr
     store_rec(L, recs + (size_t)env * LT::REC, lane);
 }
 
-template <int N>
+template <int N, bool V2>
 __global__ __launch_bounds__(64, 2) void substep_kernel(const DevModel* __restrict__ Mp, float* __restrict__ recs,
                                                      const float* __restrict__ mu_plane,
                                                      const float* __restrict__ targets, int k,
                                                      int32_t* __restrict__ info, int n_envs, float* __restrict__ rows_all,
                                                      float* __restrict__ mf_all) {
     extern __shared__ float4 smem_raw[];
-    using LT = Lds<N, (N == 16)>;
+    using LT = Lds<N, V2>;
     LT& L = *reinterpret_cast<LT*>(smem_raw);
     const DevModel& M = *Mp;
     const int env = blockIdx.x;
@@ -1398,11 +1410,11 @@ __global__ __launch_bounds__(64, 2) void substep_kernel(const DevModel* __restri
     store_rec(L, recs + (size_t)env * LT::REC, lane);
 }
 
-template <int N>
+template <int N, bool V2>
 __global__ __launch_bounds__(64) void reset_kernel(float* __restrict__ recs, const uint8_t* __restrict__ mask,
                                                    float* __restrict__ obs, int hard, int n_envs) {
     extern __shared__ float4 smem_raw[];
-    using LT = Lds<N, (N == 16)>;
+    using LT = Lds<N, V2>;
     LT& L = *reinterpret_cast<LT*>(smem_raw);
     const int env = blockIdx.x;
     const int lane = threadIdx.x;
@@ -1421,12 +1433,12 @@ __global__ __launch_bounds__(64) void reset_kernel(float* __restrict__ recs, con
     store_rec(L, recs + (size_t)env * LT::REC, lane);
 }
 
-template <int N>
+template <int N, bool V2>
 __global__ __launch_bounds__(64) void obs_kernel(const DevModel* __restrict__ Mp, const float* __restrict__ recs,
                                                  float* __restrict__ obs, float* __restrict__ height,
                                                  float* __restrict__ linkpos, int n_envs) {
     extern __shared__ float4 smem_raw[];
-    using LT = Lds<N, (N == 16)>;
+    using LT = Lds<N, V2>;
     LT& L = *reinterpret_cast<LT*>(smem_raw);
     const DevModel& M = *Mp;
     const int env = blockIdx.x;
@@ -1704,7 +1716,7 @@ __global__ __launch_bounds__(1024) void plan_sched_kernel(const DevModel* __rest
     for (int e = tid + kKeep * 1024; e < n_envs; e += 1024) enqueue(e, key_of(e));
 }
 
-template <int N>
+template <int N, bool V2>
 __global__ __launch_bounds__(64, 2) void env_step_sched_kernel(int model_slot, float* __restrict__ recs,
                                                             const float* __restrict__ mu_plane,
                                                             float* __restrict__ actions, float* __restrict__ obs,
@@ -1713,7 +1725,7 @@ __global__ __launch_bounds__(64, 2) void env_step_sched_kernel(int model_slot, f
                                                             Sched sc, float* __restrict__ rows_all,
                                                             float* __restrict__ mf_all) {
     extern __shared__ float4 smem_raw[];
-    using LT = Lds<N, (N == 16)>;
+    using LT = Lds<N, V2>;
     LT& L = *reinterpret_cast<LT*>(smem_raw);
     const DevModel& M = g_models[model_slot];
     const int lane = threadIdx.x;

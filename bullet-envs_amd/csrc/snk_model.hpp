@@ -56,6 +56,8 @@ struct DevModel {
     // r (sin, cos)(2 pi s / hull_sides), the importer's vertex order; contact_model 1 = persistent manifold;
     // cyl_zoff = cylinder centre in its link's frame (snake.urdf:807,863), the manifold keeps link coordinates
     int hull_sides, contact_model, self_collision;
+    int obstacle;                        // a static box on the ground (snake/block.urdf), contacts through the streamed-row solve
+    float obs_c[3], obs_h[3], mu_obs;    // its centre, half extents, lateral friction
     float cyl_zoff;
     float hull_xy[32][2];
     // sensors
@@ -220,6 +222,9 @@ inline void build_dev_model(const snk_params& P, const HostModel& H, DevModel& D
     D.cyl_r = 0.026f; D.cyl_hl = 0.0165f;                               // snake.urdf:809
     D.hull_sides = P.hull_sides; D.contact_model = P.contact_model;
     D.self_collision = (P.self_collision && n == 32) ? 1 : 0;    // only the streamed-row solve builds link-link rows
+    D.obstacle = P.obstacle;
+    for (int i = 0; i < 3; i++) { D.obs_c[i] = (float)P.obstacle_pos[i]; D.obs_h[i] = (float)P.obstacle_half[i]; }
+    D.mu_obs = (float)P.mu_obstacle;
     D.cyl_zoff = 0.0183f;                                               // snake.urdf:807,863
     for (int s = 0; s < P.hull_sides && s < 32; s++) {
         const double th = 2.0 * 3.14159265358979323846 * s / P.hull_sides;

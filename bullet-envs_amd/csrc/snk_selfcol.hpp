@@ -22,8 +22,10 @@ namespace snk {
 constexpr float kShrink = 0.006f;
 
 struct Cvx {
-    f3 c;           // world centre of the cylinder
-    float R[9];     // world rotation of the cylinder's link frame
+    f3 c;           // world centre of the shape
+    float R[9];     // world rotation of its frame
+    int box;        // 0: one of the snake's cylinders; 1: the obstacle box (half extents below)
+    f3 half;
 };
 
 // support point of the core shape (radius and half length reduced by `shrink`) in world direction dw
@@ -31,7 +33,10 @@ __device__ __forceinline__ f3 support_core(const DevModel& M, const Cvx& s, f3 d
     const f3 dl = mulRtv(s.R, dw);
     const float rad = M.cyl_r - shrink, hl = M.cyl_hl - shrink;
     f3 v;
-    if (M.hull_sides > 0) {
+    if (s.box) {          // btBoxShape keeps its collision margin INSIDE the nominal box: the core is smaller by it
+        const f3 h = mk3(s.half.x - M.margin - shrink, s.half.y - M.margin - shrink, s.half.z - M.margin - shrink);
+        v = mk3(dl.x < 0.f ? -h.x : h.x, dl.y < 0.f ? -h.y : h.y, dl.z < 0.f ? -h.z : h.z);
+    } else if (M.hull_sides > 0) {
         const float sc = rad / M.cyl_r;
         float best = -3.0e38f;
         v = mk3(0.f, 0.f, 0.f);
@@ -240,6 +245,8 @@ __device__ int find_self_contacts_v1(LT& L, const DevModel& M, int lane, float m
             for (int j = 0; j < 3; j++)
                 s.R[3 * i + j] = Rb[3 * i] * Rc[j] + Rb[3 * i + 1] * Rc[3 + j] + Rb[3 * i + 2] * Rc[6 + j];
         s.c = ld3(L.o[b]) + mulRv(Rb, ld3(M.cyl_c[c]));
+        s.box = 0;
+        s.half = mk3(0.f, 0.f, 0.f);
     };
     // lane = cylinder a; pass = offset delta: the pairs (a, a + delta).  The other cylinder's centre comes from lane
     // a + delta through the LDS crossbar (ds_bpermute: no LDS memory).  All the neighbours-across-one-joint
@@ -249,7 +256,7 @@ __device__ int find_self_contacts_v1(LT& L, const DevModel& M, int lane, float m
     const int ba = (a + 1) >> 1;
     const f3 ca = ld3(L.o[ba]) + mulRv(L.R[ba], ld3(M.cyl_c[a]));
     int nself = 0;
-    for (int delta = 2; delta < NCYL; delta++) {
+    for (int delta = 2; delta < (M.self_collision ? NCYL : 0); delta++) {
         const int bc = a + delta;
         const bool valid = lane < NCYL && bc < NCYL;
         const int src = (bc < NCYL ? bc : NCYL - 1) << 2;
@@ -312,6 +319,70 @@ __device__ int find_self_contacts_v1(LT& L, const DevModel& M, int lane, float m
             }
         }
         nself += __popcll(bal);
+    }
+    // the obstacle box (static): lane = cylinder, one point per (cylinder, box) pair, normal from the box to the link,
+    // friction mu_link x mu_obstacle, directions scaled by the link's anisotropy only; the records follow the link-link ones
+    if (M.obstacle) {
+        Cvx Bx;
+        Bx.c = mk3(M.obs_c[0], M.obs_c[1], M.obs_c[2]);
+#pragma unroll
+        for (int i = 0; i < 9; i++) Bx.R[i] = (i % 4 == 0) ? 1.f : 0.f;
+        Bx.box = 1;
+        Bx.half = mk3(M.obs_h[0], M.obs_h[1], M.obs_h[2]);
+        const float rbox = sqrtf(dot(Bx.half, Bx.half));
+        const float mu_ob = fminf(M.mu_link * M.mu_obs, 10.0f);
+        const float rho_ob = mu_ground > 0.f ? mu_ob / mu_ground : 0.f;
+        const f3 d = ca - Bx.c;
+        const float reach_ob = rb + rbox + M.break_thr;
+        const bool cand = lane < NCYL && dot(d, d) <= reach_ob * reach_ob;
+        if (__any(cand)) {
+            bool hit = false;
+            f3 P = mk3(0, 0, 0), nrm = mk3(0, 0, 1);
+            float dist = 0.f;
+            Cvx A;
+            if (cand) {
+                frame(a, A);
+                f3 pa, pb;
+                float mg = M.margin;
+                float dd = gjk_distance(M, A, Bx, 0.f, pa, pb);
+                if (dd < 0.f) {
+                    dd = gjk_distance(M, A, Bx, kShrink, pa, pb);
+                    mg = M.margin + kShrink;
+                }
+                if (dd < 0.f) {
+                    const float nn = sqrtf(dot(d, d));
+                    nrm = nn > 0.f ? d * (1.0f / nn) : mk3(-1.f, 0.f, 0.f);
+                    P = A.c;
+                    dist = -2.0f * mg;
+                } else {
+                    nrm = (pa - pb) * (1.0f / dd);
+                    dist = dd - 2.0f * mg;
+                    P = pa - nrm * mg;
+                }
+                hit = dist < M.break_thr;
+            }
+            const unsigned long long bal = __ballot(hit);
+            if (hit) {
+                const int idx = nself + __popcll(bal & ((1ull << lane) - 1ull));
+                if (idx < LT::kMaxSelf) {
+                    float* geo = rows + LT::kGeoOff + (size_t)(LT::NC + idx) * LT::kGeo;
+                    f3 dA, dB;
+                    plane_space(nrm, dA, dB);
+                    dA = aniso_scale(M, A.R, dA);
+                    dB = aniso_scale(M, A.R, dB);
+                    st3(geo, P);
+                    geo[3] = dist;
+                    st3(geo + 4, dA);
+                    st3(geo + 7, dB);
+                    st3(geo + 10, nrm);
+                    st3(geo + 13, mk3(0.f, 0.f, 0.f));
+                    geo[16] = (float)((a + 1) >> 1);
+                    geo[17] = -1.0f;
+                    geo[18] = rho_ob;
+                }
+            }
+            nself += __popcll(bal);
+        }
     }
     return nself > LT::kMaxSelf ? LT::kMaxSelf : nself;
 }

@@ -40,7 +40,13 @@ typedef struct snk_params {
                                    URDF_USE_SELF_COLLISION (snake.py:93) switches on [U].  Evaluated for
                                    n_modules 32; for the 16-link snake they can never act inside the joint
                                    limits and no rows are built                               */
-    int32_t reserved0;          /* keeps the doubles behind it 8-byte aligned; must be 0                    */
+    int32_t obstacle;           /* 1: a box stands on the ground in front of the snake -- snake/block.urdf loaded by
+                                   Snake.add_obstacle (snake.py:83-84, commented out at :94) and by
+                                   snake_gait_test.py:51.  STATIC here (the reference's is a free 200-kg body).
+                                   Its contacts need the streamed-row solve (slower for 16 links). Default 0  */
+    double  obstacle_pos[3];    /* centre of the box: [2, 0, 0.1] (snake.py:94, snake_gait_test.py:51)         */
+    double  obstacle_half[3];   /* half extents: [0.1, 0.4, 0.1] (snake/block.urdf:16)                         */
+    double  mu_obstacle;        /* 0.5 [U]: Bullet's default lateral friction for a link without <contact>     */
     /* pybullet world */
     double  dt;                 /* 1/240 [U]: setTimeSteps is never called (snake.py:271-272) */
     double  gravity_z;          /* snake.py:8,91   -9.8                                       */
@@ -152,6 +158,12 @@ int snk_mean_height(snk_handle* h, float* out);
  * (SnakeGymEnv.py:43-44): world COM of Bullet links 0,3,...,3n of every env, host buffer
  * [n_envs x 3(n+1)] laid out [x_0..x_n, y_0..y_n, z_0..z_n]. */
 int snk_link_positions(snk_handle* h, float* out);
+
+/* Reaction force through the first motor joint (Bullet joint 3: INPUT_IF_1 -> OUTPUT_BODY_1), z component in the
+ * child link's frame, of every env's last physics substep: what snake_gait_test.py:33-40,126 reads
+ * (getJointState(robot, 3)[2][2], "> 20: the snake has hit the wall").  Host buffer [n_envs].  Evaluated by the
+ * streamed-row solve (32 links, or 16 links with an obstacle); fails for a register-resident 16-link handle. */
+int snk_joint3_reaction_fz(snk_handle* h, float* out);
 
 /* BASELINE config 5: per-env lateral friction of the ground plane (reference: plane.urdf = 1). */
 int snk_set_ground_friction(snk_handle* h, const float* mu /* host [n_envs] */);

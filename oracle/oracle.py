@@ -18,7 +18,8 @@ class OrcParams(C.Structure):
         ("n_modules", C.c_int32), ("inertia_from_file", C.c_int32),
         ("default_mass", C.c_double), ("collision_margin", C.c_double),
         ("hull_sides", C.c_int32), ("contact_model", C.c_int32), ("max_contacts", C.c_int32),
-        ("self_collision", C.c_int32), ("max_self_contacts", C.c_int32),
+        ("self_collision", C.c_int32), ("max_self_contacts", C.c_int32), ("obstacle", C.c_int32),
+        ("obstacle_pos", C.c_double * 3), ("obstacle_half", C.c_double * 3), ("mu_obstacle", C.c_double),
         ("dt", C.c_double), ("gravity_z", C.c_double),
         ("lin_damping", C.c_double), ("ang_damping", C.c_double),
         ("joint_damping", C.c_double), ("max_coord_vel", C.c_double),
@@ -75,6 +76,7 @@ def _load(f32=False):
         "orc_get_aux": (None, [vp, D, D, D]), "orc_set_aux": (None, [vp, D, C.c_double, C.c_double]),
         "orc_hard_reset": (None, [vp]), "orc_reset": (None, [vp, D]),
         "orc_get_obs": (None, [vp, D]), "orc_mean_height": (C.c_double, [vp]),
+        "orc_joint3_reaction_fz": (C.c_double, [vp]),
         "orc_substep": (None, [vp, D]),
         "orc_manifold_floats": (C.c_int32, [vp]),
         "orc_get_manifold": (None, [vp, D]), "orc_set_manifold": (None, [vp, D]),
@@ -102,9 +104,9 @@ def default_params(**over):
     p = OrcParams()
     _load().orc_default_params(C.byref(p))
     for k, v in over.items():
-        if k == "aniso":
+        if k in ("aniso", "obstacle_pos", "obstacle_half"):
             for i in range(3):
-                p.aniso[i] = v[i]
+                getattr(p, k)[i] = v[i]
         else:
             setattr(p, k, v)
     return p
@@ -202,6 +204,9 @@ class OracleEnv:
 
     def mean_height(self):
         return self.lib.orc_mean_height(self.h)
+
+    def joint3_reaction_fz(self):
+        return self.lib.orc_joint3_reaction_fz(self.h)
 
     def substep(self, targets):
         t = np.ascontiguousarray(targets, dtype=np.float64)

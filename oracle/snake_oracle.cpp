@@ -190,6 +190,7 @@ struct Contact {
     int linkB;
     Real PB[3], n[3];
     Real mu;     /* combined friction coefficient of the pair */
+    int kind;    /* 0 ground, 1 link-link, 2 obstacle box */
 };
 
 /* btPersistentManifold of one (ground, link collider) pair [U]: up to 4 cached points, each kept as the point
@@ -215,6 +216,7 @@ struct orc_env {
     Real pos[3], quat[4], omega[3], vel[3];
     std::vector<Real> q, qd, tau_motor;
     Real fz, prev_x;
+    Real fz3;                 /* reaction Fz through Bullet joint 3 (the first motor joint), last substep */
     double last_terminal_x;   /* base x of the last env-step's terminal observation (before any reset) */
     /* workspace, per link */
     std::vector<Real> Rw, ow, E, X, v, c, I6, IA, pA, U, a, S;
@@ -575,10 +577,10 @@ void base_acc_world(const orc_env* e, bool with_vel, Real* acc6) {
 
 /* wrench transmitted through Bullet joint 0 (root -> `base` link), link-1 coordinates:
  * spatInertia * spatAcc + zeroAccSpatFrc of that link [U] */
-void joint0_wrench(const orc_env* e, Real* w6) {
+void joint0_wrench(const orc_env* e, Real* w6, int link = 1) {
     Real t[6];
-    mat6_vec(&e->IA[36 * 1], &e->a[6 * 1], t);
-    for (int r = 0; r < 6; r++) w6[r] = t[r] + e->pA[6 * 1 + r];
+    mat6_vec(&e->IA[36 * link], &e->a[6 * link], t);
+    for (int r = 0; r < 6; r++) w6[r] = t[r] + e->pA[6 * link + r];
 }
 
 /* y = M^-1 J^T for a unit force along d at world point Pw on link `link` (or a unit
@@ -688,7 +690,7 @@ void find_contacts_stateless(orc_env* e) {
             Real w[3];
             mat3_vec(Rw, loc, w);
             Contact c;
-            c.link = i; c.linkB = -1; c.mu = 0;
+            c.link = i; c.linkB = -1; c.mu = 0; c.kind = 0;
             c.n[0] = 0; c.n[1] = 0; c.n[2] = 1; c.PB[0] = c.PB[1] = c.PB[2] = 0;
             for (int r = 0; r < 3; r++) c.P[r] = e->ow[3 * i + r] + w[r];
             c.dist = c.P[2];
@@ -798,7 +800,7 @@ void find_contacts_manifold(orc_env* e) {
         }
         for (int j = 0; j < m.n; j++) {
             Contact c;
-            c.link = i; c.linkB = -1; c.mu = 0;
+            c.link = i; c.linkB = -1; c.mu = 0; c.kind = 0;
             c.n[0] = 0; c.n[1] = 0; c.n[2] = 1; c.PB[0] = c.PB[1] = c.PB[2] = 0;
             for (int r = 0; r < 3; r++) c.P[r] = wa[j][r];
             c.dist = m.p[j].dist;
@@ -818,7 +820,7 @@ void find_contacts_manifold(orc_env* e) {
  * rounded at the rims -- and, if even those overlap (> 14 mm deep), a contact along the line of centres at that
  * depth (documented deviation; position motors of unlimited force can push links this deep). */
 const double kShrink = 0.006;
-struct Convex { const orc_env* e; int link; Real c[3]; const Real* R; Real shrink; };
+struct Convex { const orc_env* e; int link; Real c[3]; const Real* R; Real shrink; int box; Real half[3]; };
 
 void support_core(const Convex& s, const Real* dw, Real* out) {
     const orc_env* e = s.e;
@@ -826,7 +828,12 @@ void support_core(const Convex& s, const Real* dw, Real* out) {
     mat3T_vec(s.R, dw, dl);
     /* s.shrink > 0: the same shape with radius and half length reduced by that much (second tier, see below) */
     const Real rad = e->cyl_r - s.shrink, hl = e->cyl_len / 2 - s.shrink;
-    if (e->P.hull_sides > 0) {
+    if (s.box) {           /* btBoxShape: the collision margin lies INSIDE the nominal box, the core is smaller by it */
+        for (int r = 0; r < 3; r++) {
+            Real h = s.half[r] - (Real)e->P.collision_margin - s.shrink;
+            v[r] = dl[r] < 0 ? -h : h;
+        }
+    } else if (e->P.hull_sides > 0) {
         Real best = -std::numeric_limits<Real>::infinity();
         v[0] = v[1] = v[2] = 0;
         for (int k = 0; k < 2 * e->P.hull_sides; k++) {
@@ -975,7 +982,7 @@ void find_self_contacts(orc_env* e) {
     std::vector<Convex> cv(cyl.size());
     for (size_t a = 0; a < cyl.size(); a++) {
         int i = cyl[a];
-        cv[a].e = e; cv[a].link = i; cv[a].R = &e->Rw[9 * i]; cv[a].shrink = 0;
+        cv[a].e = e; cv[a].link = i; cv[a].R = &e->Rw[9 * i]; cv[a].shrink = 0; cv[a].box = 0;
         Real w[3];
         mat3_vec(cv[a].R, e->links[i].cyl_c, w);
         for (int r = 0; r < 3; r++) cv[a].c[r] = e->ow[3 * i + r] + w[r];
@@ -997,7 +1004,7 @@ void find_self_contacts(orc_env* e) {
                 mgx = mg + (Real)kShrink;
             }
             Contact c;
-            c.link = cv[a].link; c.linkB = cv[b].link; c.mu = mu;
+            c.link = cv[a].link; c.linkB = cv[b].link; c.mu = mu; c.kind = 1;
             if (dist < 0) {
                 Real nn = std::sqrt(dot3(d, d));
                 for (int r = 0; r < 3; r++) {
@@ -1014,16 +1021,64 @@ void find_self_contacts(orc_env* e) {
         }
 }
 
+/* Contacts with the obstacle box (snake/block.urdf placed by Snake.add_obstacle / snake_gait_test.py:51), kept STATIC
+ * here: one point per (cylinder link, box) pair per step from the same two-tier GJK, the normal pointing from the box
+ * to the link, friction mu_link x mu_obstacle [U], friction directions scaled by the link's anisotropy only. */
+void find_obstacle_contacts(orc_env* e) {
+    const orc_params& P = e->P;
+    static const Real Rid[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    const Real mg = (Real)P.collision_margin, thr = (Real)P.breaking_threshold;
+    Convex box;
+    box.e = e; box.link = -1; box.R = Rid; box.shrink = 0; box.box = 1;
+    for (int r = 0; r < 3; r++) { box.c[r] = (Real)P.obstacle_pos[r]; box.half[r] = (Real)P.obstacle_half[r]; }
+    const Real rb = std::sqrt(e->cyl_r * e->cyl_r + e->cyl_len * e->cyl_len / 4) + mg;
+    const Real rbox = std::sqrt(dot3(box.half, box.half));
+    Real mu = (Real)(P.mu_link * P.mu_obstacle);
+    if (mu > 10) mu = 10;
+    for (int i = 0; i < e->L; i++) {
+        if (!e->links[i].has_cyl) continue;
+        Convex cy;
+        cy.e = e; cy.link = i; cy.R = &e->Rw[9 * i]; cy.shrink = 0; cy.box = 0;
+        Real w[3];
+        mat3_vec(cy.R, e->links[i].cyl_c, w);
+        for (int r = 0; r < 3; r++) cy.c[r] = e->ow[3 * i + r] + w[r];
+        Real d[3] = {cy.c[0] - box.c[0], cy.c[1] - box.c[1], cy.c[2] - box.c[2]};
+        Real reach = rb + rbox + thr;
+        if (dot3(d, d) > reach * reach) continue;
+        Real pa[3], pb[3];
+        Real dist = gjk_distance(cy, box, pa, pb);
+        Real mgx = mg;
+        if (dist < 0) {
+            Convex sa = cy, sb = box;
+            sa.shrink = sb.shrink = (Real)kShrink;
+            dist = gjk_distance(sa, sb, pa, pb);
+            mgx = mg + (Real)kShrink;
+        }
+        Contact c;
+        c.link = i; c.linkB = -1; c.mu = mu; c.kind = 2;
+        c.PB[0] = c.PB[1] = c.PB[2] = 0;
+        if (dist < 0) {
+            Real nn = std::sqrt(dot3(d, d));
+            for (int r = 0; r < 3; r++) { c.n[r] = nn > 0 ? d[r] / nn : (r == 0 ? -1 : 0); c.P[r] = cy.c[r]; }
+            c.dist = -2 * mgx;
+        } else {
+            for (int r = 0; r < 3; r++) c.n[r] = (pa[r] - pb[r]) / dist;
+            c.dist = dist - 2 * mgx;
+            for (int r = 0; r < 3; r++) c.P[r] = pa[r] - mgx * c.n[r];
+        }
+        if (c.dist < thr) e->contacts.push_back(c);
+    }
+}
+
 void find_contacts(orc_env* e) {
     if (e->P.contact_model == 1) find_contacts_manifold(e);
     else find_contacts_stateless(e);
     if (e->P.max_contacts > 0 && (int)e->contacts.size() > e->P.max_contacts) e->contacts.resize(e->P.max_contacts);
-    if (e->P.self_collision) {
-        size_t before = e->contacts.size();
-        find_self_contacts(e);
-        if (e->P.max_self_contacts > 0 && e->contacts.size() > before + (size_t)e->P.max_self_contacts)
-            e->contacts.resize(before + e->P.max_self_contacts);
-    }
+    size_t before = e->contacts.size();
+    if (e->P.self_collision) find_self_contacts(e);
+    if (e->P.obstacle) find_obstacle_contacts(e);
+    if (e->P.max_self_contacts > 0 && e->contacts.size() > before + (size_t)e->P.max_self_contacts)
+        e->contacts.resize(before + e->P.max_self_contacts);
 }
 
 void apply_dv(orc_env* e, const Real* dvec, Real mult) {
@@ -1096,8 +1151,9 @@ void substep(orc_env* e, const Real* targets) {
     aba_solve(e, tau.data(), true, qdd.data());
     base_acc_world(e, true, acc.data());
     for (int j = 0; j < n; j++) acc[6 + j] = qdd[j];
-    Real w1[6];
+    Real w1[6], w1m[6];
     joint0_wrench(e, w1);   /* joint feedback, first (non-constraint) pass */
+    joint0_wrench(e, w1m, 4);   /* ... and of Bullet joint 3, INPUT_IF_1 -> OUTPUT_BODY_1 (snake_gait_test.py:33-40) */
 
     /* (3) v += a dt  (applyDeltaVeeMultiDof, clamped) */
     apply_dv(e, acc.data(), dt);
@@ -1165,7 +1221,7 @@ void substep(orc_env* e, const Real* targets) {
     };
     for (int ci = 0; ci < nc; ci++) {
         Contact& c = e->contacts[ci];
-        if (c.linkB < 0) c.mu = mu;
+        if (c.kind == 0) c.mu = mu;
         Real nrm[3] = {c.n[0], c.n[1], c.n[2]};
         Row row;
         row.kind = 2; row.joint = -1; row.contact = ci;
@@ -1307,6 +1363,9 @@ void substep(orc_env* e, const Real* targets) {
     Real w2[6];
     joint0_wrench(e, w2);
     e->fz = w1[5] + w2[5];   /* linear z in the `base` link frame = getJointState(0)[2][2] */
+    Real w2m[6];
+    joint0_wrench(e, w2m, 4);
+    e->fz3 = w1m[5] + w2m[5];
 
     /* (7) apply solver delta-v (processDeltaVeeMultiDof2), motor torques, integrate */
     apply_dv(e, dv.data(), 1);
@@ -1366,6 +1425,10 @@ void orc_default_params(orc_params* p) {
     p->max_contacts = 0;
     p->self_collision = 0;   /* 1 = link-link contacts (URDF_USE_SELF_COLLISION, snake.py:93); tests switch it on */
     p->max_self_contacts = 0;
+    p->obstacle = 0;
+    p->obstacle_pos[0] = 2.0; p->obstacle_pos[1] = 0.0; p->obstacle_pos[2] = 0.1;      /* snake.py:94 */
+    p->obstacle_half[0] = 0.1; p->obstacle_half[1] = 0.4; p->obstacle_half[2] = 0.1;   /* snake/block.urdf:16 */
+    p->mu_obstacle = 0.5;
     p->contact_model = 0;/* stateless two-point manifold (default here); 1 = Bullet's persistent manifold [U] */
     p->dt = 1.0 / 240.0;
     p->gravity_z = -9.8;
@@ -1493,6 +1556,7 @@ void orc_reset(orc_env* e, double* obs) {
     if (obs) memcpy(obs, o.data(), sizeof(double) * o.size());
 }
 void orc_get_obs(const orc_env* e, double* obs) { get_obs(e, obs); }
+double orc_joint3_reaction_fz(const orc_env* e) { return (double)e->fz3; }
 double orc_mean_height(orc_env* e) { return (double)mean_height(e); }
 
 void orc_substep(orc_env* e, const double* targets_n) {

@@ -51,7 +51,12 @@ typedef struct orc_params {
                                * For the 16-link snake the rows are speculative only and never carry an impulse
                                * inside the joint limits (tools/self_collision_clearance.py, and a test);
                                * the 32-link tests switch it on (the product evaluates it for 32 links)        */
-    int32_t max_self_contacts;/* 0 = no limit; > 0 mirrors the product's cap on link-link contacts (tests)    */
+    int32_t max_self_contacts;/* 0 = no limit; > 0 mirrors the product's cap on link-link + obstacle contacts  */
+    int32_t obstacle;         /* 1: a STATIC box on the ground (snake/block.urdf; snake.py:83-84,94,
+                               * snake_gait_test.py:51 -- a free 200-kg body there: documented deviation)      */
+    double  obstacle_pos[3];  /* centre [2, 0, 0.1]                                                            */
+    double  obstacle_half[3]; /* half extents [0.1, 0.4, 0.1] (block.urdf:16)                                  */
+    double  mu_obstacle;      /* 0.5 [U]                                                                       */
     /* world / integrator */
     double  dt;               /* PyBullet default fixedTimeStep 1/240 [U] (F2)           */
     double  gravity_z;        /* snake.py:8  -9.8                                        */
@@ -114,6 +119,8 @@ void     orc_hard_reset(orc_env* e);                  /* snake.py:88-95  */
 void     orc_reset(orc_env* e, double* obs);          /* SnakeGymEnv.py:28-31 (soft) */
 void     orc_get_obs(const orc_env* e, double* obs);  /* snake.py:209-217 */
 double   orc_mean_height(orc_env* e);                 /* snake.py:237-245 (value) */
+/* getJointState(robot, 3)[2][2] of the last substep (snake_gait_test.py:33-40,126: "> 20: hit the wall") */
+double   orc_joint3_reaction_fz(const orc_env* e);
 
 /* contact cache of contact_model 1, per cylinder in link order:
  * [count, 4 x (point on the link in link coordinates 3, point on the ground in world coordinates 3)] */

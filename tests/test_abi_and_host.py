@@ -68,8 +68,8 @@ def test_oracle_and_product_defaults_agree(pkg, oracle_mod):
             assert getattr(a, name) == 1 and getattr(b, name) == 0
             continue
         va, vb = getattr(a, name), getattr(b, name)
-        if name == "aniso":
-            assert list(va) == list(vb)
+        if name in ("aniso", "obstacle_pos", "obstacle_half"):
+            assert list(va) == list(vb), name
         else:
             assert va == vb, name
 

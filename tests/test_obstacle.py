@@ -1,0 +1,113 @@
+"""The obstacle block of the reference's gait-test script: `snake/block.urdf`, a 0.2 x 0.8 x 0.2 m box
+that `Snake.add_obstacle` (/root/reference/snake.py:83-84; commented out on the training path, :94) and
+`snake_gait_test.py:51` put in front of the snake, and the script's "hit the wall" read-out: the z component of the
+first motor joint's reaction force (`getJointState(robot, 3)[2][2] > 20`, snake_gait_test.py:33-40,126).
+
+Here the box is STATIC (the reference's is a free 200-kg body resting on the ground: a documented deviation; the snake's
+4-N-m motors cannot move it).  Contacts: GJK between each cylinder and the box, one point per pair per step, rows through
+the streamed-row solve -- which a 16-link handle with `obstacle=1` therefore runs (the register-resident solve has no
+free contact slot when the snake lies flat).
+
+Tolerances: one env-step from a synchronised state, float32 GPU vs float64 oracle, judged against the float32 build of
+the oracle on the same step (factor 3, floors 1e-3 on angles / pose, 5e-2 relative on joint velocities, 2 N on the
+reaction force, which is impulse / dt: a 240x amplification of the solver's round-off)."""
+import numpy as np
+import pytest
+
+gpu = pytest.mark.gpu
+BOX = dict(obstacle=1, obstacle_pos=[0.100, 0.0, 0.1])        # its face 2 mm in front of the resting snake's head
+
+
+def test_oracle_box_stops_the_snake_and_trips_the_wall_signal(oracle_mod):
+    import bench
+    e = oracle_mod.OracleEnv(**BOX)
+    p = oracle_mod.OracleEnv()
+    e.reset(); p.reset()
+    mx = mx_free = 0.0
+    for j in range(12):
+        a = bench.gait_actions([5], j)[0]
+        o, _, _, _, _ = e.env_step(a.copy(), vec_mode=False)
+        o2, _, _, _, _ = p.env_step(a.copy(), vec_mode=False)
+        mx = max(mx, abs(e.joint3_reaction_fz()))
+        mx_free = max(mx_free, abs(p.joint3_reaction_fz()))
+    assert o2[48] > 0.01 and o[48] < 0.003          # the free snake advances, the box holds the other back
+    assert mx > 20.0 and mx_free < 10.0             # snake_gait_test.py:126's threshold separates the two
+
+
+@gpu
+@pytest.mark.parametrize("n", [16, 32])
+def test_obstacle_env_step_parity(pkg, oracle_mod, n):
+    import bench
+    B, J = 8, 6
+    A = n // 2
+    ids = np.arange(B)
+    over = dict(BOX, n_modules=n)
+    st = pkg.Stepper(B, **over)
+    st.reset()
+    sc = 1 if n == 32 else 0                       # what the kernels evaluate for this chain length
+    refs = [oracle_mod.OracleEnv(self_collision=sc, max_self_contacts=32, **over) for _ in range(B)]
+    refs32 = [oracle_mod.OracleEnv(self_collision=sc, max_self_contacts=32, f32=True, **over) for _ in range(B)]
+    w = dict(q=0.0, qd=0.0, r=0.0, f3=0.0)
+    c = dict(q=0.0, qd=0.0, r=0.0, f3=0.0)
+    mism = touched = 0
+    for j in range(J):
+        S, X = st.get_state()
+        a = bench.gait_actions(ids + 5, j, A).astype(np.float32)
+        obs, rew, done, sub = st.step(a.copy(), vec_mode=False)
+        f3 = st.joint3_reaction_fz()
+        for i in range(B):
+            out = []
+            for e in (refs[i], refs32[i]):
+                e.set_state(S[i].astype(np.float64))
+                e.set_aux(X[i, :n].astype(np.float64), float(X[i, n]), float(X[i, n + 1]))
+                out.append(e.env_step(a[i].astype(np.float64), vec_mode=False) + (e.joint3_reaction_fz(),))
+            (o, r, d, k, _, g3), (o32, r32, d32, k32, _, g32) = out
+            if refs[i].last_num_contacts > 4 * n:
+                touched += 1
+
+            def errs(oo, rr, ff):
+                q = max(np.abs(oo[:n] - o[:n]).max(), np.abs(oo[3 * n:3 * n + 7] - o[3 * n:3 * n + 7]).max())
+                qd = (np.abs(oo[n:2 * n] - o[n:2 * n]) / (1 + np.abs(o[n:2 * n]))).max()
+                return dict(q=q, qd=qd, r=abs(rr - r), f3=abs(ff - g3))
+            if k32 == k and d32 == d:
+                for key, v in errs(o32, r32, g32).items():
+                    c[key] = max(c[key], v)
+            if k != sub[i] or d != bool(done[i]):
+                mism += 1
+                assert abs(k - sub[i]) <= 1
+                continue
+            if k == 0:
+                continue                          # no substep ran: the read-out keeps its previous value
+            for key, v in errs(obs[i].astype(np.float64), float(rew[i]), float(f3[i])).items():
+                w[key] = max(w[key], v)
+    print("obstacle parity n =", n, "GPU-f32", w, "| oracle-f32", c, "| boundary mismatches", mism, "| steps touching the box", touched)
+    assert touched >= B
+    assert mism <= max(2, B * J // 10)
+    assert w["q"] < max(1e-3, 3 * c["q"]) and w["qd"] < max(5e-2, 3 * c["qd"])
+    assert w["r"] < max(5e-3, 3 * c["r"]) and w["f3"] < max(2.0, 3 * c["f3"])
+    st.close()
+
+
+@gpu
+def test_wall_signal_on_device(pkg):
+    """Free-running: with the box in its way the 16-link snake stays put and the first motor joint's reaction exceeds the
+    script's threshold; without it neither happens.  Also: the read-out needs the streamed-row solve."""
+    import bench
+    B = 16
+    ids = np.arange(B) + 5
+    res = {}
+    for name, over in (("box", BOX), ("free", dict(obstacle=1, obstacle_pos=[5.0, 0.0, 0.1]))):
+        st = pkg.Stepper(B, **over)
+        st.reset()
+        mx = np.zeros(B)
+        for j in range(12):
+            o, r, d, s = st.step(bench.gait_actions(ids, j).astype(np.float32), vec_mode=False)
+            mx = np.maximum(mx, np.abs(st.joint3_reaction_fz()))
+        res[name] = (o[:, 48].copy(), mx)
+        st.close()
+    assert np.median(res["free"][0]) > 0.01 and np.median(res["box"][0]) < 0.004
+    assert np.median(res["box"][1]) > 20.0 and np.median(res["free"][1]) < 10.0
+    plain = pkg.Stepper(2)
+    with pytest.raises(RuntimeError):
+        plain.joint3_reaction_fz()
+    plain.close()
