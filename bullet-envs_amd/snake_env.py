@@ -118,6 +118,17 @@ class Snake(object):
         self._need_env()._reset_robot(hardReset)
         return True
 
+    def add_obstacle(self, urdf_file, position):
+        """snake.py:83-84: loads snake/block.urdf at `position` ([2, 0, 0.1] at snake.py:94 and
+        snake_gait_test.py:51).  The box is the one of block.urdf (0.2 x 0.8 x 0.2 m) whatever `urdf_file` says, and it
+        is static here.  Takes effect with a hard reset of the world, like loadURDF."""
+        env = self._need_env()
+        env.params.obstacle = 1
+        for i in range(3):
+            env.params.obstacle_pos[i] = float(position[i])
+        env._reset_robot(True)
+        self.obstacle = 0          # the reference keeps the body id here
+
 
 class SnakeGymEnv(object):
     """Single environment with SnakeGymEnv's API, backed by a 1-env GPU stepper."""

@@ -111,3 +111,19 @@ def test_wall_signal_on_device(pkg):
     with pytest.raises(RuntimeError):
         plain.joint3_reaction_fz()
     plain.close()
+
+
+@gpu
+def test_add_obstacle_mirror(pkg):
+    """Snake.add_obstacle (snake.py:83-84) on the single-env mirror: the world is rebuilt with the box in it."""
+    robot = pkg.Snake(None, "snake/snake.urdf", None)
+    env = pkg.SnakeGymEnv(robot, None)
+    robot.add_obstacle("block.urdf", [0.100, 0.0, 0.1])
+    assert env.params.obstacle == 1
+    import bench
+    mx = 0.0
+    for j in range(12):
+        o, r, d, info = env.step(bench.gait_actions([5], j)[0].astype(np.float64))
+        mx = max(mx, abs(float(env._stepper.joint3_reaction_fz()[0])))
+    assert o[48] < 0.004 and mx > 20.0
+    env.close()
