@@ -17,8 +17,8 @@ ap.add_argument("--command", default="python3 bench.py --steps 10 --warmup 2 --n
 ap.add_argument("--skip", type=int, default=2, help="leading launches left out of the per-launch means (warm-up)")
 a = ap.parse_args()
 src, tag, N = a.src, a.tag, a.links
-K = a.kernel or 'env_step_sched_kernel<%d>' % N
-RK = 'reset_kernel<%d>' % N
+K = a.kernel or 'env_step_sched_kernel<%d,' % N     # <N, rows-in-registers?>
+RK = 'reset_kernel<%d,' % N
 
 
 def one(pattern, required=True):
@@ -48,12 +48,12 @@ fs, ws = f['FETCH_SIZE'][a.skip:], w['WRITE_SIZE'][a.skip:]
 fetch_kb, write_kb = sum(fs) / len(fs), sum(ws) / len(ws)
 rec_kb = 4096 * (256 if N == 16 else 512) / 1024.0
 out = {
-    "round": a.round, "tag": tag, "kernel": "snk::" + K,
+    "round": a.round, "tag": tag, "kernel": "snk::" + K.rstrip(",") + (", ...>" if K.endswith(",") else ""),
     "workload": a.workload,
     "command": "rocprofv3 --pmc <counters> --output-format csv -- %s  (FETCH_SIZE, WRITE_SIZE and the SQ set in "
                "separate passes; kernel trace in its own pass)" % a.command,
     "kernel_trace_average_ms": kavg,
-    "calibration": {"kernel": "snk::" + RK, "known_read_KB": rec_kb, "FETCH_SIZE_KB": fr['FETCH_SIZE'],
+    "calibration": {"kernel": "snk::" + RK.rstrip(",") + ", ...>", "known_read_KB": rec_kb, "FETCH_SIZE_KB": fr['FETCH_SIZE'],
                     "known_write_KB_record_only": rec_kb, "WRITE_SIZE_KB": wr['WRITE_SIZE'],
                     "conclusion": "FETCH_SIZE reads 1/2 of the bytes of this 4-B-per-lane coalesced record load "
                                   "(gfx950 rule of MI355X_MICROARCH.md); WRITE_SIZE exact"},
