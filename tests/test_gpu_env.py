@@ -651,3 +651,22 @@ def test_bench_multi_rank_rehearsal():
     r = json.loads(lines[0])
     assert r["n_gpus"] == 2 and r["steps"] == 2 and r["scaling"] == "weak" and r["value"] > 0
     assert r["config"]["envs_per_gpu"] == 512 and r.get("cpu_baseline") is None      # the CPU baseline is an N = 1 leg
+
+
+@pytest.mark.gpu
+def test_test_mode_telemetry_follows_overridden_parameters(pkg):
+    """gait / scaling_factor passed through **over reach the device but not the robot facade; the test-mode
+    replay must take them from the parameters the device uses (it raised "replay diverged" before)."""
+    class Args:
+        alpha, beta, gamma = 1.0, 0.01, 0.1
+        gaitSelection, scaling_factor, mode = 1, 6.0, 'test'
+        motorVelocityLimit, motorTorqueLimit = np.inf, np.inf
+    robot = pkg.Snake(None, "snake/snake.urdf", Args())
+    env = pkg.SnakeGymEnv(robot, Args(), gait=0, scaling_factor=np.pi / 5)      # overrides the args' gait 1, pi/6
+    env.reset()
+    o, r, d, info = env.step(np.linspace(-0.8, 0.8, 8))
+    assert len(info['internal_observations']) == robot.counter >= 1
+    assert np.array_equal(info['internal_observations'][-1].astype(np.float32), o.astype(np.float32))
+    q = info['internal_observations'][-1][:16]
+    assert np.abs(q[1::2]).max() < 1e-3 and np.abs(q[0::2]).max() > 0.05          # gait 0 drives the even slots
+    env.close()
