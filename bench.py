@@ -159,6 +159,8 @@ def main():
                          "the 32-link kernels; 0 switches them off (round-1 state of configs[3])")
     ap.add_argument("--cpu-steps", type=int, default=2000,
                     help="env-steps of the CPU baseline (BASELINE.md B3: 2000 after 20 warm-up steps)")
+    ap.add_argument("--no-variants", action="store_true",
+                    help="skip the extra measurement of Bullet's own contact model (1 GPU, default configuration only)")
     ap.add_argument("--policy", action="store_true",
                     help="not the BASELINE metric: actions sampled from an on-device 2x256 actor-critic "
                          "(bullet-envs_amd/rollout.py, SURVEY 8(f)-1) instead of the precomputed gait; 1 GPU")
@@ -277,6 +279,30 @@ def main():
     elapsed = float(t_el.item())
     substeps = float(subs.item())
 
+    # Not the headline: the same K steps under Bullet's own contact handling (32-gon hulls + persistent manifold,
+    # DESIGN.md 3), after and outside the timed region of the headline, so that the record shows what that model costs.
+    variants = None
+    if (world == 1 and not args.no_variants and not args.policy and NL == 16 and not args.hull_sides
+            and not args.contact_model and args.friction_seed is None):
+        v_env = pkg.DeviceVecEnv(E, device_index=local_rank, n_modules=NL, hull_sides=32, contact_model=1)
+        v_env.reset()
+        v_sub = torch.zeros((), dtype=torch.int64, device=dev)
+        for j in range(W):
+            v_env.step(acts_all[j].clone())
+        torch.cuda.synchronize()
+        tv = time.perf_counter()
+        for j in range(W, W + K):
+            v_env.step(acts_all[j].clone())
+            v_sub.add_(v_env.substeps.sum())
+        torch.cuda.synchronize()
+        tv = time.perf_counter() - tv
+        variants = {"bullet_contact_model": {
+            "value": E * K / tv, "unit": "env-steps/s", "hull_sides": 32, "contact_model": 1,
+            "mean_substeps_per_env_step": float(v_sub.item()) / (E * K),
+            "note": "same action stream; PyBullet's 32-gon hull import + Bullet's persistent <= 4-point manifold instead "
+                    "of the default stateless manifold on implicit cylinders (DESIGN.md 3)"}}
+        v_env.close()
+
     if rank == 0:
         n_env_steps = world * E * K
         # per-launch algorithmic bytes of the dominant kernel on this rank
@@ -358,6 +384,7 @@ def main():
                         "reported as the contract asks, it is not the limiter (DESIGN.md §5)",
             },
             "cpu_baseline": cpu,
+            "variants": variants,
         }
         print(json.dumps(out))
     if dist is not None:

@@ -9,11 +9,11 @@ sq=0
 if [ "$1" = "sq" ]; then sq=1; shift; fi
 [ "$1" = "--" ] && shift
 mkdir -p "$out"
-rocprofv3 --kernel-trace --stats -d "$out/trace" --output-format csv -- python3 bench.py "$@" --no-cpu-baseline > "$out/trace.log" 2>&1
-rocprofv3 --pmc FETCH_SIZE -d "$out/pmc_fetch" --output-format csv -- python3 bench.py "$@" --no-cpu-baseline > "$out/f.log" 2>&1
-rocprofv3 --pmc WRITE_SIZE -d "$out/pmc_write" --output-format csv -- python3 bench.py "$@" --no-cpu-baseline > "$out/w.log" 2>&1
+rocprofv3 --kernel-trace --stats -d "$out/trace" --output-format csv -- python3 bench.py "$@" --no-cpu-baseline --no-variants > "$out/trace.log" 2>&1
+rocprofv3 --pmc FETCH_SIZE -d "$out/pmc_fetch" --output-format csv -- python3 bench.py "$@" --no-cpu-baseline --no-variants > "$out/f.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE -d "$out/pmc_write" --output-format csv -- python3 bench.py "$@" --no-cpu-baseline --no-variants > "$out/w.log" 2>&1
 if [ $sq = 1 ]; then
   rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_SALU SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAVES SQ_WAVE_CYCLES \
-    -d "$out/pmc_sq" --output-format csv -- python3 bench.py "$@" --no-cpu-baseline > "$out/sq.log" 2>&1
+    -d "$out/pmc_sq" --output-format csv -- python3 bench.py "$@" --no-cpu-baseline --no-variants > "$out/sq.log" 2>&1
 fi
 echo "profiled: $out"
