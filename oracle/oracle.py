@@ -89,6 +89,9 @@ def _load(f32=False):
         "orc_momentum": (None, [vp, D, D, D]),
         "orc_contacts": (C.c_int32, [vp, D, C.c_int32]),
         "orc_last_normal_impulses": (C.c_int32, [vp, D, C.c_int32]),
+        "orc_cylinder_frames": (C.c_int32, [vp, D]),
+        "orc_debug_gjk": (C.c_double, [vp, D, D, D]),
+        "orc_contacts_full": (C.c_int32, [vp, D, C.c_int32]),
         "orc_bench_gait": (C.c_double, [C.POINTER(OrcParams), C.c_int32, D, D, C.c_int32, C.c_int32, C.c_int32,
                                         C.POINTER(C.c_int64), D]),
     }
@@ -274,6 +277,25 @@ class OracleEnv:
     def contacts(self, maxc=256):
         out = np.zeros((maxc, 5))
         nc = self.lib.orc_contacts(self.h, _dp(out), maxc)
+        return out[:nc]
+
+    def cylinder_frames(self):
+        """[2n, 12]: world centre (3) and rotation (9, row-major) of every collision cylinder, link order."""
+        out = np.zeros((2 * self.n, 12))
+        self.lib.orc_cylinder_frames(self.h, _dp(out))
+        return out
+
+    def debug_gjk(self, fa, fb):
+        """Core distance (no margins) between two cylinders given as [centre 3, rotation 9]; (dist, pa, pb)."""
+        fa = np.ascontiguousarray(fa, dtype=np.float64); fb = np.ascontiguousarray(fb, dtype=np.float64)
+        out = np.zeros(6)
+        d = self.lib.orc_debug_gjk(self.h, _dp(fa), _dp(fb), _dp(out))
+        return d, out[:3], out[3:]
+
+    def contacts_full(self, maxc=512):
+        """[nc, 12]: P, dist, link, linkB, normal, PB of every contact of the current pose."""
+        out = np.zeros((maxc, 12))
+        nc = self.lib.orc_contacts_full(self.h, _dp(out), maxc)
         return out[:nc]
 
     def last_normal_impulses(self, maxc=256):

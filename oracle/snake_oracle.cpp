@@ -1712,6 +1712,46 @@ int32_t orc_contacts(orc_env* e, double* out, int32_t maxc) {
     }
     return nc;
 }
+/* world frame of every collision cylinder, in link order: centre (3) then rotation (9, row-major); returns their count */
+int32_t orc_cylinder_frames(orc_env* e, double* out) {
+    if (!e->fk_valid) fk(e);
+    int c = 0;
+    for (int i = 0; i < e->L; i++) {
+        if (!e->links[i].has_cyl) continue;
+        Real w[3];
+        mat3_vec(&e->Rw[9 * i], e->links[i].cyl_c, w);
+        for (int r = 0; r < 3; r++) out[12 * c + r] = e->ow[3 * i + r] + w[r];
+        for (int r = 0; r < 9; r++) out[12 * c + 3 + r] = e->Rw[9 * i + r];
+        c++;
+    }
+    return c;
+}
+/* test hook: core distance between two cylinders given as [centre 3, rotation 9]; witness points in out6; -1 = overlap */
+double orc_debug_gjk(orc_env* e, const double* fa, const double* fb, double* out6) {
+    Real Ra[9], Rb[9];
+    Convex a, b;
+    a.e = b.e = e; a.link = b.link = -1; a.shrink = b.shrink = 0; a.box = b.box = 0;
+    for (int r = 0; r < 9; r++) { Ra[r] = (Real)fa[3 + r]; Rb[r] = (Real)fb[3 + r]; }
+    for (int r = 0; r < 3; r++) { a.c[r] = (Real)fa[r]; b.c[r] = (Real)fb[r]; }
+    a.R = Ra; b.R = Rb;
+    Real pa[3] = {0, 0, 0}, pb[3] = {0, 0, 0};
+    Real d = gjk_distance(a, b, pa, pb);
+    for (int r = 0; r < 3; r++) { out6[r] = pa[r]; out6[3 + r] = pb[r]; }
+    return (double)d;
+}
+/* contacts of the current pose with both participants: per contact [P(3), dist, link, linkB, n(3), PB(3)] */
+int32_t orc_contacts_full(orc_env* e, double* out, int32_t maxc) {
+    if (!e->fk_valid) fk(e);
+    find_contacts(e);
+    int nc = (int)e->contacts.size();
+    for (int i = 0; i < nc && i < maxc; i++) {
+        const Contact& c = e->contacts[i];
+        double* o = out + 12 * i;
+        for (int r = 0; r < 3; r++) { o[r] = c.P[r]; o[6 + r] = c.n[r]; o[9 + r] = c.PB[r]; }
+        o[3] = c.dist; o[4] = c.link; o[5] = c.linkB;
+    }
+    return nc;
+}
 int32_t orc_last_normal_impulses(const orc_env* e, double* out, int32_t maxc) {
     int nc = (int)e->last_normal_impulse.size();
     for (int i = 0; i < nc && i < maxc; i++) out[i] = e->last_normal_impulse[i];

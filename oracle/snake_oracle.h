@@ -156,6 +156,10 @@ void     orc_minv_mul(orc_env* e, const double* x, double* y);
 void     orc_momentum(orc_env* e, double* lin3, double* ang3, double* kinetic);
 /* contacts of the current pose: returns count; per contact [px,py,pz, dist, link] */
 int32_t  orc_contacts(orc_env* e, double* out, int32_t max_contacts);
+/* world frames of the collision cylinders in link order: [centre 3, rotation 9 row-major] each; returns the count */
+int32_t  orc_cylinder_frames(orc_env* e, double* out);
+/* contacts with both participants: per contact [P 3, dist, link, linkB (-1 ground / box), n 3, PB 3] */
+int32_t  orc_contacts_full(orc_env* e, double* out, int32_t max_contacts);
 /* impulses of the last substep: normal impulses per contact */
 int32_t  orc_last_normal_impulses(const orc_env* e, double* out, int32_t max_contacts);
 
