@@ -677,6 +677,82 @@ __device__ __forceinline__ void duo_step(float& RJ, const float RM, float& dv, f
     if (RES) asm volatile("v_max3_f32 %[lsq], %[lsq], |%[x]|, |%[c2]|" : [lsq] "+v"(lsq) : [x] "v"(x), [c2] "v"(c2));
 }
 
+// one DPP step of two interleaved half-reductions (each instruction is the other's wait state)
+#define SNK_RED2(MODE)                                        \
+    "v_add_f32_dpp %[t1], %[t1], %[t1] " MODE "\n\t"           \
+    "v_add_f32_dpp %[t2], %[t2], %[t2] " MODE "\n\t"
+// FOUR consecutive contact normals (two slots) in one step, 44 VALU like two duo steps, but with the two reductions
+// interleaved (no s_nop) and only the four scalar round trips in sequence.  Row order r1 (slot 1 lower), r2 (slot 1
+// upper), r3, r4 as in the sequential sweep; later rows see earlier ones through coupling scalars parked in RJ:
+//   RJ1 lane 62: c(r2,r1);   RJ2 lanes 29 / 61: c(r3,r1), c(r4,r1);   lanes 28 / 60: c(r3,r2), c(r4,r2);   lane 62: c(r4,r3)
+// each applied to lanes 31 / 63 of the partial sums by one v_fmac_f32_dpp (row_shr:1, 2, 3).
+template <bool RES>
+__device__ __forceinline__ void quad_step(float& RJ1, const float RM1, float& RJ2, const float RM2, float& dv, float E3163,
+                                          unsigned long long lowmask, float& lsq) {
+    float t1, t2, d1, d2, d3, d4;
+    float a1, a2, a3, a4, s1, s2, s3, s4;
+    asm volatile(
+        "v_mul_f32 %[t1], %[RJ1], %[dv]\n\t"
+        "v_mul_f32 %[t2], %[RJ2], %[dv]\n\t"
+        "v_readlane_b32 %[a1], %[RJ1], 31\n\t"
+        "v_readlane_b32 %[a2], %[RJ1], 63\n\t"
+        SNK_RED2("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1")
+        "v_readlane_b32 %[a3], %[RJ2], 31\n\t"
+        "v_readlane_b32 %[a4], %[RJ2], 63\n\t"
+        SNK_RED2("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1")
+        "s_nop 0\n\t"
+        SNK_RED2("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+        "s_nop 0\n\t"
+        SNK_RED2("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+        "s_nop 0\n\t"
+        SNK_RED2("row_bcast:15 row_mask:0xa bank_mask:0xf")
+        "v_readlane_b32 %[s1], %[t1], 31\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_e64 %[d1], -%[s1], 0\n\t"
+        "v_subrev_f32 %[d1], %[a1], %[d1]\n\t"
+        "s_nop 0\n\t"
+        "v_fmac_f32_dpp %[t1], %[RJ1], %[d1] row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_fmac_f32_dpp %[t2], %[RJ2], %[d1] row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_readlane_b32 %[s2], %[t1], 63\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_e64 %[d2], -%[s2], 0\n\t"
+        "v_subrev_f32 %[d2], %[a2], %[d2]\n\t"
+        "s_nop 0\n\t"
+        "v_fmac_f32_dpp %[t2], %[RJ2], %[d2] row_shr:3 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 0\n\t"
+        "v_readlane_b32 %[s3], %[t2], 31\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_e64 %[d3], -%[s3], 0\n\t"
+        "v_subrev_f32 %[d3], %[a3], %[d3]\n\t"
+        "s_nop 0\n\t"
+        "v_fmac_f32_dpp %[t2], %[RJ2], %[d3] row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 0\n\t"
+        "v_readlane_b32 %[s4], %[t2], 63\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_e64 %[d4], -%[s4], 0\n\t"
+        "v_subrev_f32 %[d4], %[a4], %[d4]\n\t"
+        // per-half impulses, the two slots' contributions
+        "v_cndmask_b32_e64 %[d1], %[d2], %[d1], %[lowmask]\n\t"
+        "v_cndmask_b32_e64 %[d3], %[d4], %[d3], %[lowmask]\n\t"
+        "v_mul_f32 %[t1], %[RM1], %[d1]\n\t"
+        "v_mul_f32 %[t2], %[RM2], %[d3]\n\t"
+        "v_fmac_f32 %[RJ1], %[E], %[d1]\n\t"
+        "v_fmac_f32 %[RJ2], %[E], %[d3]\n\t"
+        : [t1] "=&v"(t1), [t2] "=&v"(t2), [d1] "=&v"(d1), [d2] "=&v"(d2), [d3] "=&v"(d3), [d4] "=&v"(d4),
+          [a1] "=&s"(a1), [a2] "=&s"(a2), [a3] "=&s"(a3), [a4] "=&s"(a4), [s1] "=&s"(s1), [s2] "=&s"(s2), [s3] "=&s"(s3),
+          [s4] "=&s"(s4), [RJ1] "+v"(RJ1), [RJ2] "+v"(RJ2)
+        : [RM1] "v"(RM1), [RM2] "v"(RM2), [dv] "v"(dv), [E] "v"(E3163), [lowmask] "s"(lowmask));
+    if (RES) asm volatile("v_max3_f32 %[lsq], %[lsq], |%[p1]|, |%[p2]|" : [lsq] "+v"(lsq) : [p1] "v"(t1), [p2] "v"(t2));
+    asm volatile(
+        "v_add_f32 %[p1], %[p1], %[p2]\n\t"
+        "v_mov_b32 %[p2], %[p1]\n\t"
+        "s_nop 1\n\t"
+        "v_permlane32_swap_b32 %[p1], %[p2]\n\t"
+        "v_add_f32 %[dv], %[dv], %[p1]\n\t"
+        "v_add_f32 %[dv], %[dv], %[p2]\n\t"
+        : [p1] "+v"(t1), [p2] "+v"(t2), [dv] "+v"(dv));
+}
+
 // Bullet's cone-friction pair (hand-written, 27 VALU): direction A in the lower half and B in
 // the upper half of one register, so one reduction yields both sums; the pair of new
 // accumulated impulses is projected radially onto the disc of radius lambda_n (the friction
@@ -730,9 +806,6 @@ __device__ __forceinline__ void cone_step(float& RJ, const float RM, const float
 // (d = 30: coupling with A1, d = 29: with B1) so that two v_fmac_f32_dpp (row_shr:1 / row_shr:2) add them to lanes
 // 31 / 63 of the partial sums without any scalar traffic.  Same arithmetic per row as cone_step; what changes is
 // the dependency chain (one reduction + one scalar round trip per two pairs instead of two).
-#define SNK_RED2(MODE)                                        \
-    "v_add_f32_dpp %[t1], %[t1], %[t1] " MODE "\n\t"           \
-    "v_add_f32_dpp %[t2], %[t2], %[t2] " MODE "\n\t"
 template <bool RES>
 __device__ __forceinline__ void cone2_step(float& RJ1, const float RM1, float& RJ2, const float RM2, const float RJnorm,
                                            float& dv, float EPS, float E3163, unsigned long long lowmask, float& lsq) {
@@ -805,14 +878,16 @@ __device__ __forceinline__ void cone2_step(float& RJ1, const float RM1, float& R
 
 // The four coupling scalars of cone2_step for the friction slots (S, S+1) of two consecutive contacts, written into
 // lanes d = 30 (with A1) and d = 29 (with B1) of both halves of RJ[S+1].
+// SH: the coupling with the first slot's lower-half row goes to lane d = 31 - SH, with its upper-half row to d = 30 - SH
+template <int SH = 1>
 __device__ __forceinline__ void cone2_coupling(const float RM1, float& RJ2, int lane) {
     const swap2 sw = half_swap(RM1, RM1);                 // a = [RM_A1, RM_A1], b = [RM_B1, RM_B1]
     const float tA = half_reduce(RJ2 * sw.a);             // lane 31: c(A2,A1), lane 63: c(B2,A1)
     const float tB = half_reduce(RJ2 * sw.b);             // lane 31: c(A2,B1), lane 63: c(B2,B1)
-    const float mA = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(tA), 0x101, 0xf, 0xf, true));   // row_shl:1
-    const float mB = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(tB), 0x102, 0xf, 0xf, true));   // row_shl:2
+    const float mA = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(tA), 0x100 + SH, 0xf, 0xf, true));       // row_shl:SH
+    const float mB = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(tB), 0x100 + SH + 1, 0xf, 0xf, true));   // row_shl:SH+1
     const int d = lane & 31;
-    RJ2 = d == 30 ? mA : (d == 29 ? mB : RJ2);
+    RJ2 = d == 31 - SH ? mA : (d == 30 - SH ? mB : RJ2);
 }
 
 // A motor row has a unit Jacobian (J = e_{6+j}), so its dot is just delta-v of that joint, and
@@ -863,7 +938,7 @@ __device__ __forceinline__ float motor_step(const float RMj, float& dv, const fl
 template <bool RES, int BASE>
 __device__ __forceinline__ void duos4(float (&RJ)[kSlots], float (&RM)[kSlots], float& dv, float E3163, float& lsq) {
 #pragma unroll
-    for (int s = BASE; s < BASE + 4; s++) duo_step<RES, false>(RJ[s], RM[s], dv, 0.f, E3163, kLowMask, lsq);
+    for (int s = BASE; s < BASE + 4; s += 2) quad_step<RES>(RJ[s], RM[s], RJ[s + 1], RM[s + 1], dv, E3163, kLowMask, lsq);
 }
 
 // eight consecutive friction pairs (contacts 8G..8G+7), two contacts per step; the normal impulses of contacts
@@ -1061,6 +1136,17 @@ __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane, f
             swap2 sw = half_swap(RM[s], RM[s]);             // a = [RM_lower, RM_lower], b = [RM_upper, RM_upper]
             float t = half_reduce(RJ[s] * sw.a);
             RJ[s] = wrlane(RJ[s], rdlane(t, 63), 62);       // d = 30 of the upper half: duo_step's row_shr:1 source
+        }
+        // ... and the 2 x 2 block between the two slots of a quad_step (four normals per step): lanes d = 29, 28
+#pragma unroll
+        for (int g = 0; g < 8; g++) {
+            if (nc > 8 * g) {
+#pragma unroll
+                for (int i = 0; i < 2; i++) {
+                    const int s = kSlotNormal + 4 * g + 2 * i;
+                    cone2_coupling<2>(RM[s], RJ[s + 1], lane);
+                }
+            }
         }
         if (M.cone == 0) {
 #pragma unroll
