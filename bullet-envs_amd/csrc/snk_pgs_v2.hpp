@@ -710,21 +710,18 @@ __device__ __forceinline__ void quad_step(float& RJ1, const float RM1, float& RJ
         "s_nop 1\n\t"
         "v_max_f32_e64 %[d1], -%[s1], 0\n\t"
         "v_subrev_f32 %[d1], %[a1], %[d1]\n\t"
-        "s_nop 0\n\t"
         "v_fmac_f32_dpp %[t1], %[RJ1], %[d1] row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
         "v_fmac_f32_dpp %[t2], %[RJ2], %[d1] row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
         "v_readlane_b32 %[s2], %[t1], 63\n\t"
         "s_nop 1\n\t"
         "v_max_f32_e64 %[d2], -%[s2], 0\n\t"
         "v_subrev_f32 %[d2], %[a2], %[d2]\n\t"
-        "s_nop 0\n\t"
         "v_fmac_f32_dpp %[t2], %[RJ2], %[d2] row_shr:3 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
         "s_nop 0\n\t"
         "v_readlane_b32 %[s3], %[t2], 31\n\t"
         "s_nop 1\n\t"
         "v_max_f32_e64 %[d3], -%[s3], 0\n\t"
         "v_subrev_f32 %[d3], %[a3], %[d3]\n\t"
-        "s_nop 0\n\t"
         "v_fmac_f32_dpp %[t2], %[RJ2], %[d3] row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
         "s_nop 0\n\t"
         "v_readlane_b32 %[s4], %[t2], 63\n\t"
