@@ -183,3 +183,74 @@ def test_scheduler_ticket_wraparound(pkg, monkeypatch, n, B):
                 assert np.array_equal(x, y)
     with pytest.raises(RuntimeError):
         pkg.Stepper(1 << 24)
+
+
+@pytest.mark.parametrize("n", [16, 32])
+def test_env_step_parity_random_actions(pkg, oracle_mod, n):
+    """Beyond the gait: uniformly random actions in [-1.5, 1.5] (a third of the components get clipped in place), both
+    chain lengths, self-collision as the kernels evaluate it.  One env-step from a synchronised state, float32 GPU vs
+    float64 oracle, judged against the float32 oracle on the same step.  These are violent, contact-rich steps (a
+    third of the 32-link episodes end within three of them), where float32 and float64 themselves part by 1e-3 in
+    angle within one env-step: the worst case is held to 3x the float32 oracle's with floors 3e-3 / 0.2 / 5e-2, the
+    MEDIAN error -- the robust statement -- to 3x the float32 oracle's median with floors 2e-4 / 5e-3 / 5e-4."""
+    B, J = (16, 5) if n == 16 else (12, 4)
+    A = n // 2
+    rng = np.random.default_rng(77 + n)
+    st = pkg.Stepper(B, n_modules=n)
+    st.reset()
+    sc = 1 if n == 32 else 0
+    refs = [oracle_mod.OracleEnv(n_modules=n, self_collision=sc, max_self_contacts=32) for _ in range(B)]
+    refs32 = [oracle_mod.OracleEnv(n_modules=n, self_collision=sc, max_self_contacts=32, f32=True) for _ in range(B)]
+    w = dict(q=0.0, qd=0.0, r=0.0)
+    c = dict(q=0.0, qd=0.0, r=0.0)
+    wl = dict(q=[], qd=[], r=[])
+    cl = dict(q=[], qd=[], r=[])
+    mism = cal_mism = compared = 0
+    for j in range(J):
+        S, X = st.get_state()
+        a = rng.uniform(-1.5, 1.5, (B, A)).astype(np.float32)
+        a_in = a.copy()
+        obs, rew, done, sub = st.step(a_in, vec_mode=True)
+        assert np.array_equal(a_in, np.clip(a, -1, 1))                    # checkBound clipped the caller's array
+        for i in range(B):
+            out = []
+            for e in (refs[i], refs32[i]):
+                e.set_state(S[i].astype(np.float64))
+                e.set_aux(X[i, :n].astype(np.float64), float(X[i, n]), float(X[i, n + 1]))
+                out.append(e.env_step(a[i].astype(np.float64), vec_mode=True))
+            (o, r, d, k, _), (o32, r32, d32, k32, _) = out
+
+            def smooth(rr, oo):           # without the -10 step at |joint-0 force| > 10 (a boundary decision)
+                return rr + (10.0 if abs(oo[3 * n + 7]) > 10.0 else 0.0)
+
+            def errs(oo, rr):
+                q = max(np.abs(oo[:n] - o[:n]).max(), np.abs(oo[3 * n:3 * n + 7] - o[3 * n:3 * n + 7]).max())
+                qd = (np.abs(oo[n:2 * n] - o[n:2 * n]) / (1 + np.abs(o[n:2 * n]))).max()
+                return dict(q=q, qd=qd, r=abs(smooth(rr, oo) - smooth(r, o)))
+            if k32 == k and d32 == d:
+                if not d:                 # a done env returns the post-reset observation: nothing to compare but the reward
+                    for key, v in errs(o32, r32).items():
+                        c[key] = max(c[key], v)
+                        cl[key].append(v)
+            else:
+                cal_mism += 1
+            if k != sub[i] or d != bool(done[i]):
+                mism += 1
+                assert abs(k - sub[i]) <= 1, (i, j, k, sub[i])
+                continue
+            if d:
+                assert rew[i] < -4.0
+                continue
+            compared += 1
+            for key, v in errs(obs[i].astype(np.float64), float(rew[i])).items():
+                w[key] = max(w[key], v)
+                wl[key].append(v)
+    wm = {k: float(np.median(v)) for k, v in wl.items()}
+    cm = {k: float(np.median(v)) for k, v in cl.items()}
+    print("random-action parity n =", n, "medians GPU-f32", wm, "| oracle-f32", cm)
+    print("random-action parity n =", n, "GPU-f32", w, "| oracle-f32", c, "| boundary mismatches", mism, cal_mism, "| compared", compared)
+    assert compared >= B * J // 2
+    assert mism <= max(B * J // 10, 2 * cal_mism + 2)
+    assert w["q"] < max(3e-3, 3 * c["q"]) and w["qd"] < max(0.2, 3 * c["qd"]) and w["r"] < max(5e-2, 3 * c["r"])
+    assert wm["q"] < max(2e-4, 3 * cm["q"]) and wm["qd"] < max(5e-3, 3 * cm["qd"]) and wm["r"] < max(5e-4, 3 * cm["r"])
+    st.close()
