@@ -114,6 +114,10 @@ int resident_waves(size_t bytes, int device, int* out) {
     if (lds < 160 * 1024) lds = 160 * 1024;
     int per_cu = (int)(lds / (bytes ? bytes : 1));
     if (per_cu > 8) per_cu = 8;
+    if (const char* w = getenv("SNK_WAVES_PER_CU")) {       // occupancy experiments only (fewer resident waves than fit)
+        const int v = atoi(w);
+        if (v >= 1 && v < per_cu) per_cu = v;
+    }
     if (per_cu < 1) per_cu = 1;
     *out = per_cu * prop.multiProcessorCount;
     return 0;

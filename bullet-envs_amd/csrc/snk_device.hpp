@@ -20,6 +20,7 @@
 //   mean_height()        Snake.checkSnakeHeight (snake.py:237-245)
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 #include "snk_model.hpp"
 
@@ -96,6 +97,19 @@ __device__ __forceinline__ float wave_sum(float x) {
     }
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 31));
 }
+// Sum over the active lanes 0 .. LAST (32 <= LAST < 48) of a wave running with exactly those lanes enabled, returned
+// wave-uniform: the same DPP steps; lane LAST collects its own row's partial sum and the total of lanes 0 .. 31.
+template <int LAST>
+__device__ __forceinline__ float cols_sum(float x) {
+    static_assert(LAST >= 32 && LAST < 48, "lane LAST must sit in row 2");
+    x = dpp_add<0xB1, 0xf>(x);
+    x = dpp_add<0x4E, 0xf>(x);
+    x = dpp_add<0x114, 0xf>(x);
+    x = dpp_add<0x118, 0xf>(x);
+    x = dpp_add<0x142, 0xa>(x);
+    x = dpp_add<0x143, 0xc>(x);
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), LAST));
+}
 __device__ __forceinline__ float lane_bcast(float x, int src_lane_uniform) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), src_lane_uniform));
 }
@@ -124,7 +138,6 @@ struct LdsCommon {
     // non-contact rows kept in LDS: in v1 limits + motors, in v2 only the (rare) limit rows
     int nc_joint[2 * N];
     float nc_sign[2 * N], nc_rhs[2 * N], nc_dinv[2 * N], nc_den[2 * N], nc_lo[2 * N], nc_hi[2 * N], nc_app[2 * N];
-    float Mm[N][ND];             // M^-1 e_j for the motor / limit rows
 
     __device__ __forceinline__ float* base() { return rec; }
     __device__ __forceinline__ float* q() { return rec + 13; }
@@ -146,32 +159,43 @@ struct Lds<N, false> : LdsCommon<N> {
     int clist[NC];               // compact contact index -> slot
     int cidx[NC];                // slot -> compact contact index (-1: not in contact)
     // The contact rows themselves (J and M^-1 J^T, 2 x 384 x 38 floats = 117 KB) do not fit LDS next
-    // to anything else; they live in a per-environment block of global memory that the solve
-    // streams once per iteration (see pgs_v1): kRows rows of J, then kRows rows of M^-1 J^T.
+    // to anything else; they live in a per-resident-wave block of global memory that the solve
+    // streams once per iteration (see pgs_v1), one 320-byte record [J | M^-1 J^T] per row.
     static constexpr int kRing = 32;                       // contacts per loop trip of the solve
     // link-link (self-collision) contacts follow the ground contacts in the compact list: at most kMaxSelf of them,
     // geometry slots NC .. NC + kMaxSelf - 1; the per-contact scalars cN / cF already have kRing entries of padding
     static constexpr int kMaxSelf = kRing;
     static constexpr int NCT = NC + kMaxSelf;              // contact slots in all
-    static constexpr int kRows = 3 * NCT + 6 * kRing + 3;  // + inert padding, the refill's over-read, 3 rows always zero
+    // record order: the NCT normal rows, then the NCT friction pairs (A, B) -- each phase of the solve streams its own
+    // rows back to back, every fetched cache line used whole (interleaved by contact, a phase used 320 of every 960
+    // bytes and paid for the neighbours' half lines), then 3 rows that stay zero
+    static constexpr int kRows = 3 * NCT + 3;
+    static constexpr int kFric = NCT;                      // first friction record
     // a row of the block: [J (ND floats), pad, M^-1 J^T (ND floats), pad], 320 B = five aligned 64-B
     // sectors for 304 useful bytes (separate, unaligned 152-B rows fetched 1.4x their size)
     static constexpr int kRS = 80;                         // floats per row of the block
     static constexpr int kMO = 40;                         // float offset of the M^-1 J^T half
-    static_assert(ND <= kMO, "row layout");
+    // The two pad columns of each half carry the row's scalars, so that the solve needs nothing but the accumulated
+    // impulses in LDS (round 2: 7.7 KB of per-contact scalars {rhs, den, 1/den, a} shrank to 2.5 KB of a's):
+    //   J half:        columns < ND  J / den;   column kSpec  -rhs = -target / den;   column kSpec + 1  0
+    //   M^-1 J^T half: columns < ND  M^-1 J^T;  column kSpec  0;                      column kSpec + 1  den
+    // With delta-v's lane kSpec held at 1 the row's dot IS (J.dv)/den - rhs, and lane kSpec + 1 of the step's
+    // M^-1 J^T dI is dI * den, the row's residual (the same layout trick as the register-resident solve's d = 22 / 24).
+    static constexpr int kSpec = kMO - 2;
+    static_assert(ND <= kSpec, "row layout");
     // behind the rows: the contact geometry of the NCT slots, 20 floats each: P[3] (point on body kA), distance,
     // friction direction A[3], B[3], normal[3], PB[3] (point on body kB), kA, kB (-1: the ground), friction scale,
     // pad (written lane = slot by find_contacts_v1 / find_self_contacts_v1, read by the row builder and the
     // sensor pass)
     static constexpr int kGeo = 20;
     static constexpr size_t kGeoOff = (size_t)kRows * kRS;
-    static constexpr size_t kRowFloats = kGeoOff + (size_t)NCT * kGeo;
-    // per-contact scalars of the rows, grouped the way the solve reads them (one ds_read_b128 each):
-    //   cN[ci] = {rhs, den, accumulated impulse, 1/den} of the normal row 3ci
-    //   cF[ci] = {rhsA, rhsB, denA, denB | accA, accB, 1/denA, 1/denB} of the friction rows 3ci+1, 3ci+2
-    alignas(16) float cN[NC + kRing + 1][4];
-    alignas(16) float cF[NC + kRing + 1][8];
-    static_assert(NCT <= NC + kRing, "the scalars of the link-link contacts live in the ring's padding entries");
+    // behind the geometry: M^-1 e_j of the n motor / limit rows, kMO floats each (columns >= ND zero).  The solve keeps
+    // them in registers; they left LDS (4.9 KB for 32 links) so that eight waves fit a CU
+    static constexpr size_t kMmOff = kGeoOff + (size_t)NCT * kGeo;
+    static constexpr size_t kRowFloats = kMmOff + (size_t)N * kMO;
+    // accumulated impulses of contact ci: {normal, friction A, friction B, -}
+    alignas(16) float acc[NC + kRing + 1][4];
+    static_assert(NCT <= NC + kRing, "the impulses of the link-link contacts live in the ring's padding entries");
     int nplane;                  // ground contacts of this substep (the link-link contacts follow them)
 };
 
@@ -181,6 +205,7 @@ struct Lds<N, true> : LdsCommon<N> {
     static constexpr bool kV2 = true;
     static constexpr int NC = 4 * N, ND = N + 6;
     static_assert(N + 6 + 3 <= 32, "v2 packs two rows per 64-lane register");
+    float Mm[N][ND];             // M^-1 e_j for the motor / limit rows
     float ccP[NC][3], ccdist[NC], ccdir[NC][2][3];        // indexed by COMPACT contact index
     int ccbody[NC];
     float stM[64][25];           // staging of one 64-row batch: M^-1 J^T [22], rhs, den, 1/den
@@ -626,17 +651,21 @@ __device__ void build_rows_v1(LT& L, const DevModel& M, int lane, int nc, int& n
     constexpr int ND = N + 6;
     const int nrows = N + 3 * nc;
     const float* gb = L.base() + 7;   // omega_w, v_w (after the unconstrained update)
+    float mden = 0.f;                 // diagonal M^-1[6+j][6+j] of this lane's motor row (row j = lane < N: first trip)
     for (int rid = lane; rid < nrows; rid += 64) {
+        // every trip re-reads the chain from LDS: with no LDS store left in the loop the compiler would otherwise hoist
+        // the ~500 loop-invariant per-body values out of it and spill them (1.2 KB of scratch per lane)
+        asm volatile("" : : : "memory");
         const bool motor = rid < N;
         int k, slot = 0, kind = 0, kB = -1;
         f3 P = mk3(0, 0, 0), d = mk3(0, 0, 0), PB = mk3(0, 0, 0);
         float cdist_slot = 0.f, fscale = 1.0f;
-        float* Mrow;             // final row of M^-1 J^T: LDS for a motor, global memory for a contact row
+        float* Mrow;             // final row of M^-1 J^T (global memory: the motors' block or the contact row's record)
         float* Jrow = nullptr;   // final J row (contact rows only)
         float uu[N];             // joint-space residuals between the two sweeps, in registers (both sweeps are fully unrolled)
         if (motor) {
             k = rid + 1;
-            Mrow = L.Mm[rid];
+            Mrow = rows + LT::kMmOff + (size_t)rid * LT::kMO;
         } else {
             const int ci = (rid - N) / 3;
             kind = (rid - N) - 3 * ci;
@@ -650,7 +679,7 @@ __device__ void build_rows_v1(LT& L, const DevModel& M, int lane, int nc, int& n
             kB = (int)geo[17];                  // -1: the ground
             PB = ld3(geo + 13);
             if (kind != 0) fscale = geo[18];    // friction rows of a link-link contact: see find_self_contacts_v1
-            Jrow = rows + (size_t)(rid - N) * LT::kRS;
+            Jrow = rows + (size_t)(kind == 0 ? ci : LT::kFric + 2 * ci + kind - 1) * LT::kRS;
             Mrow = Jrow + LT::kMO;
         }
         // backward sweep of the delta problem (zero velocity, impulse only)
@@ -674,6 +703,9 @@ __device__ void build_rows_v1(LT& L, const DevModel& M, int lane, int nc, int& n
             pN = paN + cross(ld3(L.r[b]), paF);
             pF = paF;
         }
+        // (same reason, between the sweeps: the forward sweep re-reads each body from LDS instead of finding 13 values
+        //  per body kept -- spilled -- from the backward sweep)
+        asm volatile("" : : : "memory");
         f3 J0 = mk3(0, 0, 0), J1 = mk3(0, 0, 0);
         if (!motor) {
             J0 = cross(P - ld3(L.o[0]), d);
@@ -698,7 +730,6 @@ __device__ void build_rows_v1(LT& L, const DevModel& M, int lane, int nc, int& n
         f3 al = mk3(a0[0], a0[1], a0[2]), a = mk3(a0[3], a0[4], a0[5]);
         float den = dot(J0, al) + dot(J1, a);
         float rv = dot(J0, ld3(gb)) + dot(J1, ld3(gb + 3));
-        if (!motor) { st3(Jrow, J0); st3(Jrow + 3, J1); }
 #pragma unroll
         for (int b = 1; b <= N; b++) {
             a = a + cross(al, ld3(L.r[b]));
@@ -710,13 +741,14 @@ __device__ void build_rows_v1(LT& L, const DevModel& M, int lane, int nc, int& n
             if (!motor) {
                 float Jb = (b <= k) ? dot(ax, cross(P - ld3(L.o[b]), d)) : 0.f;
                 if (b <= kB) Jb -= dot(ax, cross(PB - ld3(L.o[b]), d));
-                Jrow[6 + b - 1] = Jb;
+                Jrow[6 + b - 1] = Jb;      // unscaled for now: the denominator comes out of this very loop
                 den += Jb * qdd;
                 rv += Jb * L.qd()[b - 1];
             } else if (b == k) {
                 den = qdd;
             }
         }
+        if (motor) mden = den;
         if (!motor) {
             const int row = rid - N;
             den *= fscale;
@@ -728,13 +760,20 @@ __device__ void build_rows_v1(LT& L, const DevModel& M, int lane, int nc, int& n
             } else {
                 target = -rv;
             }
-            const int cid = row / 3;
-            if (kind == 0) {
-                L.cN[cid][0] = target * dinv; L.cN[cid][1] = den; L.cN[cid][2] = 0.f; L.cN[cid][3] = dinv;
-            } else {
-                float* cf = L.cF[cid] + (kind - 1);
-                cf[0] = target * dinv; cf[2] = den; cf[4] = 0.f; cf[6] = dinv;
+            // the record: J / den, the scalars in the pad columns (Lds<N, false>::kSpec); a row without a usable
+            // denominator becomes all zero (dI = 0 for good, as Bullet's 1/den = 0 makes it)
+            // (the joint columns go through memory once more instead of waiting in 32 registers: with them the
+            //  unrolled sweeps spilled 1.4 KB per lane)
+            st3(Jrow, J0 * dinv); st3(Jrow + 3, J1 * dinv);
+            {
+                float* Jq = Jrow;
+                asm volatile("" : "+v"(Jq) : : "memory");       // no store-to-load forwarding of the 32 values
+#pragma unroll
+                for (int b = 0; b < N; b++) Jq[6 + b] *= dinv;
             }
+            Jrow[LT::kSpec] = -target * dinv; Jrow[LT::kSpec + 1] = 0.f;
+            Mrow[LT::kSpec] = 0.f; Mrow[LT::kSpec + 1] = den;
+            L.acc[row / 3][kind] = 0.f;
         }
     }
     lds_sync();
@@ -754,7 +793,7 @@ __device__ void build_rows_v1(LT& L, const DevModel& M, int lane, int nc, int& n
         nlim = __popcll(bal);
         if (viol) {
             int idx = __popcll(bal & ((1ull << lane) - 1ull));
-            float den = L.Mm[lane][6 + lane];
+            float den = mden;
             float dinv = den > 1.1920929e-7f ? 1.0f / den : 0.f;
             float rel = sgn * L.qd()[lane];
             L.nc_joint[idx] = lane; L.nc_sign[idx] = sgn;
@@ -764,7 +803,7 @@ __device__ void build_rows_v1(LT& L, const DevModel& M, int lane, int nc, int& n
         }
         if (lane < N) {
             int idx = nlim + lane;
-            float den = L.Mm[lane][6 + lane];
+            float den = mden;
             float dinv = den > 1.1920929e-7f ? 1.0f / den : 0.f;
             float cur = L.qd()[lane];
             float want = M.kp * (L.targets[lane] - L.q()[lane]) * M.inv_dt + cur + M.kd * (0.f - cur);
@@ -808,40 +847,42 @@ __device__ void build_rows_v1(LT& L, const DevModel& M, int lane, int nc, int& n
     "v_add_f32_dpp " B ", " B ", " B " " MODE "\n\t"      \
     "s_nop 0\n\t"
 
-// a contact-normal row: a' = max(a + rhs - (J.dv)/den, 0); dv += M^-1 J^T (a' - a).  Returns a'.
-__device__ __forceinline__ float row_step_normal(float jv, float mv, float rhs, float acc, float den, float dinv, float& dv,
-                                                 float& lsq) {
-    float t, x, dI, P, s;
+// Row steps of the streamed-row solve.  jv: the row's J half (J / den, -rhs in lane kSpec, where delta-v holds 1), mv: its
+// M^-1 J^T half (den in lane kSpec + 1), both one value per lane; the dot  s = (J.dv)/den - rhs  comes out of one
+// multiply and a 6-step DPP reduction, the clamp runs on wave-uniform values, and |M^-1 J^T dI| carries the row's
+// residual |dI den| in lane kSpec + 1 (collected per lane in lsq, read once per iteration).
+// a contact-normal row: a' = max(a - s, 0); dv += M^-1 J^T (a' - a).  Returns a'.  14 VALU.
+template <int SUM_LANE>
+__device__ __forceinline__ float row_step_normal(float jv, float mv, float acc, float& dv, float& lsq) {
+    float t, x, P, s;
     asm volatile(
         "v_mul_f32 %[t], %[jv], %[dv]\n\t"
-        "v_add_f32 %[x], %[acc], %[rhs]\n\t"
-        "s_nop 0\n\t"
+        "s_nop 1\n\t"
         SNK_RED64("%[t]")
         "s_nop 0\n\t"
-        "v_readlane_b32 %[s], %[t], 63\n\t"
+        "v_readlane_b32 %[s], %[t], %[SL]\n\t"
         "s_nop 1\n\t"
-        "v_fma_f32 %[x], -%[s], %[dinv], %[x]\n\t"
+        "v_subrev_f32 %[x], %[s], %[acc]\n\t"
         "v_max_f32 %[x], 0, %[x]\n\t"
-        "v_sub_f32 %[dI], %[x], %[acc]\n\t"
-        "v_mul_f32 %[P], %[dI], %[mv]\n\t"
-        "v_mul_f32 %[t], %[dI], %[den]\n\t"
+        "v_sub_f32 %[t], %[x], %[acc]\n\t"
+        "v_mul_f32 %[P], %[t], %[mv]\n\t"
         "v_add_f32 %[dv], %[dv], %[P]\n\t"
-        "v_max_f32 %[lsq], %[lsq], |%[t]|\n\t"
-        : [t] "=&v"(t), [x] "=&v"(x), [dI] "=&v"(dI), [P] "=&v"(P), [s] "=&s"(s), [dv] "+v"(dv), [lsq] "+v"(lsq)
-        : [jv] "v"(jv), [mv] "v"(mv), [rhs] "v"(rhs), [acc] "v"(acc), [den] "v"(den), [dinv] "v"(dinv));
+        "v_max_f32_e64 %[lsq], %[lsq], |%[P]|\n\t"
+        : [t] "=&v"(t), [x] "=&v"(x), [P] "=&v"(P), [s] "=&s"(s), [dv] "+v"(dv), [lsq] "+v"(lsq)
+        : [jv] "v"(jv), [mv] "v"(mv), [acc] "v"(acc), [SL] "n"(SUM_LANE));
     return x;
 }
 
-// Bullet's cone-friction pair of one contact: both dots from the same delta-v, the new pair
-// (a + rhs - dot) projected radially onto the disc of radius lim.
-__device__ __forceinline__ void row_step_cone(float jA, float mA, float jB, float mB, float rhsA, float rhsB, float& accA,
-                                              float& accB, float denA, float denB, float dinvA, float dinvB, float lim,
+// Bullet's cone-friction pair of one contact: both dots from the same delta-v, the new pair (a - s) projected
+// radially onto the disc of radius lim.  30 VALU.
+template <int SUM_LANE>
+__device__ __forceinline__ void row_step_cone(float jA, float mA, float jB, float mB, float& accA, float& accB, float lim,
                                               float EPS, float& dv, float& lsq) {
     float tA, tB, xA, xB, r2, P, sA, sB;
     asm volatile(
         "v_mul_f32 %[tA], %[jA], %[dv]\n\t"
         "v_mul_f32 %[tB], %[jB], %[dv]\n\t"
-        "v_add_f32 %[xA], %[accA], %[rhsA]\n\t"
+        "s_nop 0\n\t"
         SNK_RED64x2_STEP("%[tA]", "%[tB]", "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1")
         SNK_RED64x2_STEP("%[tA]", "%[tB]", "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1")
         SNK_RED64x2_STEP("%[tA]", "%[tB]", "row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1")
@@ -849,12 +890,12 @@ __device__ __forceinline__ void row_step_cone(float jA, float mA, float jB, floa
         SNK_RED64x2_STEP("%[tA]", "%[tB]", "row_bcast:15 row_mask:0xa bank_mask:0xf")
         "v_add_f32_dpp %[tA], %[tA], %[tA] row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
         "v_add_f32_dpp %[tB], %[tB], %[tB] row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-        "v_add_f32 %[xB], %[accB], %[rhsB]\n\t"
-        "v_readlane_b32 %[sA], %[tA], 63\n\t"
-        "v_readlane_b32 %[sB], %[tB], 63\n\t"
         "s_nop 0\n\t"
-        "v_fma_f32 %[xA], -%[sA], %[dinvA], %[xA]\n\t"
-        "v_fma_f32 %[xB], -%[sB], %[dinvB], %[xB]\n\t"
+        "v_readlane_b32 %[sA], %[tA], %[SL]\n\t"
+        "v_readlane_b32 %[sB], %[tB], %[SL]\n\t"
+        "s_nop 0\n\t"
+        "v_subrev_f32 %[xA], %[sA], %[accA]\n\t"
+        "v_subrev_f32 %[xB], %[sB], %[accB]\n\t"
         "v_fma_f32 %[r2], %[xA], %[xA], %[EPS]\n\t"
         "v_fma_f32 %[r2], %[xB], %[xB], %[r2]\n\t"
         "v_rsq_f32 %[r2], %[r2]\n\t"
@@ -865,16 +906,13 @@ __device__ __forceinline__ void row_step_cone(float jA, float mA, float jB, floa
         "v_sub_f32 %[tA], %[xA], %[accA]\n\t"
         "v_sub_f32 %[tB], %[xB], %[accB]\n\t"
         "v_mul_f32 %[P], %[tA], %[mA]\n\t"
-        "v_mul_f32 %[r2], %[tA], %[denA]\n\t"
         "v_fmac_f32 %[P], %[tB], %[mB]\n\t"
-        "v_mul_f32 %[tB], %[tB], %[denB]\n\t"
         "v_add_f32 %[dv], %[dv], %[P]\n\t"
-        "v_max3_f32 %[lsq], %[lsq], |%[r2]|, |%[tB]|\n\t"
+        "v_max_f32_e64 %[lsq], %[lsq], |%[P]|\n\t"
         : [tA] "=&v"(tA), [tB] "=&v"(tB), [xA] "=&v"(xA), [xB] "=&v"(xB), [r2] "=&v"(r2), [P] "=&v"(P), [sA] "=&s"(sA),
           [sB] "=&s"(sB), [dv] "+v"(dv), [lsq] "+v"(lsq)
-        : [jA] "v"(jA), [mA] "v"(mA), [jB] "v"(jB), [mB] "v"(mB), [rhsA] "v"(rhsA), [rhsB] "v"(rhsB), [accA] "v"(accA),
-          [accB] "v"(accB), [denA] "v"(denA), [denB] "v"(denB), [dinvA] "v"(dinvA), [dinvB] "v"(dinvB), [lim] "v"(lim),
-          [EPS] "v"(EPS));
+        : [jA] "v"(jA), [mA] "v"(mA), [jB] "v"(jB), [mB] "v"(mB), [accA] "v"(accA), [accB] "v"(accB), [lim] "v"(lim),
+          [EPS] "v"(EPS), [SL] "n"(SUM_LANE));
     accA = xA;
     accB = xB;
 }
@@ -885,7 +923,7 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
     constexpr int N = LT::kN;
     constexpr int ND = N + 6;
     static_assert(ND <= 64, "this solve is laid out for one row per 64-lane register");
-    constexpr int NR = LT::NR;
+    constexpr int kSpec = LT::kSpec;
     const bool act = lane < ND;
     const int nlim = nn - N;                       // violated joint limits come first in the non-contact list
     // model fields used inside the loops, read once (the model lives in global memory)
@@ -904,35 +942,52 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
     const float EPS = 1e-30f;
     // Row operands come from global memory, kRing contacts per loop trip, each contact's two (or
     // four) row vectors requested kRing contacts before they are used (the next trip's loads are
-    // issued one by one as this trip's slots are consumed).  Lane d < ND reads column d of a row
-    // (152 contiguous bytes per row: coalesced); lanes >= ND stay on the last three rows of the
-    // block, which are never written (zero).  The rows and scalars of the contacts between nc and
-    // the end of the last trip are zeroed: resolving them changes nothing (dI = 0 exactly).
+    // issued one by one as this trip's slots are consumed).  Lane d < ND reads column d of a row, lanes kSpec and
+    // kSpec + 1 the row's scalars (160 contiguous bytes per half row: coalesced); the other lanes sit the solve out.
+    // The rows and impulses of the contacts between nc and the end of the last group are zeroed: resolving them
+    // changes nothing (dI = 0 exactly).
     constexpr int kRing = LT::kRing;
-    constexpr int kRows = LT::kRows;
     // contacts are resolved in groups of 8 behind one scalar branch: the rows between nc and the next multiple of 8
     // are zeroed (inert), a ring trip ends at that multiple instead of running its full kRing steps (round 1 padded
     // to a whole trip: 144 contacts -- 128 on the ground + 16 link-link -- cost 160)
-    const int nc_pad = (nc + 7) / 8 * 8;
+    const int nc_pad = __builtin_amdgcn_readfirstlane((nc + 7) / 8 * 8);
     {
-        float* z = rows + (size_t)3 * nc * LT::kRS;
-        const int nz = 3 * (nc_pad - nc) * LT::kRS;
+        float* z = rows + (size_t)nc * LT::kRS;
+        float* zf = rows + (size_t)(LT::kFric + 2 * nc) * LT::kRS;
+        const int nz = (nc_pad - nc) * LT::kRS;
         for (int i = lane; i < nz; i += 64) z[i] = 0.f;
-        for (int i = lane; i < 4 * (nc_pad - nc); i += 64) L.cN[nc][i] = 0.f;
-        for (int i = lane; i < 8 * (nc_pad - nc); i += 64) L.cF[nc][i] = 0.f;
+        for (int i = lane; i < 2 * nz; i += 64) zf[i] = 0.f;
+        for (int i = lane; i < 4 * (nc_pad - nc); i += 64) L.acc[nc][i] = 0.f;
     }
     __threadfence();          // the rows were written lane = row, they are read lane = column
     lds_sync();
-    const float* const Jg = rows;
     constexpr int kRS = LT::kRS;
-    const float* const Mg = rows + LT::kMO;
-    const int off0 = act ? lane : (kRows - 3) * kRS;         // float offset of this lane's column in row 0
-    const int ostep = act ? 3 * kRS : 0;                       // ... its advance per contact
-    float dv = 0.f;
+    // Addressing: a record's address is a wave-uniform base (scalar arithmetic) plus the lane's column, 4 * lane bytes,
+    // so a load is  global_load_dword v, v_column, s[base:base+1] offset:imm  with no vector arithmetic at all
+    // (round-2 measurement: per-lane 64-bit pointers cost 4 VALU per friction step, a tenth of its issue slots).
+    // For that every lane that takes part must stride alike, so the solve runs with lanes 0 .. kMO - 1 only (the
+    // 38 velocity components and the two scalar columns); the sum of a row's products lands in lane kMO - 1.
+    constexpr unsigned kRecB = kRS * 4, kHalfB = LT::kMO * 4;        // bytes per record, offset of its M^-1 J^T half
+    constexpr unsigned kFricB = (unsigned)LT::kFric * kRecB;          // the first friction pair
+    // (buffer loads: resource descriptor and record offset in SGPRs, the column in a VGPR, the half in the immediate)
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(rows, 0, (int)(LT::kRowFloats * sizeof(float)), 0x00020000);
+    const int vcol = 4 * lane;
+    auto ldJ = [&](unsigned rec_bytes) {
+        return __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, vcol, (int)rec_bytes, 0));
+    };
+    auto ldM = [&](unsigned rec_bytes) {
+        return __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, vcol + (int)kHalfB, (int)rec_bytes, 0));
+    };
+    float dv = lane == kSpec ? 1.0f : 0.f;        // lane kSpec: the constant that multiplies the rows' -rhs column
     int it = 0;
+    if (lane < LT::kMO) {
+    // the motors' M^-1 columns stay in registers for the whole solve (they are read 50 x n times)
+    float RMm[N];
+#pragma unroll
+    for (int j = 0; j < N; j++) RMm[j] = ldJ((unsigned)(LT::kMmOff * 4) + (unsigned)j * kHalfB);   // columns >= ND: zero
     for (; it < n_iter; it++) {
-        float lsq = 0.f;       // max |dI * den| of the contact rows
-        float lsq_nc = 0.f;    // ... of the limit and motor rows
+        float lsq = 0.f;       // per lane max |M^-1 J^T dI| of the contact rows: lane kSpec + 1 holds max |dI * den|
+        float lsq_nc = 0.f;    // max |dI * den| of the limit and motor rows
         auto limit_rows = [&](bool fwd) {
             for (int jj = 0; jj < nlim; jj++) {
                 const int idx = fwd ? jj : nlim - 1 - jj;
@@ -944,58 +999,53 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
                 float sum = fminf(fmaxf(a0 + dI, L.nc_lo[idx]), L.nc_hi[idx]);
                 dI = sum - a0;
                 L.nc_app[idx] = sum;   // uniform value, every lane stores it: no barrier needed
-                float mv = act ? L.Mm[j][lane] : 0.f;
+                const float mv = ldJ((unsigned)(LT::kMmOff * 4) + (unsigned)j * kHalfB);      // a violated limit is rare
                 dv += sg * mv * dI;
                 lsq_nc = fmaxf(lsq_nc, fabsf(dI * L.nc_den[idx]));
             }
         };
-        auto motor_rows = [&](bool fwd) {
-            const float* mrow = &L.Mm[fwd ? 0 : N - 1][act ? lane : 0];
-            const int mstep = fwd ? ND : -ND;
-            float mvn = mrow[0];
-            float denn = L.nc_den[nlim + (fwd ? 0 : N - 1)];
+        auto motor_rows = [&](auto fwd_c) {
+            constexpr bool fwd = decltype(fwd_c)::value;
+#pragma unroll
             for (int jj = 0; jj < N; jj++) {
                 const int j = fwd ? jj : N - 1 - jj;
-                const float mv = mvn, den = denn;
-                if (jj + 1 < N) {
-                    mrow += mstep;
-                    mvn = mrow[0];
-                    denn = L.nc_den[nlim + (fwd ? j + 1 : j - 1)];
-                }
                 float u = (TARGV - dv) * DINVV;                          // every motor's candidate dI, lane-local (DINVV = 0 beyond the joints)
                 if (mi < 1e30f) u = fminf(fmaxf(ACCV + u, -mi), mi) - ACCV;
                 const float sdI = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(u), 6 + j));
                 ACCV = (lane == 6 + j) ? ACCV + u : ACCV;
-                dv += act ? sdI * mv : 0.f;
-                lsq_nc = fmaxf(lsq_nc, fabsf(sdI * den));
+                dv += sdI * RMm[j];                                      // zero beyond the velocity components
+                lsq_nc = fmaxf(lsq_nc, fabsf(sdI * L.nc_den[nlim + j]));
             }
         };
-        if (it & 1) { limit_rows(true); motor_rows(true); }
-        else { motor_rows(false); limit_rows(false); }
+        if (it & 1) { limit_rows(true); motor_rows(std::true_type{}); }
+        else { motor_rows(std::false_type{}); limit_rows(false); }
         if (nc > 0) {
             // normals: slot k of the ring holds contact (trip base + k).  A slot is refilled with
-            // the contact kRing further on as soon as it has been consumed (unconditionally: behind
-            // the last trip this reads padding rows that nobody uses); the contact's scalars
-            // {rhs, den, a, 1/den} come from LDS one step ahead.
+            // the contact kRing further on as soon as it has been consumed -- if there is one: round 1 refilled
+            // unconditionally, and with the usual 128 contacts the last trip of each phase fetched 32 (16) contacts'
+            // worth of rows nobody used, 14 % of the stream this kernel is bound by; the contact's
+            // accumulated impulse comes from LDS one step ahead.
             float jr[kRing], mr[kRing];
 #pragma unroll
             for (int k = 0; k < kRing; k++) {
-                jr[k] = Jg[off0 + k * ostep];
-                mr[k] = Mg[off0 + k * ostep];
+                jr[k] = ldJ((unsigned)k * kRecB);
+                mr[k] = ldM((unsigned)k * kRecB);
             }
-            int off = off0;
-            float4 sn = *reinterpret_cast<const float4*>(L.cN[0]);
+            float an = L.acc[0][0];
+            unsigned rb = 0;           // record the current group of eight refills counts from (wave-uniform)
             for (int base = 0; base < nc_pad; base += kRing) {
-                off += kRing * ostep;
 #pragma unroll
                 for (int k = 0; k < kRing; k++) {
                     if ((k & 7) == 0 && k > 0 && base + k >= nc_pad) break;      // wave-uniform
-                    const float4 sc = sn;
-                    sn = *reinterpret_cast<const float4*>(L.cN[base + k + 1]);
+                    const float a = an;
+                    an = L.acc[base + k + 1][0];
                     const float jv = jr[k], mv = mr[k];
-                    jr[k] = Jg[off + k * ostep];
-                    mr[k] = Mg[off + k * ostep];
-                    L.cN[base + k][2] = row_step_normal(jv, mv, sc.x, sc.z, sc.y, sc.w, dv, lsq);
+                    // the refill: the contact kRing further on if there is one, else this trip's contact once more
+                    // (a cache hit instead of a fetch of rows nobody uses; no branch, the load is issued either way)
+                    if ((k & 7) == 0) rb = (unsigned)((base + kRing + k < nc_pad) ? base + kRing : base) * kRecB;
+                    jr[k] = ldJ(rb + (unsigned)k * kRecB);
+                    mr[k] = ldM(rb + (unsigned)k * kRecB);
+                    L.acc[base + k][0] = row_step_normal<LT::kMO - 1>(jv, mv, a, dv, lsq);
                 }
             }
             if (cone) {
@@ -1004,60 +1054,55 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
                 float jA[kC], jB[kC], mA[kC], mB[kC];
 #pragma unroll
                 for (int k = 0; k < kC; k++) {
-                    const int o = off0 + k * ostep;
-                    jA[k] = Jg[o + kRS]; jB[k] = Jg[o + 2 * kRS];
-                    mA[k] = Mg[o + kRS]; mB[k] = Mg[o + 2 * kRS];
+                    const unsigned o = kFricB + (unsigned)k * 2u * kRecB;
+                    jA[k] = ldJ(o); jB[k] = ldJ(o + kRecB);
+                    mA[k] = ldM(o); mB[k] = ldM(o + kRecB);
                 }
-                off = off0;
-                float4 f0 = *reinterpret_cast<const float4*>(L.cF[0]), f1 = *reinterpret_cast<const float4*>(L.cF[0] + 4);
-                float ln = mu * L.cN[0][2];
+                float4 fn = *reinterpret_cast<const float4*>(L.acc[0]);
                 for (int base = 0; base < nc_pad; base += kC) {
-                    off += kC * ostep;
 #pragma unroll
                     for (int k = 0; k < kC; k++) {
                         if ((k & 7) == 0 && k > 0 && base + k >= nc_pad) break;  // wave-uniform
-                        const float4 c0 = f0, c1 = f1;
-                        const float lim = ln;
-                        f0 = *reinterpret_cast<const float4*>(L.cF[base + k + 1]);
-                        f1 = *reinterpret_cast<const float4*>(L.cF[base + k + 1] + 4);
-                        ln = mu * L.cN[base + k + 1][2];
+                        const float4 c = fn;
+                        fn = *reinterpret_cast<const float4*>(L.acc[base + k + 1]);
                         const float cjA = jA[k], cjB = jB[k], cmA = mA[k], cmB = mB[k];
-                        const int o = off + k * ostep;
-                        jA[k] = Jg[o + kRS]; jB[k] = Jg[o + 2 * kRS];
-                        mA[k] = Mg[o + kRS]; mB[k] = Mg[o + 2 * kRS];
-                        float aA = c1.x, aB = c1.y;
-                        row_step_cone(cjA, cmA, cjB, cmB, c0.x, c0.y, aA, aB, c0.z, c0.w, c1.z, c1.w, lim, EPS, dv, lsq);
-                        L.cF[base + k][4] = aA; L.cF[base + k][5] = aB;
+                        if ((k & 7) == 0) rb = kFricB + (unsigned)((base + kC + k < nc_pad) ? base + kC : base) * 2u * kRecB;   // as above
+                        const unsigned o = rb + (unsigned)k * 2u * kRecB;
+                        jA[k] = ldJ(o); jB[k] = ldJ(o + kRecB);
+                        mA[k] = ldM(o); mB[k] = ldM(o + kRecB);
+                        float aA = c.y, aB = c.z;
+                        row_step_cone<LT::kMO - 1>(cjA, cmA, cjB, cmB, aA, aB, mu * c.x, EPS, dv, lsq);
+                        *reinterpret_cast<float2*>(&L.acc[base + k][1]) = make_float2(aA, aB);
                     }
                 }
             } else {
                 // pyramid friction (not Bullet's default here): box-clamped rows, one after the other
-                int o = off0;
-                for (int ci = 0; ci < nc; ci++, o += ostep) {
-                    float* cf = L.cF[ci];
-                    const float lim = mu * L.cN[ci][2];
+                for (int ci = 0; ci < nc; ci++) {
+                    const unsigned o = kFricB + (unsigned)ci * 2u * kRecB;
+                    float* ac = L.acc[ci];
+                    const float lim = mu * ac[0];
                     if (!(lim > 0.f)) continue;
-                    const float accA = cf[4], accB = cf[5];
-                    float uA = wave_sum<64>(Jg[o + kRS] * dv) * cf[6];
-                    float sA = fminf(fmaxf(accA + (cf[0] - uA), -lim), lim);
-                    float eA = sA - accA;
-                    dv += Mg[o + kRS] * eA;
-                    float uB = wave_sum<64>(Jg[o + 2 * kRS] * dv) * cf[7];
-                    float sB = fminf(fmaxf(accB + (cf[1] - uB), -lim), lim);
-                    float eB = sB - accB;
-                    dv += Mg[o + 2 * kRS] * eB;
-                    cf[4] = sA; cf[5] = sB;
-                    lsq = fmaxf(lsq, fmaxf(fabsf(eA * cf[2]), fabsf(eB * cf[3])));
+                    const float accA = ac[1], accB = ac[2];
+                    const float sA = fminf(fmaxf(accA - cols_sum<LT::kMO - 1>(ldJ(o) * dv), -lim), lim);
+                    const float PA = ldM(o) * (sA - accA);
+                    dv += PA;
+                    const float sB = fminf(fmaxf(accB - cols_sum<LT::kMO - 1>(ldJ(o + kRecB) * dv), -lim), lim);
+                    const float PB = ldM(o + kRecB) * (sB - accB);
+                    dv += PB;
+                    ac[1] = sA; ac[2] = sB;
+                    lsq = fmaxf(lsq, fmaxf(fabsf(PA), fabsf(PB)));
                 }
             }
         }
-        const float res = fmaxf(lsq, lsq_nc);
+        const float res = fmaxf(lane_bcast(lsq, kSpec + 1), lsq_nc);
         if (res * res <= thr2 || it >= n_iter - 1) { it++; break; }
     }
+    }
+    it = __builtin_amdgcn_readfirstlane(it);
     if (lane >= 6 && lane < 6 + N) L.nc_app[nlim + lane - 6] = ACCV;
     lds_sync();
     iters = it;
-    return dv;
+    return act ? dv : 0.f;
 }
 
 // ----------------------------------------------------------------------------------
@@ -1128,8 +1173,8 @@ __device__ void substep_v1(LT& L, const DevModel& M, int lane, float mu, int& it
                 const int ci = (slot >= 0 && slot < 4 * N) ? L.cidx[slot] : -1;
                 if (ci >= 0) {
                     const float* geo = rows + LT::kGeoOff + (size_t)slot * LT::kGeo;
-                    f3 F = (mk3(0.f, 0.f, 1.f) * L.cN[ci][2] + ld3(geo + 4) * L.cF[ci][4] +
-                            ld3(geo + 7) * L.cF[ci][5]) * M.inv_dt;
+                    f3 F = (mk3(0.f, 0.f, 1.f) * L.acc[ci][0] + ld3(geo + 4) * L.acc[ci][1] +
+                            ld3(geo + 7) * L.acc[ci][2]) * M.inv_dt;
                     eF = eF + F;
                     eN = eN + cross(ld3(geo) - ld3(L.o[b]), F);
                 }
@@ -1140,8 +1185,8 @@ __device__ void substep_v1(LT& L, const DevModel& M, int lane, float mu, int& it
                 const int kA = (int)geo[16], kB2 = (int)geo[17];
                 if (kA != b && kB2 != b) continue;
                 const float fs = geo[18];
-                const f3 F = (ld3(geo + 10) * L.cN[ci][2] + ld3(geo + 4) * (L.cF[ci][4] * fs) +
-                              ld3(geo + 7) * (L.cF[ci][5] * fs)) * M.inv_dt;
+                const f3 F = (ld3(geo + 10) * L.acc[ci][0] + ld3(geo + 4) * (L.acc[ci][1] * fs) +
+                              ld3(geo + 7) * (L.acc[ci][2] * fs)) * M.inv_dt;
                 if (kA == b) { eF = eF + F; eN = eN + cross(ld3(geo) - ld3(L.o[b]), F); }
                 if (kB2 == b) { eF = eF - F; eN = eN - cross(ld3(geo + 13) - ld3(L.o[b]), F); }
             }
