@@ -110,6 +110,21 @@ __device__ __forceinline__ float cols_sum(float x) {
     x = dpp_add<0x143, 0xc>(x);
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), LAST));
 }
+// ... and the maximum of non-negative values, same lanes
+template <int LAST>
+__device__ __forceinline__ float cols_max(float x) {
+    static_assert(LAST >= 32 && LAST < 48, "lane LAST must sit in row 2");
+    auto step = [](float v, auto ctrl, auto rows) {
+        return fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), decltype(ctrl)::value, decltype(rows)::value, 0xf, true)));
+    };
+    x = step(x, std::integral_constant<int, 0xB1>{}, std::integral_constant<int, 0xf>{});
+    x = step(x, std::integral_constant<int, 0x4E>{}, std::integral_constant<int, 0xf>{});
+    x = step(x, std::integral_constant<int, 0x114>{}, std::integral_constant<int, 0xf>{});
+    x = step(x, std::integral_constant<int, 0x118>{}, std::integral_constant<int, 0xf>{});
+    x = step(x, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{});
+    x = step(x, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{});
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), LAST));
+}
 __device__ __forceinline__ float lane_bcast(float x, int src_lane_uniform) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), src_lane_uniform));
 }
@@ -162,6 +177,7 @@ struct Lds<N, false> : LdsCommon<N> {
     // to anything else; they live in a per-resident-wave block of global memory that the solve
     // streams once per iteration (see pgs_v1), one 320-byte record [J | M^-1 J^T] per row.
     static constexpr int kRing = 32;                       // contacts per loop trip of the solve
+    static constexpr int kResN = 32;                       // contacts whose normal rows stay in registers over the solve
     // link-link (self-collision) contacts follow the ground contacts in the compact list: at most kMaxSelf of them,
     // geometry slots NC .. NC + kMaxSelf - 1; the per-contact scalars cN / cF already have kRing entries of padding
     static constexpr int kMaxSelf = kRing;
@@ -937,7 +953,8 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
     const bool mot = lane >= 6 && act;
     const int jm = mot ? lane - 6 : 0;
     const float DINVV = mot ? L.nc_dinv[nlim + jm] : 0.f;
-    const float TARGV = (mot && DINVV > 0.f) ? L.nc_rhs[nlim + jm] * L.nc_den[nlim + jm] : 0.f;
+    const float DENV = mot ? L.nc_den[nlim + jm] : 0.f;
+    const float TARGV = (mot && DINVV > 0.f) ? L.nc_rhs[nlim + jm] * DENV : 0.f;
     float ACCV = 0.f;                               // accumulated motor impulses, motor j in lane 6+j
     const float EPS = 1e-30f;
     // Row operands come from global memory, kRing contacts per loop trip, each contact's two (or
@@ -985,6 +1002,15 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
     float RMm[N];
 #pragma unroll
     for (int j = 0; j < N; j++) RMm[j] = ldJ((unsigned)(LT::kMmOff * 4) + (unsigned)j * kHalfB);   // columns >= ND: zero
+    // ... and so do the normal rows of the first kResN contacts: the registers the rings leave free hold an eighth of
+    // the stream (the kernel is bound by that stream)
+    constexpr int kResN = LT::kResN;
+    float RNJ[kResN], RNM[kResN];
+#pragma unroll
+    for (int k = 0; k < kResN; k++) {
+        RNJ[k] = ldJ((unsigned)k * kRecB);
+        RNM[k] = ldM((unsigned)k * kRecB);
+    }
     for (; it < n_iter; it++) {
         float lsq = 0.f;       // per lane max |M^-1 J^T dI| of the contact rows: lane kSpec + 1 holds max |dI * den|
         float lsq_nc = 0.f;    // max |dI * den| of the limit and motor rows
@@ -1006,16 +1032,18 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
         };
         auto motor_rows = [&](auto fwd_c) {
             constexpr bool fwd = decltype(fwd_c)::value;
+            float Uv = 0.f;                                              // lane 6+j: the dI motor j got in this sweep
 #pragma unroll
             for (int jj = 0; jj < N; jj++) {
                 const int j = fwd ? jj : N - 1 - jj;
                 float u = (TARGV - dv) * DINVV;                          // every motor's candidate dI, lane-local (DINVV = 0 beyond the joints)
-                if (mi < 1e30f) u = fminf(fmaxf(ACCV + u, -mi), mi) - ACCV;
+                if (mi < 1e30f) u = fminf(fmaxf(ACCV + u, -mi), mi) - ACCV;   // (a lane's ACCV only matters at its own step)
                 const float sdI = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(u), 6 + j));
-                ACCV = (lane == 6 + j) ? ACCV + u : ACCV;
+                Uv = (lane == 6 + j) ? u : Uv;
                 dv += sdI * RMm[j];                                      // zero beyond the velocity components
-                lsq_nc = fmaxf(lsq_nc, fabsf(sdI * L.nc_den[nlim + j]));
             }
+            ACCV += Uv;
+            lsq_nc = fmaxf(lsq_nc, cols_max<LT::kMO - 1>(fabsf(Uv * DENV)));
         };
         if (it & 1) { limit_rows(true); motor_rows(std::true_type{}); }
         else { motor_rows(std::false_type{}); limit_rows(false); }
@@ -1028,12 +1056,19 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
             float jr[kRing], mr[kRing];
 #pragma unroll
             for (int k = 0; k < kRing; k++) {
-                jr[k] = ldJ((unsigned)k * kRecB);
-                mr[k] = ldM((unsigned)k * kRecB);
+                jr[k] = ldJ((unsigned)(kResN + k) * kRecB);
+                mr[k] = ldM((unsigned)(kResN + k) * kRecB);
             }
             float an = L.acc[0][0];
+#pragma unroll
+            for (int k = 0; k < kResN; k++) {                                   // the resident rows
+                if ((k & 7) == 0 && k > 0 && k >= nc_pad) break;                // wave-uniform
+                const float a = an;
+                an = L.acc[k + 1][0];
+                L.acc[k][0] = row_step_normal<LT::kMO - 1>(RNJ[k], RNM[k], a, dv, lsq);
+            }
             unsigned rb = 0;           // record the current group of eight refills counts from (wave-uniform)
-            for (int base = 0; base < nc_pad; base += kRing) {
+            for (int base = kResN; base < nc_pad; base += kRing) {
 #pragma unroll
                 for (int k = 0; k < kRing; k++) {
                     if ((k & 7) == 0 && k > 0 && base + k >= nc_pad) break;      // wave-uniform
