@@ -184,7 +184,10 @@ struct Lds<N, false> : LdsCommon<N> {
     static constexpr int NCT = NC + kMaxSelf;              // contact slots in all
     // record order: the NCT normal rows, then the NCT friction pairs (A, B) -- each phase of the solve streams its own
     // rows back to back, every fetched cache line used whole (interleaved by contact, a phase used 320 of every 960
-    // bytes and paid for the neighbours' half lines), then 3 rows that stay zero
+    // bytes and paid for the neighbours' half lines), then 3 rows that stay zero.  Inside a record the vectors are
+    // interleaved by column -- a normal's 320 bytes are [J0 M0 J1 M1 ...], a friction pair's 640 bytes
+    // [JA0 JB0 MA0 MB0 JA1 ...] -- so that lane d fetches everything it needs of a contact with ONE 8- or 16-byte
+    // load (one 320- / 640-byte request per contact instead of two / four of 160 bytes)
     static constexpr int kRows = 3 * NCT + 3;
     static constexpr int kFric = NCT;                      // first friction record
     // a row of the block: [J (ND floats), pad, M^-1 J^T (ND floats), pad], 320 B = five aligned 64-B
@@ -678,6 +681,7 @@ __device__ void build_rows_v1(LT& L, const DevModel& M, int lane, int nc, int& n
         float cdist_slot = 0.f, fscale = 1.0f;
         float* Mrow;             // final row of M^-1 J^T (global memory: the motors' block or the contact row's record)
         float* Jrow = nullptr;   // final J row (contact rows only)
+        int S = 1;               // floats between a row's consecutive columns (the records interleave their vectors)
         float uu[N];             // joint-space residuals between the two sweeps, in registers (both sweeps are fully unrolled)
         if (motor) {
             k = rid + 1;
@@ -695,8 +699,16 @@ __device__ void build_rows_v1(LT& L, const DevModel& M, int lane, int nc, int& n
             kB = (int)geo[17];                  // -1: the ground
             PB = ld3(geo + 13);
             if (kind != 0) fscale = geo[18];    // friction rows of a link-link contact: see find_self_contacts_v1
-            Jrow = rows + (size_t)(kind == 0 ? ci : LT::kFric + 2 * ci + kind - 1) * LT::kRS;
-            Mrow = Jrow + LT::kMO;
+            // a normal's record: [J0 M0 J1 M1 ...]; a friction pair's: [JA0 JB0 MA0 MB0 JA1 ...] (Lds<N, false>)
+            if (kind == 0) {
+                S = 2;
+                Jrow = rows + (size_t)ci * LT::kRS;
+                Mrow = Jrow + 1;
+            } else {
+                S = 4;
+                Jrow = rows + (size_t)(LT::kFric + 2 * ci) * LT::kRS + (kind - 1);
+                Mrow = Jrow + 2;
+            }
         }
         // backward sweep of the delta problem (zero velocity, impulse only)
         f3 pN = mk3(0, 0, 0), pF = mk3(0, 0, 0);
@@ -741,7 +753,7 @@ __device__ void build_rows_v1(LT& L, const DevModel& M, int lane, int nc, int& n
 #pragma unroll
             for (int j = 0; j < 6; j++) s -= L.Inv0[6 * i + j] * p0[j];
             a0[i] = s;
-            Mrow[i] = s * fscale;
+            Mrow[i * S] = s * fscale;
         }
         f3 al = mk3(a0[0], a0[1], a0[2]), a = mk3(a0[3], a0[4], a0[5]);
         float den = dot(J0, al) + dot(J1, a);
@@ -753,11 +765,11 @@ __device__ void build_rows_v1(LT& L, const DevModel& M, int lane, int nc, int& n
             float qdd = (u - (dot(ld3(L.Ua[b]), al) + dot(ld3(L.Ub[b]), a))) * L.Dinv[b];
             f3 ax = ld3(L.ax[b]);
             al = al + ax * qdd;
-            Mrow[6 + b - 1] = qdd * fscale;
+            Mrow[(6 + b - 1) * S] = qdd * fscale;
             if (!motor) {
                 float Jb = (b <= k) ? dot(ax, cross(P - ld3(L.o[b]), d)) : 0.f;
                 if (b <= kB) Jb -= dot(ax, cross(PB - ld3(L.o[b]), d));
-                Jrow[6 + b - 1] = Jb;      // unscaled for now: the denominator comes out of this very loop
+                Jrow[(6 + b - 1) * S] = Jb;      // unscaled for now: the denominator comes out of this very loop
                 den += Jb * qdd;
                 rv += Jb * L.qd()[b - 1];
             } else if (b == k) {
@@ -780,15 +792,16 @@ __device__ void build_rows_v1(LT& L, const DevModel& M, int lane, int nc, int& n
             // denominator becomes all zero (dI = 0 for good, as Bullet's 1/den = 0 makes it)
             // (the joint columns go through memory once more instead of waiting in 32 registers: with them the
             //  unrolled sweeps spilled 1.4 KB per lane)
-            st3(Jrow, J0 * dinv); st3(Jrow + 3, J1 * dinv);
+            Jrow[0] = J0.x * dinv; Jrow[S] = J0.y * dinv; Jrow[2 * S] = J0.z * dinv;
+            Jrow[3 * S] = J1.x * dinv; Jrow[4 * S] = J1.y * dinv; Jrow[5 * S] = J1.z * dinv;
             {
                 float* Jq = Jrow;
                 asm volatile("" : "+v"(Jq) : : "memory");       // no store-to-load forwarding of the 32 values
 #pragma unroll
-                for (int b = 0; b < N; b++) Jq[6 + b] *= dinv;
+                for (int b = 0; b < N; b++) Jq[(6 + b) * S] *= dinv;
             }
-            Jrow[LT::kSpec] = -target * dinv; Jrow[LT::kSpec + 1] = 0.f;
-            Mrow[LT::kSpec] = 0.f; Mrow[LT::kSpec + 1] = den;
+            Jrow[LT::kSpec * S] = -target * dinv; Jrow[(LT::kSpec + 1) * S] = 0.f;
+            Mrow[LT::kSpec * S] = 0.f; Mrow[(LT::kSpec + 1) * S] = den;
             L.acc[row / 3][kind] = 0.f;
         }
     }
@@ -989,11 +1002,18 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
     // (buffer loads: resource descriptor and record offset in SGPRs, the column in a VGPR, the half in the immediate)
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(rows, 0, (int)(LT::kRowFloats * sizeof(float)), 0x00020000);
     const int vcol = 4 * lane;
-    auto ldJ = [&](unsigned rec_bytes) {
+    auto ldJ = [&](unsigned rec_bytes) {             // a column of a plain (motor) row
         return __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, vcol, (int)rec_bytes, 0));
     };
-    auto ldM = [&](unsigned rec_bytes) {
-        return __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, vcol + (int)kHalfB, (int)rec_bytes, 0));
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    auto ldN = [&](unsigned rec_bytes, float& j, float& m) {       // {J, M^-1 J^T} of a normal's record
+        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, 2 * vcol, (int)rec_bytes, 0);
+        j = __uint_as_float(v.x); m = __uint_as_float(v.y);
+    };
+    auto ldF = [&](unsigned rec_bytes, float& ja, float& jb, float& ma, float& mb) {    // a friction pair's record
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, 4 * vcol, (int)rec_bytes, 0);
+        ja = __uint_as_float(v.x); jb = __uint_as_float(v.y); ma = __uint_as_float(v.z); mb = __uint_as_float(v.w);
     };
     float dv = lane == kSpec ? 1.0f : 0.f;        // lane kSpec: the constant that multiplies the rows' -rhs column
     int it = 0;
@@ -1007,10 +1027,7 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
     constexpr int kResN = LT::kResN;
     float RNJ[kResN], RNM[kResN];
 #pragma unroll
-    for (int k = 0; k < kResN; k++) {
-        RNJ[k] = ldJ((unsigned)k * kRecB);
-        RNM[k] = ldM((unsigned)k * kRecB);
-    }
+    for (int k = 0; k < kResN; k++) ldN((unsigned)k * kRecB, RNJ[k], RNM[k]);
     for (; it < n_iter; it++) {
         float lsq = 0.f;       // per lane max |M^-1 J^T dI| of the contact rows: lane kSpec + 1 holds max |dI * den|
         float lsq_nc = 0.f;    // max |dI * den| of the limit and motor rows
@@ -1055,10 +1072,7 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
             // accumulated impulse comes from LDS one step ahead.
             float jr[kRing], mr[kRing];
 #pragma unroll
-            for (int k = 0; k < kRing; k++) {
-                jr[k] = ldJ((unsigned)(kResN + k) * kRecB);
-                mr[k] = ldM((unsigned)(kResN + k) * kRecB);
-            }
+            for (int k = 0; k < kRing; k++) ldN((unsigned)(kResN + k) * kRecB, jr[k], mr[k]);
             float an = L.acc[0][0];
 #pragma unroll
             for (int k = 0; k < kResN; k++) {                                   // the resident rows
@@ -1074,13 +1088,12 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
                     if ((k & 7) == 0 && k > 0 && base + k >= nc_pad) break;      // wave-uniform
                     const float a = an;
                     an = L.acc[base + k + 1][0];
-                    const float jv = jr[k], mv = mr[k];
+                    L.acc[base + k][0] = row_step_normal<LT::kMO - 1>(jr[k], mr[k], a, dv, lsq);
                     // the refill: the contact kRing further on if there is one, else this trip's contact once more
-                    // (a cache hit instead of a fetch of rows nobody uses; no branch, the load is issued either way)
+                    // (a cache hit instead of a fetch of rows nobody uses; no branch, the load is issued either way).
+                    // Issued after the step: the register pair is free then and takes the new record as it is
                     if ((k & 7) == 0) rb = (unsigned)((base + kRing + k < nc_pad) ? base + kRing : base) * kRecB;
-                    jr[k] = ldJ(rb + (unsigned)k * kRecB);
-                    mr[k] = ldM(rb + (unsigned)k * kRecB);
-                    L.acc[base + k][0] = row_step_normal<LT::kMO - 1>(jv, mv, a, dv, lsq);
+                    ldN(rb + (unsigned)k * kRecB, jr[k], mr[k]);
                 }
             }
             if (cone) {
@@ -1089,9 +1102,7 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
                 float jA[kC], jB[kC], mA[kC], mB[kC];
 #pragma unroll
                 for (int k = 0; k < kC; k++) {
-                    const unsigned o = kFricB + (unsigned)k * 2u * kRecB;
-                    jA[k] = ldJ(o); jB[k] = ldJ(o + kRecB);
-                    mA[k] = ldM(o); mB[k] = ldM(o + kRecB);
+                    ldF(kFricB + (unsigned)k * 2u * kRecB, jA[k], jB[k], mA[k], mB[k]);
                 }
                 float4 fn = *reinterpret_cast<const float4*>(L.acc[0]);
                 for (int base = 0; base < nc_pad; base += kC) {
@@ -1100,14 +1111,11 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
                         if ((k & 7) == 0 && k > 0 && base + k >= nc_pad) break;  // wave-uniform
                         const float4 c = fn;
                         fn = *reinterpret_cast<const float4*>(L.acc[base + k + 1]);
-                        const float cjA = jA[k], cjB = jB[k], cmA = mA[k], cmB = mB[k];
-                        if ((k & 7) == 0) rb = kFricB + (unsigned)((base + kC + k < nc_pad) ? base + kC : base) * 2u * kRecB;   // as above
-                        const unsigned o = rb + (unsigned)k * 2u * kRecB;
-                        jA[k] = ldJ(o); jB[k] = ldJ(o + kRecB);
-                        mA[k] = ldM(o); mB[k] = ldM(o + kRecB);
                         float aA = c.y, aB = c.z;
-                        row_step_cone<LT::kMO - 1>(cjA, cmA, cjB, cmB, aA, aB, mu * c.x, EPS, dv, lsq);
+                        row_step_cone<LT::kMO - 1>(jA[k], mA[k], jB[k], mB[k], aA, aB, mu * c.x, EPS, dv, lsq);
                         *reinterpret_cast<float2*>(&L.acc[base + k][1]) = make_float2(aA, aB);
+                        if ((k & 7) == 0) rb = kFricB + (unsigned)((base + kC + k < nc_pad) ? base + kC : base) * 2u * kRecB;   // as above
+                        ldF(rb + (unsigned)k * 2u * kRecB, jA[k], jB[k], mA[k], mB[k]);
                     }
                 }
             } else {
@@ -1118,11 +1126,13 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
                     const float lim = mu * ac[0];
                     if (!(lim > 0.f)) continue;
                     const float accA = ac[1], accB = ac[2];
-                    const float sA = fminf(fmaxf(accA - cols_sum<LT::kMO - 1>(ldJ(o) * dv), -lim), lim);
-                    const float PA = ldM(o) * (sA - accA);
+                    float fjA, fjB, fmA, fmB;
+                    ldF(o, fjA, fjB, fmA, fmB);
+                    const float sA = fminf(fmaxf(accA - cols_sum<LT::kMO - 1>(fjA * dv), -lim), lim);
+                    const float PA = fmA * (sA - accA);
                     dv += PA;
-                    const float sB = fminf(fmaxf(accB - cols_sum<LT::kMO - 1>(ldJ(o + kRecB) * dv), -lim), lim);
-                    const float PB = ldM(o + kRecB) * (sB - accB);
+                    const float sB = fminf(fmaxf(accB - cols_sum<LT::kMO - 1>(fjB * dv), -lim), lim);
+                    const float PB = fmB * (sB - accB);
                     dv += PB;
                     ac[1] = sA; ac[2] = sB;
                     lsq = fmaxf(lsq, fmaxf(fabsf(PA), fabsf(PB)));
