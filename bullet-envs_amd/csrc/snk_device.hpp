@@ -1097,25 +1097,59 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
                 }
             }
             if (cone) {
-                // friction pairs: half a ring of contacts in flight (four vectors per contact)
+                // friction pairs: half a ring of contacts in flight (four vectors per contact).
+                // A pair whose contact carries no normal impulse and no friction impulse yet resolves to exactly
+                // nothing (the disc it is projected onto has radius 0: a' = a = 0, dI = 0) -- typically one contact in
+                // six.  Its step is skipped and its record is not fetched: `live`, one bit per contact, is fixed for the
+                // whole phase (the normal impulses are this iteration's final ones, a pair's own impulses only change
+                // at its own step), built with four ballots and kept in SGPRs, so a step's test is scalar.
                 constexpr int kC = kRing / 2;
-                float jA[kC], jB[kC], mA[kC], mB[kC];
+                unsigned long long m0, m1, m2;
+                {
+                    unsigned long long b[4];
 #pragma unroll
-                for (int k = 0; k < kC; k++) {
-                    ldF(kFricB + (unsigned)k * 2u * kRecB, jA[k], jB[k], mA[k], mB[k]);
+                    for (int p = 0; p < 4; p++) {
+                        const int c = LT::kMO * p + lane;
+                        bool lv = false;
+                        if (c < nc_pad) {
+                            const float4 a = *reinterpret_cast<const float4*>(L.acc[c]);
+                            lv = (mu * a.x > 0.f) || (a.y != 0.f) || (a.z != 0.f);     // (-0 counts as zero: a pair projected onto radius 0)
+                        }
+                        b[p] = __ballot(lv);
+                    }
+                    static_assert(LT::kMO == 40 && LT::NCT <= 160, "the bit arithmetic below");
+                    m0 = b[0] | (b[1] << 40);                           // contacts 0 .. 63
+                    m1 = (b[1] >> 24) | (b[2] << 16) | (b[3] << 56);    // 64 .. 127
+                    m2 = b[3] >> 8;                                      // 128 .. 159
+                }
+                // (m2:m1:m0 is shifted down by sixteen contacts per trip: bits 0 .. 15 are this trip's, 16 .. 31 the next one's)
+                constexpr unsigned kZeroB = (unsigned)(LT::kRows - 3) * kRecB;   // 960 bytes of zeros: the refill of a skipped pair
+                float jA[kC], jB[kC], mA[kC], mB[kC];
+                {
+                    const unsigned l0 = (unsigned)m0;
+#pragma unroll
+                    for (int k = 0; k < kC; k++)
+                        ldF((l0 >> k) & 1u ? kFricB + (unsigned)k * 2u * kRecB : kZeroB, jA[k], jB[k], mA[k], mB[k]);
                 }
                 float4 fn = *reinterpret_cast<const float4*>(L.acc[0]);
                 for (int base = 0; base < nc_pad; base += kC) {
+                    unsigned lv = (unsigned)m0;                     // bits 0 .. 15: this trip, 16 .. 31: the next
+                    m0 = (m0 >> 16) | (m1 << 48);
+                    m1 = (m1 >> 16) | (m2 << 48);
+                    m2 >>= 16;
 #pragma unroll
                     for (int k = 0; k < kC; k++) {
                         if ((k & 7) == 0 && k > 0 && base + k >= nc_pad) break;  // wave-uniform
                         const float4 c = fn;
                         fn = *reinterpret_cast<const float4*>(L.acc[base + k + 1]);
-                        float aA = c.y, aB = c.z;
-                        row_step_cone<LT::kMO - 1>(jA[k], mA[k], jB[k], mB[k], aA, aB, mu * c.x, EPS, dv, lsq);
-                        *reinterpret_cast<float2*>(&L.acc[base + k][1]) = make_float2(aA, aB);
-                        if ((k & 7) == 0) rb = kFricB + (unsigned)((base + kC + k < nc_pad) ? base + kC : base) * 2u * kRecB;   // as above
-                        ldF(rb + (unsigned)k * 2u * kRecB, jA[k], jB[k], mA[k], mB[k]);
+                        asm volatile("" : "+s"(lv));         // the test stays a scalar bit test here (hoisted, sixteen lane masks spill SGPRs)
+                        if ((lv >> k) & 1u) {
+                            float aA = c.y, aB = c.z;
+                            row_step_cone<LT::kMO - 1>(jA[k], mA[k], jB[k], mB[k], aA, aB, mu * c.x, EPS, dv, lsq);
+                            *reinterpret_cast<float2*>(&L.acc[base + k][1]) = make_float2(aA, aB);
+                        }
+                        // the refill, issued after the step (the four registers are free then): the pair kC further on
+                        ldF((lv >> (kC + k)) & 1u ? kFricB + (unsigned)(base + kC + k) * 2u * kRecB : kZeroB, jA[k], jB[k], mA[k], mB[k]);
                     }
                 }
             } else {
