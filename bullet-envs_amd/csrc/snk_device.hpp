@@ -178,6 +178,8 @@ struct Lds<N, false> : LdsCommon<N> {
     // streams once per iteration (see pgs_v1), one 320-byte record [J | M^-1 J^T] per row.
     static constexpr int kRing = 32;                       // contacts per loop trip of the solve
     static constexpr int kResN = 32;                       // contacts whose normal rows stay in registers over the solve
+    static constexpr int kRingN = 32;                      // normal rows in flight behind them
+    static constexpr int kRingF = 16;                      // friction pairs in flight
     // link-link (self-collision) contacts follow the ground contacts in the compact list: at most kMaxSelf of them,
     // geometry slots NC .. NC + kMaxSelf - 1; the per-contact scalars cN / cF already have kRing entries of padding
     static constexpr int kMaxSelf = kRing;
@@ -976,7 +978,7 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
     // kSpec + 1 the row's scalars (160 contiguous bytes per half row: coalesced); the other lanes sit the solve out.
     // The rows and impulses of the contacts between nc and the end of the last group are zeroed: resolving them
     // changes nothing (dI = 0 exactly).
-    constexpr int kRing = LT::kRing;
+    constexpr int kRN = LT::kRingN;      // normals in flight
     // contacts are resolved in groups of 8 behind one scalar branch: the rows between nc and the next multiple of 8
     // are zeroed (inert), a ring trip ends at that multiple instead of running its full kRing steps (round 1 padded
     // to a whole trip: 144 contacts -- 128 on the ground + 16 link-link -- cost 160)
@@ -1070,9 +1072,9 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
             // unconditionally, and with the usual 128 contacts the last trip of each phase fetched 32 (16) contacts'
             // worth of rows nobody used, 14 % of the stream this kernel is bound by; the contact's
             // accumulated impulse comes from LDS one step ahead.
-            float jr[kRing], mr[kRing];
+            float jr[kRN], mr[kRN];
 #pragma unroll
-            for (int k = 0; k < kRing; k++) ldN((unsigned)(kResN + k) * kRecB, jr[k], mr[k]);
+            for (int k = 0; k < kRN; k++) ldN((unsigned)(kResN + k) * kRecB, jr[k], mr[k]);
             float an = L.acc[0][0];
 #pragma unroll
             for (int k = 0; k < kResN; k++) {                                   // the resident rows
@@ -1082,17 +1084,17 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
                 L.acc[k][0] = row_step_normal<LT::kMO - 1>(RNJ[k], RNM[k], a, dv, lsq);
             }
             unsigned rb = 0;           // record the current group of eight refills counts from (wave-uniform)
-            for (int base = kResN; base < nc_pad; base += kRing) {
+            for (int base = kResN; base < nc_pad; base += kRN) {
 #pragma unroll
-                for (int k = 0; k < kRing; k++) {
+                for (int k = 0; k < kRN; k++) {
                     if ((k & 7) == 0 && k > 0 && base + k >= nc_pad) break;      // wave-uniform
                     const float a = an;
                     an = L.acc[base + k + 1][0];
                     L.acc[base + k][0] = row_step_normal<LT::kMO - 1>(jr[k], mr[k], a, dv, lsq);
-                    // the refill: the contact kRing further on if there is one, else this trip's contact once more
+                    // the refill: the contact kRN further on if there is one, else this trip's contact once more
                     // (a cache hit instead of a fetch of rows nobody uses; no branch, the load is issued either way).
                     // Issued after the step: the register pair is free then and takes the new record as it is
-                    if ((k & 7) == 0) rb = (unsigned)((base + kRing + k < nc_pad) ? base + kRing : base) * kRecB;
+                    if ((k & 7) == 0) rb = (unsigned)((base + kRN + k < nc_pad) ? base + kRN : base) * kRecB;
                     ldN(rb + (unsigned)k * kRecB, jr[k], mr[k]);
                 }
             }
@@ -1103,7 +1105,7 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
                 // six.  Its step is skipped and its record is not fetched: `live`, one bit per contact, is fixed for the
                 // whole phase (the normal impulses are this iteration's final ones, a pair's own impulses only change
                 // at its own step), built with four ballots and kept in SGPRs, so a step's test is scalar.
-                constexpr int kC = kRing / 2;
+                constexpr int kC = LT::kRingF;
                 unsigned long long m0, m1, m2;
                 {
                     unsigned long long b[4];
@@ -1122,7 +1124,7 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
                     m1 = (b[1] >> 24) | (b[2] << 16) | (b[3] << 56);    // 64 .. 127
                     m2 = b[3] >> 8;                                      // 128 .. 159
                 }
-                // (m2:m1:m0 is shifted down by sixteen contacts per trip: bits 0 .. 15 are this trip's, 16 .. 31 the next one's)
+                // (m2:m1:m0 is shifted down by kC contacts per trip)
                 constexpr unsigned kZeroB = (unsigned)(LT::kRows - 3) * kRecB;   // 960 bytes of zeros: the refill of a skipped pair
                 float jA[kC], jB[kC], mA[kC], mB[kC];
                 {
@@ -1133,10 +1135,10 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
                 }
                 float4 fn = *reinterpret_cast<const float4*>(L.acc[0]);
                 for (int base = 0; base < nc_pad; base += kC) {
-                    unsigned lv = (unsigned)m0;                     // bits 0 .. 15: this trip, 16 .. 31: the next
-                    m0 = (m0 >> 16) | (m1 << 48);
-                    m1 = (m1 >> 16) | (m2 << 48);
-                    m2 >>= 16;
+                    unsigned lv = (unsigned)m0;                     // bits 0 .. kC - 1: this trip, kC .. 2 kC - 1: the next
+                    m0 = (m0 >> kC) | (m1 << (64 - kC));
+                    m1 = (m1 >> kC) | (m2 << (64 - kC));
+                    m2 >>= kC;
 #pragma unroll
                     for (int k = 0; k < kC; k++) {
                         if ((k & 7) == 0 && k > 0 && base + k >= nc_pad) break;  // wave-uniform
