@@ -24,6 +24,14 @@
 
 #include "snk_model.hpp"
 
+// -DSNK_PROFILE (bullet-envs_amd/build.py --profile): s_memtime stamps between the phases of a substep; the phase
+// durations (ticks) replace the motor torques of the record (tools/profile_phases.py)
+#ifdef SNK_PROFILE
+#define SNK_STAMP(i) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); prof_t[i] = t_; }
+#else
+#define SNK_STAMP(i)
+#endif
+
 namespace snk {
 
 // ----------------------------------------------------------------------------------
@@ -212,8 +220,9 @@ struct Lds<N, false> : LdsCommon<N> {
     static constexpr size_t kGeoOff = (size_t)kRows * kRS;
     // behind the geometry: M^-1 e_j of the n motor / limit rows, kMO floats each (columns >= ND zero).  The solve keeps
     // them in registers; they left LDS (4.9 KB for 32 links) so that eight waves fit a CU
-    static constexpr size_t kMmOff = kGeoOff + (size_t)NCT * kGeo;
-    static constexpr size_t kRowFloats = kMmOff + (size_t)N * kMO;
+    static constexpr size_t kMmOff = kGeoOff + (size_t)NCT * kGeo;     // M^-1: ND rows (6 base, then the joints) of kMO floats
+    static constexpr size_t kYOff = kMmOff + (size_t)(N + 6) * kMO;     // Y_k of every body (build_rows_v1), 6 x kMO floats each
+    static constexpr size_t kRowFloats = kYOff + (size_t)(N + 1) * 6 * kMO;
     // accumulated impulses of contact ci: {normal, friction A, friction B, -}
     alignas(16) float acc[NC + kRing + 1][4];
     static_assert(NCT <= NC + kRing, "the impulses of the link-link contacts live in the ring's padding entries");
@@ -667,7 +676,7 @@ __device__ void aba_main(LT& L, const DevModel& M, int lane) {
 // (btMultiBodyConstraintSolver::setupMultiBodyContactConstraint / btMultiBodyJointMotor [U]).
 // ----------------------------------------------------------------------------------
 template <class LT>
-__device__ void build_rows_v1(LT& L, const DevModel& M, int lane, int nc, int& n_noncontact, float* __restrict__ rows) {
+__device__ void build_rows_v1_lane_is_row(LT& L, const DevModel& M, int lane, int nc, int& n_noncontact, float* __restrict__ rows) {
     constexpr int N = LT::kN;
     constexpr int ND = N + 6;
     const int nrows = N + 3 * nc;
@@ -835,6 +844,230 @@ __device__ void build_rows_v1(LT& L, const DevModel& M, int lane, int nc, int& n
         if (lane < N) {
             int idx = nlim + lane;
             float den = mden;
+            float dinv = den > 1.1920929e-7f ? 1.0f / den : 0.f;
+            float cur = L.qd()[lane];
+            float want = M.kp * (L.targets[lane] - L.q()[lane]) * M.inv_dt + cur + M.kd * (0.f - cur);
+            L.nc_joint[idx] = lane; L.nc_sign[idx] = 1.f;
+            L.nc_rhs[idx] = (want - cur) * dinv;
+            L.nc_dinv[idx] = dinv; L.nc_den[idx] = den;
+            L.nc_lo[idx] = -M.max_motor_imp; L.nc_hi[idx] = M.max_motor_imp; L.nc_app[idx] = 0.f;
+        }
+    }
+    n_noncontact = nlim + N;
+    lds_sync();
+}
+
+// ----------------------------------------------------------------------------------
+// S5 (round 2): the same rows, built lane = velocity component.
+// A contact row's M^-1 J^T is linear in the 6-dimensional wrench its unit impulse puts on its body:
+//     M^-1 J^T = Y_k (tau, f),   tau = (P - o_k) x dir,  f = dir,   Y_k = M^-1 Jbody_k^T   (38 x 6),
+// and the Y_k follow from the columns of M^-1 by a recursion down the chain (a wrench on body k about o_k is the
+// wrench (tau + r_k x f, f) on body k-1 about o_{k-1} plus the torque ax_k . tau on joint k):
+//     Y_0 = M^-1[:, 0..5],   Y_k(tau, f) = Y_{k-1}(tau + r_k x f, f) + M^-1[:, 6+k-1] (ax_k . tau).
+// So instead of one pair of ABA delta sweeps PER ROW (416 rows = 7 trips of 64 lanes through two serial 32-body
+// recurrences, 19 % of a substep) there is ONE trip of 38 sweeps -- the columns of M^-1, which the motor rows need
+// anyway -- nine FMAs per lane and body for the recursion, and per row: six FMAs for M^-1 J^T, J from the lane's own
+// joint axis, two wave reductions (denominator, relative velocity), and ONE coalesced store of the finished record.
+// (btMultiBodyConstraintSolver::setupMultiBodyContactConstraint / btMultiBody::calcAccelerationDeltasMultiDof [U]: the
+//  rows are the same linear map of the same unit impulses; only the order of the floating-point sums differs.)
+// ----------------------------------------------------------------------------------
+template <class LT>
+__device__ void build_rows_v1(LT& L, const DevModel& M, int lane, int nc, int& n_noncontact, float* __restrict__ rows) {
+    constexpr int N = LT::kN;
+    constexpr int ND = N + 6;
+    constexpr int kMO = LT::kMO;
+    float* const Mmx = rows + LT::kMmOff;           // M^-1, ND rows of kMO floats (columns >= ND stay zero)
+    float mden = 0.f;                               // lane 6+j: M^-1[6+j][6+j], motor j's denominator
+    // ---- (a) the columns of M^-1: lane = velocity component, unit generalized force on it
+    if (lane < ND) {
+        const bool isbase = lane < 6;
+        const int k = lane - 5;                     // the joint's body (lanes >= 6)
+        float* Mrow = Mmx + (size_t)lane * kMO;
+        float uu[N];
+        f3 pN = mk3(0, 0, 0), pF = mk3(0, 0, 0);
+#pragma unroll
+        for (int b = N; b >= 1; b--) {
+            f3 ax = ld3(L.ax[b]);
+            float u = -dot(ax, pN);
+            if (!isbase && b == k) u += 1.0f;
+            uu[b - 1] = u;
+            float t = u * L.Dinv[b];
+            f3 paN = pN + ld3(L.Ua[b]) * t, paF = pF + ld3(L.Ub[b]) * t;
+            pN = paN + cross(ld3(L.r[b]), paF);
+            pF = paF;
+        }
+        asm volatile("" : : : "memory");            // the forward sweep re-reads the bodies (build_rows_v1_lane_is_row)
+        float p0[6] = {pN.x, pN.y, pN.z, pF.x, pF.y, pF.z}, a0[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) if (lane == i) p0[i] = -1.0f;      // unit force on the base: bias -e_i
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int j = 0; j < 6; j++) sacc -= L.Inv0[6 * i + j] * p0[j];
+            a0[i] = sacc;
+            Mrow[i] = sacc;
+        }
+        f3 al = mk3(a0[0], a0[1], a0[2]), a = mk3(a0[3], a0[4], a0[5]);
+#pragma unroll
+        for (int b = 1; b <= N; b++) {
+            a = a + cross(al, ld3(L.r[b]));
+            float qdd = (uu[b - 1] - (dot(ld3(L.Ua[b]), al) + dot(ld3(L.Ub[b]), a))) * L.Dinv[b];
+            al = al + ld3(L.ax[b]) * qdd;
+            Mrow[6 + b - 1] = qdd;
+            if (b == k) mden = qdd;
+        }
+    }
+    __threadfence();          // M^-1 was written lane = row, it is read lane = column
+    lds_sync();
+    // ---- (b) lane = velocity component d: what J[d] is made of, and the current velocity
+    const int d = lane;
+    const int jb = d >= 6 ? d - 5 : 0;              // the body this component's joint belongs to (0: the base)
+    f3 Aj = mk3(0, 0, 0), Oj = mk3(0, 0, 0), Bj = mk3(0, 0, 0);
+    float vd = 0.f;
+    if (d < 3) { Aj = mk3(d == 0 ? 1.f : 0.f, d == 1 ? 1.f : 0.f, d == 2 ? 1.f : 0.f); Oj = ld3(L.o[0]); vd = L.base()[7 + d]; }
+    else if (d < 6) { Bj = mk3(d == 3 ? 1.f : 0.f, d == 4 ? 1.f : 0.f, d == 5 ? 1.f : 0.f); vd = L.base()[7 + d]; }
+    else if (d < ND) { Aj = ld3(L.ax[jb]); Oj = ld3(L.o[jb]); vd = L.qd()[d - 6]; }
+    const bool colv = d < kMO;                      // lanes that own a column of the records
+    auto mm = [&](int row) { return colv ? Mmx[(size_t)row * kMO + d] : 0.f; };
+    f3 Yt = mk3(mm(0), mm(1), mm(2)), Yf = mk3(mm(3), mm(4), mm(5));    // Y_0
+    const bool two_body = nc > L.nplane;            // link-link / obstacle contacts: any body, so every Y_k is kept
+    float* const Yb = rows + LT::kYOff;
+    auto storeY = [&](int k) {
+        if (two_body && colv) {
+            float* y = Yb + (size_t)k * 6 * kMO + d;
+            y[0] = Yt.x; y[kMO] = Yt.y; y[2 * kMO] = Yt.z; y[3 * kMO] = Yf.x; y[4 * kMO] = Yf.y; y[5 * kMO] = Yf.z;
+        }
+    };
+    storeY(0);
+    int kcur = 0;
+    float colnext = mm(6);                          // M^-1[:, 6 + k] of the next body, requested one body ahead
+    auto advance = [&]() {                          // Y_kcur -> Y_kcur+1
+        kcur++;
+        const float col = colnext;
+        colnext = mm(kcur < N ? 6 + kcur : 6);
+        const f3 r = ld3(L.r[kcur]), ax = ld3(L.ax[kcur]);
+        Yf = mk3(Yf.x + (Yt.y * r.z - Yt.z * r.y), Yf.y + (Yt.z * r.x - Yt.x * r.z), Yf.z + (Yt.x * r.y - Yt.y * r.x));
+        Yt = Yt + ax * col;
+        storeY(kcur);
+    };
+    // one contact: three rows from its geometry record and the Y of its body (and of the other body of a pair)
+    struct Geo { float4 g[5]; };
+    auto load_geo = [&](int ci) {
+        const int slot = __builtin_amdgcn_readfirstlane(ci < L.nplane ? L.clist[ci] : LT::NC + (ci - L.nplane));
+        const float4* g = reinterpret_cast<const float4*>(rows + LT::kGeoOff + (size_t)slot * LT::kGeo);
+        Geo G;
+#pragma unroll
+        for (int i = 0; i < 5; i++) G.g[i] = g[i];
+        return G;
+    };
+    auto assemble = [&](int ci, const Geo& G, const f3 YtA, const f3 YfA, const f3 YtB, const f3 YfB, int kA, int kB) {
+        const f3 P = mk3(G.g[0].x, G.g[0].y, G.g[0].z);
+        const float dist = G.g[0].w;
+        const f3 dA = mk3(G.g[1].x, G.g[1].y, G.g[1].z), dB = mk3(G.g[1].w, G.g[2].x, G.g[2].y);
+        const f3 dn = mk3(G.g[2].z, G.g[2].w, G.g[3].x), PB = mk3(G.g[3].y, G.g[3].z, G.g[3].w);
+        const float fsc = G.g[4].z;
+        const f3 pa = P - Oj, pk = P - ld3(L.o[kA]);
+        const bool inA = jb <= kA;
+        f3 pb = mk3(0, 0, 0), pkB = mk3(0, 0, 0);
+        bool inB = false;
+        if (kB >= 0) { pb = PB - Oj; pkB = PB - ld3(L.o[kB]); inB = jb <= kB; }
+        float Jr[3], Mr[3], den[3], rv[3];
+#pragma unroll
+        for (int kind = 0; kind < 3; kind++) {
+            const f3 dir = kind == 0 ? dn : (kind == 1 ? dA : dB);
+            float j = inA ? dot(Aj, cross(pa, dir)) + dot(Bj, dir) : 0.f;
+            float m = dot(YtA, cross(pk, dir)) + dot(YfA, dir);
+            if (kB >= 0) {                                              // wave-uniform
+                j -= inB ? dot(Aj, cross(pb, dir)) + dot(Bj, dir) : 0.f;
+                m -= dot(YtB, cross(pkB, dir)) + dot(YfB, dir);
+            }
+            if (kind != 0) m *= fsc;
+            Jr[kind] = j; Mr[kind] = m;
+            den[kind] = j * m; rv[kind] = j * vd;
+        }
+#pragma unroll
+        for (int kind = 0; kind < 3; kind++) { den[kind] = wave_sum<64>(den[kind]); rv[kind] = wave_sum<64>(rv[kind]); }
+        float Jo[3], Mo[3];
+#pragma unroll
+        for (int kind = 0; kind < 3; kind++) {
+            const float dn_ = den[kind];
+            const float dinv = dn_ > 1.1920929e-7f ? 1.0f / dn_ : 0.f;
+            float target = -rv[kind];
+            if (kind == 0) {
+                const float pen = dist + M.slop;
+                target += pen > 0.f ? -pen * M.inv_dt : -pen * M.contact_erp * M.inv_dt;
+            }
+            // the record's columns (Lds<N, false>): J / den, -rhs and 0 in the pad columns; M^-1 J^T, 0 and den
+            Jo[kind] = d == LT::kSpec ? -target * dinv : (d == LT::kSpec + 1 ? 0.f : Jr[kind] * dinv);
+            Mo[kind] = d == LT::kSpec ? 0.f : (d == LT::kSpec + 1 ? dn_ : Mr[kind]);
+        }
+        if (colv) {
+            *reinterpret_cast<float2*>(rows + (size_t)ci * LT::kRS + 2 * d) = make_float2(Jo[0], Mo[0]);
+            *reinterpret_cast<float4*>(rows + (size_t)(LT::kFric + 2 * ci) * LT::kRS + 4 * d) = make_float4(Jo[1], Jo[2], Mo[1], Mo[2]);
+        }
+        if (lane == 0) *reinterpret_cast<float4*>(L.acc[ci]) = make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    // ---- (c) ground contacts, in the order of their bodies: Y stays in registers
+    const int nplane = L.nplane;
+    if (nplane > 0) {
+        Geo cur = load_geo(0);
+        for (int ci = 0; ci < nplane; ci++) {
+            const Geo nxt = load_geo(ci + 1 < nplane ? ci + 1 : ci);
+            const int kA = __builtin_amdgcn_readfirstlane((int)cur.g[4].x);
+            while (kcur < kA) advance();
+            assemble(ci, cur, Yt, Yf, mk3(0, 0, 0), mk3(0, 0, 0), kA, -1);
+            cur = nxt;
+        }
+    }
+    // ---- (d) link-link and obstacle contacts: any two bodies, their Y from the block the recursion left behind
+    if (two_body) {
+        while (kcur < N) advance();
+        __threadfence();
+        lds_sync();
+        for (int ci = nplane; ci < nc; ci++) {
+            const Geo G = load_geo(ci);
+            const int kA = __builtin_amdgcn_readfirstlane((int)G.g[4].x), kB = __builtin_amdgcn_readfirstlane((int)G.g[4].y);
+            auto ldY = [&](int k, f3& yt, f3& yf) {
+                const float* y = Yb + (size_t)k * 6 * kMO + (colv ? d : 0);
+                yt = colv ? mk3(y[0], y[kMO], y[2 * kMO]) : mk3(0, 0, 0);
+                yf = colv ? mk3(y[3 * kMO], y[4 * kMO], y[5 * kMO]) : mk3(0, 0, 0);
+            };
+            f3 ytA, yfA, ytB = mk3(0, 0, 0), yfB = mk3(0, 0, 0);
+            ldY(kA, ytA, yfA);
+            if (kB >= 0) ldY(kB, ytB, yfB);
+            assemble(ci, G, ytA, yfA, ytB, yfB, kA, kB);
+        }
+    }
+    lds_sync();
+    // ---- (e) non-contact rows: violated joint limits first, then the n motors
+    // (btMultiBodyJointLimitConstraint, btMultiBodyJointMotor [U])
+    const float mden_j = __shfl(mden, lane + 6);    // motor / joint `lane`: its denominator sits in lane 6 + lane
+    int nlim = 0;
+    {
+        bool viol = false;
+        float sgn = 0.f, pen = 0.f;
+        if (lane < N) {
+            float qj = L.q()[lane];
+            float plo = qj - M.jlo, phi = M.jhi - qj;
+            if (plo <= 0.f) { viol = true; sgn = 1.f; pen = plo; }
+            else if (phi <= 0.f) { viol = true; sgn = -1.f; pen = phi; }
+        }
+        unsigned long long bal = __ballot(viol);
+        nlim = __popcll(bal);
+        if (viol) {
+            int idx = __popcll(bal & ((1ull << lane) - 1ull));
+            float den = mden_j;
+            float dinv = den > 1.1920929e-7f ? 1.0f / den : 0.f;
+            float rel = sgn * L.qd()[lane];
+            L.nc_joint[idx] = lane; L.nc_sign[idx] = sgn;
+            L.nc_rhs[idx] = (-rel + (-pen) * M.limit_erp * M.inv_dt) * dinv;
+            L.nc_dinv[idx] = dinv; L.nc_den[idx] = den;
+            L.nc_lo[idx] = 0.f; L.nc_hi[idx] = M.limit_max; L.nc_app[idx] = 0.f;
+        }
+        if (lane < N) {
+            int idx = nlim + lane;
+            float den = mden_j;
             float dinv = den > 1.1920929e-7f ? 1.0f / den : 0.f;
             float cur = L.qd()[lane];
             float want = M.kp * (L.targets[lane] - L.q()[lane]) * M.inv_dt + cur + M.kd * (0.f - cur);
@@ -1023,7 +1256,7 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
     // the motors' M^-1 columns stay in registers for the whole solve (they are read 50 x n times)
     float RMm[N];
 #pragma unroll
-    for (int j = 0; j < N; j++) RMm[j] = ldJ((unsigned)(LT::kMmOff * 4) + (unsigned)j * kHalfB);   // columns >= ND: zero
+    for (int j = 0; j < N; j++) RMm[j] = ldJ((unsigned)(LT::kMmOff * 4) + (unsigned)(6 + j) * kHalfB);   // columns >= ND: zero
     // ... and so do the normal rows of the first kResN contacts: the registers the rings leave free hold an eighth of
     // the stream (the kernel is bound by that stream)
     constexpr int kResN = LT::kResN;
@@ -1044,7 +1277,7 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
                 float sum = fminf(fmaxf(a0 + dI, L.nc_lo[idx]), L.nc_hi[idx]);
                 dI = sum - a0;
                 L.nc_app[idx] = sum;   // uniform value, every lane stores it: no barrier needed
-                const float mv = ldJ((unsigned)(LT::kMmOff * 4) + (unsigned)j * kHalfB);      // a violated limit is rare
+                const float mv = ldJ((unsigned)(LT::kMmOff * 4) + (unsigned)(6 + j) * kHalfB);      // a violated limit is rare
                 dv += sg * mv * dI;
                 lsq_nc = fmaxf(lsq_nc, fabsf(dI * L.nc_den[idx]));
             }
@@ -1195,8 +1428,13 @@ __device__ void substep_v1(LT& L, const DevModel& M, int lane, float mu, int& it
     constexpr int N = LT::kN;
     constexpr int ND = N + 6;
     const float dt = M.dt;
+#ifdef SNK_PROFILE
+    unsigned long long prof_t[10];
+#endif
+    SNK_STAMP(0)
     // (1) contacts of the current pose, (2) bias forces with gravity, joint damping torque
     int nc = find_contacts_v1(L, M, lane, rows, mf);
+    SNK_STAMP(1)
     if (lane == 0) L.nplane = nc;
     const int nplane = nc;
     if (M.self_collision || M.obstacle)
@@ -1204,6 +1442,7 @@ __device__ void substep_v1(LT& L, const DevModel& M, int lane, float mu, int& it
     ncontacts = nc;
     __threadfence();      // contact geometry: written lane = slot, read lane = row
     lds_sync();
+    SNK_STAMP(2)
     if (lane < N) {
         float qd = L.qd()[lane];
         L.qd_old[lane] = qd;
@@ -1212,6 +1451,7 @@ __device__ void substep_v1(LT& L, const DevModel& M, int lane, float mu, int& it
     body_bias<LT, true>(L, M, lane);
     lds_sync();
     aba_main<LT, true>(L, M, lane);
+    SNK_STAMP(3)
     // joint-0 force sensor, first pass [U]: -zb . [m_r (a - g) + m_r v (k + k|v|)]
     f3 zb = mulRv(L.R[0], ld3(M.zbase));
     f3 v_old = ld3(L.base() + 10);
@@ -1237,8 +1477,11 @@ __device__ void substep_v1(LT& L, const DevModel& M, int lane, float mu, int& it
     lds_sync();
     // (4) rows, (5) PGS
     int nn = 0;
+    SNK_STAMP(4)
     build_rows_v1(L, M, lane, nc, nn, rows);
+    SNK_STAMP(5)
     float dv = pgs_v1(L, M, lane, nc, nn, mu, iters, rows);
+    SNK_STAMP(6)
     // only when this substep can be the last of its env-step (sensor_pass_needed)
     if (sensor_pass_needed(L, M, lane, dv, hint)) {
         // (6) constraint pass for the joint-0 sensor [U]: ABA at the velocities after (3) with the
@@ -1305,6 +1548,7 @@ __device__ void substep_v1(LT& L, const DevModel& M, int lane, float mu, int& it
             fz3 += joint1_fz();
         }
     }
+    SNK_STAMP(7)
     // (7) apply the solver's delta-v (clamped), motor torques, integrate positions
     if (lane < 6) {
         float x = L.base()[7 + lane] + dv;
@@ -1345,8 +1589,15 @@ __device__ void substep_v1(LT& L, const DevModel& M, int lane, float mu, int& it
         }
     }
     lds_sync();
+    SNK_STAMP(8)
     // pose of the new state: feeds checkSnakeHeight and the next substep
     fk_vel(L, M, lane);
+    SNK_STAMP(9)
+#ifdef SNK_PROFILE
+    lds_sync();
+    if (lane < 9) L.taum()[lane] = (float)(prof_t[lane + 1] - prof_t[lane]);
+    lds_sync();
+#endif
 }
 
 }  // namespace snk

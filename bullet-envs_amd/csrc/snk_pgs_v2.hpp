@@ -49,11 +49,7 @@ namespace snk {
 
 // -DSNK_PROFILE: s_memtime stamps between the phases of substep_v2; the phase durations (ticks)
 // overwrite the motor-torque outputs of the substep (tools/profile_phases.py reads them).
-#ifdef SNK_PROFILE
-#define SNK_STAMP(i) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); prof_t[i] = t_; }
-#else
-#define SNK_STAMP(i)
-#endif
+// (SNK_STAMP: snk_device.hpp)
 
 struct swap2 {
     float a, b;
