@@ -137,6 +137,15 @@ __device__ __forceinline__ float lane_bcast(float x, int src_lane_uniform) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), src_lane_uniform));
 }
 
+// one DPP step of six independent reductions (operands a .. f)
+#define SNK_RED64x6_STEP(MODE)                              \
+    "v_add_f32_dpp %[a], %[a], %[a] " MODE "\n\t"            \
+    "v_add_f32_dpp %[b], %[b], %[b] " MODE "\n\t"            \
+    "v_add_f32_dpp %[c], %[c], %[c] " MODE "\n\t"            \
+    "v_add_f32_dpp %[d], %[d], %[d] " MODE "\n\t"            \
+    "v_add_f32_dpp %[e], %[e], %[e] " MODE "\n\t"            \
+    "v_add_f32_dpp %[f], %[f], %[f] " MODE "\n\t"
+
 // ----------------------------------------------------------------------------------
 // LDS image of one environment
 // ----------------------------------------------------------------------------------
@@ -961,46 +970,60 @@ __device__ void build_rows_v1(LT& L, const DevModel& M, int lane, int nc, int& n
         for (int i = 0; i < 5; i++) G.g[i] = g[i];
         return G;
     };
-    auto assemble = [&](int ci, const Geo& G, const f3 YtA, const f3 YfA, const f3 YtB, const f3 YfB, int kA, int kB) {
+    const float spec0 = d == LT::kSpec ? 1.0f : 0.f, spec1 = d == LT::kSpec + 1 ? 1.0f : 0.f;    // the records' scalar columns
+    auto assemble = [&](int ci, const Geo& G, const f3 YtA, const f3 YfA, const f3 YtB, const f3 YfB, int kA, int kB,
+                        auto two_c) {
+        constexpr bool TWO = decltype(two_c)::value;       // a pair of bodies (link-link) or one body against the world
         const f3 P = mk3(G.g[0].x, G.g[0].y, G.g[0].z);
         const float dist = G.g[0].w;
         const f3 dA = mk3(G.g[1].x, G.g[1].y, G.g[1].z), dB = mk3(G.g[1].w, G.g[2].x, G.g[2].y);
         const f3 dn = mk3(G.g[2].z, G.g[2].w, G.g[3].x), PB = mk3(G.g[3].y, G.g[3].z, G.g[3].w);
         const float fsc = G.g[4].z;
         const f3 pa = P - Oj, pk = P - ld3(L.o[kA]);
-        const bool inA = jb <= kA;
+        const float inA = jb <= kA ? 1.0f : 0.f;
         f3 pb = mk3(0, 0, 0), pkB = mk3(0, 0, 0);
-        bool inB = false;
-        if (kB >= 0) { pb = PB - Oj; pkB = PB - ld3(L.o[kB]); inB = jb <= kB; }
-        float Jr[3], Mr[3], den[3], rv[3];
+        float inB = 0.f;
+        if (TWO && kB >= 0) { pb = PB - Oj; pkB = PB - ld3(L.o[kB]); inB = jb <= kB ? 1.0f : 0.f; }
+        float Jr[3], Mr[3], red[6];
 #pragma unroll
         for (int kind = 0; kind < 3; kind++) {
             const f3 dir = kind == 0 ? dn : (kind == 1 ? dA : dB);
-            float j = inA ? dot(Aj, cross(pa, dir)) + dot(Bj, dir) : 0.f;
+            float j = inA * (dot(Aj, cross(pa, dir)) + dot(Bj, dir));
             float m = dot(YtA, cross(pk, dir)) + dot(YfA, dir);
-            if (kB >= 0) {                                              // wave-uniform
-                j -= inB ? dot(Aj, cross(pb, dir)) + dot(Bj, dir) : 0.f;
+            if (TWO && kB >= 0) {                                       // wave-uniform
+                j -= inB * (dot(Aj, cross(pb, dir)) + dot(Bj, dir));
                 m -= dot(YtB, cross(pkB, dir)) + dot(YfB, dir);
             }
-            if (kind != 0) m *= fsc;
+            if (TWO && kind != 0) m *= fsc;                             // (ground contacts: scale 1)
             Jr[kind] = j; Mr[kind] = m;
-            den[kind] = j * m; rv[kind] = j * vd;
+            red[kind] = j * m; red[3 + kind] = j * vd;
         }
-#pragma unroll
-        for (int kind = 0; kind < 3; kind++) { den[kind] = wave_sum<64>(den[kind]); rv[kind] = wave_sum<64>(rv[kind]); }
+        // six sums over the wave, their DPP steps interleaved (each instruction is the others' wait state)
+        asm volatile(
+            "s_nop 1\n\t"      // the operands may have been written by the instructions just before (VALU write -> DPP read)
+            SNK_RED64x6_STEP("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1")
+            SNK_RED64x6_STEP("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1")
+            SNK_RED64x6_STEP("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+            SNK_RED64x6_STEP("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+            SNK_RED64x6_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")
+            SNK_RED64x6_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
+            : [a] "+v"(red[0]), [b] "+v"(red[1]), [c] "+v"(red[2]), [d] "+v"(red[3]), [e] "+v"(red[4]), [f] "+v"(red[5]));
         float Jo[3], Mo[3];
 #pragma unroll
         for (int kind = 0; kind < 3; kind++) {
-            const float dn_ = den[kind];
-            const float dinv = dn_ > 1.1920929e-7f ? 1.0f / dn_ : 0.f;
-            float target = -rv[kind];
+            const float dn_ = lane_bcast(red[kind], 63), rv_ = lane_bcast(red[3 + kind], 63);
+            float rc = __builtin_amdgcn_rcpf(dn_);
+            rc = rc * (2.0f - dn_ * rc);                                // one Newton step: within an ulp of 1 / den
+            const float dinv = dn_ > 1.1920929e-7f ? rc : 0.f;
+            float target = -rv_;
             if (kind == 0) {
                 const float pen = dist + M.slop;
                 target += pen > 0.f ? -pen * M.inv_dt : -pen * M.contact_erp * M.inv_dt;
             }
-            // the record's columns (Lds<N, false>): J / den, -rhs and 0 in the pad columns; M^-1 J^T, 0 and den
-            Jo[kind] = d == LT::kSpec ? -target * dinv : (d == LT::kSpec + 1 ? 0.f : Jr[kind] * dinv);
-            Mo[kind] = d == LT::kSpec ? 0.f : (d == LT::kSpec + 1 ? dn_ : Mr[kind]);
+            // the record's columns (Lds<N, false>): J / den with -rhs and 0 in the pad columns; M^-1 J^T with 0 and den
+            // (J and M^-1 J^T are zero in the pad columns as they come)
+            Jo[kind] = dinv * (Jr[kind] - spec0 * target);
+            Mo[kind] = Mr[kind] + spec1 * dn_;
         }
         if (colv) {
             *reinterpret_cast<float2*>(rows + (size_t)ci * LT::kRS + 2 * d) = make_float2(Jo[0], Mo[0]);
@@ -1010,14 +1033,23 @@ __device__ void build_rows_v1(LT& L, const DevModel& M, int lane, int nc, int& n
     };
     // ---- (c) ground contacts, in the order of their bodies: Y stays in registers
     const int nplane = L.nplane;
-    if (nplane > 0) {
-        Geo cur = load_geo(0);
-        for (int ci = 0; ci < nplane; ci++) {
-            const Geo nxt = load_geo(ci + 1 < nplane ? ci + 1 : ci);
-            const int kA = __builtin_amdgcn_readfirstlane((int)cur.g[4].x);
+    {
+        const f3 z3 = mk3(0, 0, 0);
+        auto one = [&](int ci, const Geo& G) {
+            const int kA = __builtin_amdgcn_readfirstlane((int)G.g[4].x);
             while (kcur < kA) advance();
-            assemble(ci, cur, Yt, Yf, mk3(0, 0, 0), mk3(0, 0, 0), kA, -1);
-            cur = nxt;
+            assemble(ci, G, Yt, Yf, z3, z3, kA, -1, std::false_type{});
+        };
+        if (nplane > 0) {
+            Geo ga = load_geo(0);                                       // two records in flight, no copies between them
+            for (int ci = 0; ci < nplane; ci += 2) {
+                const Geo gb = load_geo(ci + 1 < nplane ? ci + 1 : ci);
+                one(ci, ga);
+                if (ci + 1 < nplane) {
+                    ga = load_geo(ci + 2 < nplane ? ci + 2 : ci + 1);
+                    one(ci + 1, gb);
+                }
+            }
         }
     }
     // ---- (d) link-link and obstacle contacts: any two bodies, their Y from the block the recursion left behind
@@ -1036,7 +1068,7 @@ __device__ void build_rows_v1(LT& L, const DevModel& M, int lane, int nc, int& n
             f3 ytA, yfA, ytB = mk3(0, 0, 0), yfB = mk3(0, 0, 0);
             ldY(kA, ytA, yfA);
             if (kB >= 0) ldY(kB, ytB, yfB);
-            assemble(ci, G, ytA, yfA, ytB, yfB, kA, kB);
+            assemble(ci, G, ytA, yfA, ytB, yfB, kA, kB, std::true_type{});
         }
     }
     lds_sync();
