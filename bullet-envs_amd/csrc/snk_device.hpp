@@ -680,194 +680,8 @@ __device__ void aba_main(LT& L, const DevModel& M, int lane) {
 }
 
 // ----------------------------------------------------------------------------------
-// S5: constraint rows, lane = row.  Each lane runs the ABA delta sweeps for a unit
-// (generalized) impulse -> M^-1 J^T, and builds J, the diagonal and the right-hand side
-// (btMultiBodyConstraintSolver::setupMultiBodyContactConstraint / btMultiBodyJointMotor [U]).
-// ----------------------------------------------------------------------------------
-template <class LT>
-__device__ void build_rows_v1_lane_is_row(LT& L, const DevModel& M, int lane, int nc, int& n_noncontact, float* __restrict__ rows) {
-    constexpr int N = LT::kN;
-    constexpr int ND = N + 6;
-    const int nrows = N + 3 * nc;
-    const float* gb = L.base() + 7;   // omega_w, v_w (after the unconstrained update)
-    float mden = 0.f;                 // diagonal M^-1[6+j][6+j] of this lane's motor row (row j = lane < N: first trip)
-    for (int rid = lane; rid < nrows; rid += 64) {
-        // every trip re-reads the chain from LDS: with no LDS store left in the loop the compiler would otherwise hoist
-        // the ~500 loop-invariant per-body values out of it and spill them (1.2 KB of scratch per lane)
-        asm volatile("" : : : "memory");
-        const bool motor = rid < N;
-        int k, slot = 0, kind = 0, kB = -1;
-        f3 P = mk3(0, 0, 0), d = mk3(0, 0, 0), PB = mk3(0, 0, 0);
-        float cdist_slot = 0.f, fscale = 1.0f;
-        float* Mrow;             // final row of M^-1 J^T (global memory: the motors' block or the contact row's record)
-        float* Jrow = nullptr;   // final J row (contact rows only)
-        int S = 1;               // floats between a row's consecutive columns (the records interleave their vectors)
-        float uu[N];             // joint-space residuals between the two sweeps, in registers (both sweeps are fully unrolled)
-        if (motor) {
-            k = rid + 1;
-            Mrow = rows + LT::kMmOff + (size_t)rid * LT::kMO;
-        } else {
-            const int ci = (rid - N) / 3;
-            kind = (rid - N) - 3 * ci;
-            // ground contacts first (slot = cylinder end cap), then the link-link contacts (slots NC ...)
-            slot = ci < L.nplane ? L.clist[ci] : LT::NC + (ci - L.nplane);
-            const float* geo = rows + LT::kGeoOff + (size_t)slot * LT::kGeo;
-            P = ld3(geo);
-            d = kind == 0 ? ld3(geo + 10) : (kind == 1 ? ld3(geo + 4) : ld3(geo + 7));
-            cdist_slot = geo[3];
-            k = (int)geo[16];
-            kB = (int)geo[17];                  // -1: the ground
-            PB = ld3(geo + 13);
-            if (kind != 0) fscale = geo[18];    // friction rows of a link-link contact: see find_self_contacts_v1
-            // a normal's record: [J0 M0 J1 M1 ...]; a friction pair's: [JA0 JB0 MA0 MB0 JA1 ...] (Lds<N, false>)
-            if (kind == 0) {
-                S = 2;
-                Jrow = rows + (size_t)ci * LT::kRS;
-                Mrow = Jrow + 1;
-            } else {
-                S = 4;
-                Jrow = rows + (size_t)(LT::kFric + 2 * ci) * LT::kRS + (kind - 1);
-                Mrow = Jrow + 2;
-            }
-        }
-        // backward sweep of the delta problem (zero velocity, impulse only)
-        f3 pN = mk3(0, 0, 0), pF = mk3(0, 0, 0);
-#pragma unroll
-        for (int b = N; b >= 1; b--) {
-            f3 ax = ld3(L.ax[b]);
-            if (!motor && b == k) {
-                pN = pN - cross(P - ld3(L.o[b]), d);
-                pF = pF - d;
-            }
-            if (!motor && b == kB) {          // the opposite unit impulse on the other body of a link-link contact
-                pN = pN + cross(PB - ld3(L.o[b]), d);
-                pF = pF + d;
-            }
-            float u = -dot(ax, pN);
-            if (motor && b == k) u += 1.0f;
-            uu[b - 1] = u;
-            float t = u * L.Dinv[b];
-            f3 paN = pN + ld3(L.Ua[b]) * t, paF = pF + ld3(L.Ub[b]) * t;
-            pN = paN + cross(ld3(L.r[b]), paF);
-            pF = paF;
-        }
-        // (same reason, between the sweeps: the forward sweep re-reads each body from LDS instead of finding 13 values
-        //  per body kept -- spilled -- from the backward sweep)
-        asm volatile("" : : : "memory");
-        f3 J0 = mk3(0, 0, 0), J1 = mk3(0, 0, 0);
-        if (!motor) {
-            J0 = cross(P - ld3(L.o[0]), d);
-            J1 = d;
-            if (k == 0) { pN = pN - J0; pF = pF - d; }
-            if (kB >= 0) {
-                const f3 JB = cross(PB - ld3(L.o[0]), d);
-                if (kB == 0) { pN = pN + JB; pF = pF + d; }
-                J0 = J0 - JB;                 // both bodies ride on the base: its rows see the pair's net wrench only
-                J1 = mk3(0.f, 0.f, 0.f);
-            }
-        }
-        float p0[6] = {pN.x, pN.y, pN.z, pF.x, pF.y, pF.z}, a0[6];
-#pragma unroll
-        for (int i = 0; i < 6; i++) {
-            float s = 0.f;
-#pragma unroll
-            for (int j = 0; j < 6; j++) s -= L.Inv0[6 * i + j] * p0[j];
-            a0[i] = s;
-            Mrow[i * S] = s * fscale;
-        }
-        f3 al = mk3(a0[0], a0[1], a0[2]), a = mk3(a0[3], a0[4], a0[5]);
-        float den = dot(J0, al) + dot(J1, a);
-        float rv = dot(J0, ld3(gb)) + dot(J1, ld3(gb + 3));
-#pragma unroll
-        for (int b = 1; b <= N; b++) {
-            a = a + cross(al, ld3(L.r[b]));
-            float u = uu[b - 1];
-            float qdd = (u - (dot(ld3(L.Ua[b]), al) + dot(ld3(L.Ub[b]), a))) * L.Dinv[b];
-            f3 ax = ld3(L.ax[b]);
-            al = al + ax * qdd;
-            Mrow[(6 + b - 1) * S] = qdd * fscale;
-            if (!motor) {
-                float Jb = (b <= k) ? dot(ax, cross(P - ld3(L.o[b]), d)) : 0.f;
-                if (b <= kB) Jb -= dot(ax, cross(PB - ld3(L.o[b]), d));
-                Jrow[(6 + b - 1) * S] = Jb;      // unscaled for now: the denominator comes out of this very loop
-                den += Jb * qdd;
-                rv += Jb * L.qd()[b - 1];
-            } else if (b == k) {
-                den = qdd;
-            }
-        }
-        if (motor) mden = den;
-        if (!motor) {
-            const int row = rid - N;
-            den *= fscale;
-            float dinv = den > 1.1920929e-7f ? 1.0f / den : 0.f;
-            float target;
-            if (kind == 0) {
-                float pen = cdist_slot + M.slop;
-                target = -rv + (pen > 0.f ? -pen * M.inv_dt : -pen * M.contact_erp * M.inv_dt);
-            } else {
-                target = -rv;
-            }
-            // the record: J / den, the scalars in the pad columns (Lds<N, false>::kSpec); a row without a usable
-            // denominator becomes all zero (dI = 0 for good, as Bullet's 1/den = 0 makes it)
-            // (the joint columns go through memory once more instead of waiting in 32 registers: with them the
-            //  unrolled sweeps spilled 1.4 KB per lane)
-            Jrow[0] = J0.x * dinv; Jrow[S] = J0.y * dinv; Jrow[2 * S] = J0.z * dinv;
-            Jrow[3 * S] = J1.x * dinv; Jrow[4 * S] = J1.y * dinv; Jrow[5 * S] = J1.z * dinv;
-            {
-                float* Jq = Jrow;
-                asm volatile("" : "+v"(Jq) : : "memory");       // no store-to-load forwarding of the 32 values
-#pragma unroll
-                for (int b = 0; b < N; b++) Jq[(6 + b) * S] *= dinv;
-            }
-            Jrow[LT::kSpec * S] = -target * dinv; Jrow[(LT::kSpec + 1) * S] = 0.f;
-            Mrow[LT::kSpec * S] = 0.f; Mrow[(LT::kSpec + 1) * S] = den;
-            L.acc[row / 3][kind] = 0.f;
-        }
-    }
-    lds_sync();
-    // non-contact rows: violated joint limits first, then the n motors
-    // (btMultiBodyJointLimitConstraint, btMultiBodyJointMotor [U])
-    int nlim = 0;
-    {
-        bool viol = false;
-        float sgn = 0.f, pen = 0.f;
-        if (lane < N) {
-            float qj = L.q()[lane];
-            float plo = qj - M.jlo, phi = M.jhi - qj;
-            if (plo <= 0.f) { viol = true; sgn = 1.f; pen = plo; }
-            else if (phi <= 0.f) { viol = true; sgn = -1.f; pen = phi; }
-        }
-        unsigned long long bal = __ballot(viol);
-        nlim = __popcll(bal);
-        if (viol) {
-            int idx = __popcll(bal & ((1ull << lane) - 1ull));
-            float den = mden;
-            float dinv = den > 1.1920929e-7f ? 1.0f / den : 0.f;
-            float rel = sgn * L.qd()[lane];
-            L.nc_joint[idx] = lane; L.nc_sign[idx] = sgn;
-            L.nc_rhs[idx] = (-rel + (-pen) * M.limit_erp * M.inv_dt) * dinv;
-            L.nc_dinv[idx] = dinv; L.nc_den[idx] = den;
-            L.nc_lo[idx] = 0.f; L.nc_hi[idx] = M.limit_max; L.nc_app[idx] = 0.f;
-        }
-        if (lane < N) {
-            int idx = nlim + lane;
-            float den = mden;
-            float dinv = den > 1.1920929e-7f ? 1.0f / den : 0.f;
-            float cur = L.qd()[lane];
-            float want = M.kp * (L.targets[lane] - L.q()[lane]) * M.inv_dt + cur + M.kd * (0.f - cur);
-            L.nc_joint[idx] = lane; L.nc_sign[idx] = 1.f;
-            L.nc_rhs[idx] = (want - cur) * dinv;
-            L.nc_dinv[idx] = dinv; L.nc_den[idx] = den;
-            L.nc_lo[idx] = -M.max_motor_imp; L.nc_hi[idx] = M.max_motor_imp; L.nc_app[idx] = 0.f;
-        }
-    }
-    n_noncontact = nlim + N;
-    lds_sync();
-}
-
-// ----------------------------------------------------------------------------------
-// S5 (round 2): the same rows, built lane = velocity component.
+// S5: constraint rows of the streamed-row solve, built lane = velocity component (round 1 built them lane = row:
+// one pair of ABA delta sweeps per row, see the history of this file).
 // A contact row's M^-1 J^T is linear in the 6-dimensional wrench its unit impulse puts on its body:
 //     M^-1 J^T = Y_k (tau, f),   tau = (P - o_k) x dir,  f = dir,   Y_k = M^-1 Jbody_k^T   (38 x 6),
 // and the Y_k follow from the columns of M^-1 by a recursion down the chain (a wrench on body k about o_k is the
@@ -905,7 +719,9 @@ __device__ void build_rows_v1(LT& L, const DevModel& M, int lane, int nc, int& n
             pN = paN + cross(ld3(L.r[b]), paF);
             pF = paF;
         }
-        asm volatile("" : : : "memory");            // the forward sweep re-reads the bodies (build_rows_v1_lane_is_row)
+        // the forward sweep re-reads each body from LDS instead of finding 13 values per body kept -- spilled -- from
+        // the backward sweep (there is no LDS store in between that would make the compiler reload them)
+        asm volatile("" : : : "memory");
         float p0[6] = {pN.x, pN.y, pN.z, pF.x, pF.y, pF.z}, a0[6];
 #pragma unroll
         for (int i = 0; i < 6; i++) if (lane == i) p0[i] = -1.0f;      // unit force on the base: bias -e_i
@@ -979,21 +795,24 @@ __device__ void build_rows_v1(LT& L, const DevModel& M, int lane, int nc, int& n
         const f3 dA = mk3(G.g[1].x, G.g[1].y, G.g[1].z), dB = mk3(G.g[1].w, G.g[2].x, G.g[2].y);
         const f3 dn = mk3(G.g[2].z, G.g[2].w, G.g[3].x), PB = mk3(G.g[3].y, G.g[3].z, G.g[3].w);
         const float fsc = G.g[4].z;
-        const f3 pa = P - Oj, pk = P - ld3(L.o[kA]);
-        const float inA = jb <= kA ? 1.0f : 0.f;
-        f3 pb = mk3(0, 0, 0), pkB = mk3(0, 0, 0);
-        float inB = 0.f;
-        if (TWO && kB >= 0) { pb = PB - Oj; pkB = PB - ld3(L.o[kB]); inB = jb <= kB ? 1.0f : 0.f; }
+        // J[d] = A_d . ((P - O_d) x dir) + B_d . dir = dir . (A_d x (P - O_d) + B_d), and likewise
+        // M^-1 J^T [d] = Yt . ((P - o_k) x dir) + Yf . dir = dir . (Yt x (P - o_k) + Yf): one vector per contact and
+        // lane for each, a dot product per row
+        f3 Cj = cross(Aj, P - Oj) + Bj;
+        if (!(jb <= kA)) Cj = mk3(0, 0, 0);
+        f3 Dj = cross(YtA, P - ld3(L.o[kA])) + YfA;
+        if (TWO && kB >= 0) {                                           // wave-uniform: minus the same for the other body
+            f3 Cb = cross(Aj, PB - Oj) + Bj;
+            if (!(jb <= kB)) Cb = mk3(0, 0, 0);
+            Cj = Cj - Cb;
+            Dj = Dj - (cross(YtB, PB - ld3(L.o[kB])) + YfB);
+        }
         float Jr[3], Mr[3], red[6];
 #pragma unroll
         for (int kind = 0; kind < 3; kind++) {
             const f3 dir = kind == 0 ? dn : (kind == 1 ? dA : dB);
-            float j = inA * (dot(Aj, cross(pa, dir)) + dot(Bj, dir));
-            float m = dot(YtA, cross(pk, dir)) + dot(YfA, dir);
-            if (TWO && kB >= 0) {                                       // wave-uniform
-                j -= inB * (dot(Aj, cross(pb, dir)) + dot(Bj, dir));
-                m -= dot(YtB, cross(pkB, dir)) + dot(YfB, dir);
-            }
+            const float j = dot(dir, Cj);
+            float m = dot(dir, Dj);
             if (TWO && kind != 0) m *= fsc;                             // (ground contacts: scale 1)
             Jr[kind] = j; Mr[kind] = m;
             red[kind] = j * m; red[3 + kind] = j * vd;
