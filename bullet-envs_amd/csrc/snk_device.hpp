@@ -1212,14 +1212,15 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
                 constexpr unsigned kZeroB = (unsigned)(LT::kRows - 3) * kRecB;   // 960 bytes of zeros: the refill of a skipped pair
                 float jA[kC], jB[kC], mA[kC], mB[kC];
                 {
-                    const unsigned l0 = (unsigned)m0;
+                    const unsigned long long l0 = m0;
 #pragma unroll
                     for (int k = 0; k < kC; k++)
-                        ldF((l0 >> k) & 1u ? kFricB + (unsigned)k * 2u * kRecB : kZeroB, jA[k], jB[k], mA[k], mB[k]);
+                        ldF((l0 >> k) & 1ull ? kFricB + (unsigned)k * 2u * kRecB : kZeroB, jA[k], jB[k], mA[k], mB[k]);
                 }
                 float4 fn = *reinterpret_cast<const float4*>(L.acc[0]);
                 for (int base = 0; base < nc_pad; base += kC) {
-                    unsigned lv = (unsigned)m0;                     // bits 0 .. kC - 1: this trip, kC .. 2 kC - 1: the next
+                    unsigned long long lv = m0;                     // bits 0 .. kC - 1: this trip, kC .. 2 kC - 1: the next
+                    static_assert(2 * kC <= 64, "two trips' bits in one word");
                     m0 = (m0 >> kC) | (m1 << (64 - kC));
                     m1 = (m1 >> kC) | (m2 << (64 - kC));
                     m2 >>= kC;
@@ -1229,13 +1230,13 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
                         const float4 c = fn;
                         fn = *reinterpret_cast<const float4*>(L.acc[base + k + 1]);
                         asm volatile("" : "+s"(lv));         // the test stays a scalar bit test here (hoisted, sixteen lane masks spill SGPRs)
-                        if ((lv >> k) & 1u) {
+                        if ((lv >> k) & 1ull) {
                             float aA = c.y, aB = c.z;
                             row_step_cone<LT::kMO - 1>(jA[k], mA[k], jB[k], mB[k], aA, aB, mu * c.x, EPS, dv, lsq);
                             *reinterpret_cast<float2*>(&L.acc[base + k][1]) = make_float2(aA, aB);
                         }
                         // the refill, issued after the step (the four registers are free then): the pair kC further on
-                        ldF((lv >> (kC + k)) & 1u ? kFricB + (unsigned)(base + kC + k) * 2u * kRecB : kZeroB, jA[k], jB[k], mA[k], mB[k]);
+                        ldF((lv >> (kC + k)) & 1ull ? kFricB + (unsigned)(base + kC + k) * 2u * kRecB : kZeroB, jA[k], jB[k], mA[k], mB[k]);
                     }
                 }
             } else {
