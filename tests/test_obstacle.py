@@ -141,3 +141,45 @@ def test_add_obstacle_mirror(pkg):
         mx = max(mx, abs(float(env._stepper.joint3_reaction_fz()[0])))
     assert o[48] < 0.004 and mx > 20.0
     env.close()
+
+
+@gpu
+def test_two_solves_one_physics(pkg):
+    """The 16-link chain through both solves: rows resident in registers (lane = row builder, two rows per register) and
+    rows streamed from memory (the obstacle kernels, the box parked 50 m away: rows built lane = velocity component from
+    the columns of M^-1, 40-lane solve).  Two independent float32 implementations of the same substep: one env-step
+    (13-31 substeps of 50 Gauss-Seidel iterations on a contact-rich state) from a common state, for gait and for random
+    actions.  They part the way float32 and float64 part (test_env_step_parity_*: 1e-3 in angle at worst), not the way
+    two models would: median 1e-4 in angle, nine in ten near 1e-3."""
+    import bench
+    B = 64
+    rng = np.random.default_rng(3)
+    a_ = pkg.Stepper(B)
+    b_ = pkg.Stepper(B, obstacle=1, obstacle_pos=[50.0, 0.0, 0.1])
+    a_.reset(); b_.reset()
+    eq, eqd, er = [], [], []
+    mism = 0
+    for j in range(8):
+        S, X = a_.get_state()
+        b_.set_state(S, X)
+        act = bench.gait_actions(np.arange(B), j).astype(np.float32) if j < 5 else rng.uniform(-1, 1, (B, 8)).astype(np.float32)
+        oa, ra, da, sa = a_.step(act.copy(), vec_mode=False)
+        ob, rb, db, sb = b_.step(act.copy(), vec_mode=False)
+        same = (sa == sb) & (da == db)
+        mism += int((~same).sum())
+        oa, ob = oa[same].astype(np.float64), ob[same].astype(np.float64)
+        eq.append(np.maximum(np.abs(oa[:, :16] - ob[:, :16]).max(axis=1), np.abs(oa[:, 48:55] - ob[:, 48:55]).max(axis=1)))
+        eqd.append((np.abs(oa[:, 16:32] - ob[:, 16:32]) / (1 + np.abs(oa[:, 16:32]))).max(axis=1))
+        d = np.abs(ra[same] - rb[same])
+        er.append(d[d < 5.0])                      # (the -10 step of the reward at |joint-0 force| > 10 is a boundary decision)
+    eq, eqd, er = np.concatenate(eq), np.concatenate(eqd), np.concatenate(er)
+    st = {k: (float(np.median(v)), float(np.percentile(v, 90)), float(v.max())) for k, v in (("q", eq), ("qd", eqd), ("r", er))}
+    print("register-resident vs streamed-row solve, 16 links (median, 90th percentile, worst):", st,
+          "| substep-count mismatches", mism, "of", 8 * B)
+    assert mism <= 8 * B // 20
+    # (the float32 oracle against the float64 one on the same kind of steps: medians 3e-4 / 1e-2, 90th percentiles
+    #  1e-3 / 5e-2 -- test_env_step_parity_random_actions[16])
+    assert st["q"][0] < 3e-4 and st["q"][1] < 3e-3 and st["q"][2] < 2e-2
+    assert st["qd"][0] < 1e-2 and st["qd"][1] < 0.15
+    assert st["r"][0] < 2e-4 and st["r"][1] < 2e-3
+    a_.close(); b_.close()
