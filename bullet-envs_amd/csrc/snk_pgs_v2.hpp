@@ -799,74 +799,87 @@ __device__ __forceinline__ void cone_step(float& RJ, const float RM, const float
 // (d = 30: coupling with A1, d = 29: with B1) so that two v_fmac_f32_dpp (row_shr:1 / row_shr:2) add them to lanes
 // 31 / 63 of the partial sums without any scalar traffic.  Same arithmetic per row as cone_step; what changes is
 // the dependency chain (one reduction + one scalar round trip per two pairs instead of two).
+// Since round 2's last third the A / B halves of each pair's wave-uniform arithmetic go through gfx950's packed fp32
+// instructions: the accumulated impulses (a_A, a_B) are read into an SGPR PAIR and copied with one v_mov_b64, the two
+// `new - a` updates are one v_pk_fma_f32 with the two sums in an SGPR pair -- 52 VALU instead of 56.  Inline asm cannot
+// name the halves of a 64-bit operand, so these temporaries are PINNED registers (v250..v255, s84..s89), declared as
+// clobbers: the compiler keeps nothing in them across a step.
+#define SNK_CONE2_BODY \
+    "v_mul_f32 %[t1], %[RJ1], %[dv]\n\t" \
+    "v_mul_f32 %[t2], %[RJ2], %[dv]\n\t" \
+    "v_readlane_b32 s84, %[RJ1], 31\n\t" \
+    "v_readlane_b32 s85, %[RJ1], 63\n\t" \
+    SNK_RED2("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1") \
+    "v_readlane_b32 s86, %[RJ2], 31\n\t" \
+    "v_readlane_b32 s87, %[RJ2], 63\n\t" \
+    SNK_RED2("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1") \
+    "v_readlane_b32 %[l1], %[RJn], 31\n\t" \
+    "v_readlane_b32 %[l2], %[RJn], 63\n\t" \
+    SNK_RED2("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1") \
+    "v_mov_b64 v[250:251], s[84:85]\n\t" \
+    "s_nop 0\n\t" \
+    SNK_RED2("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1") \
+    "v_mov_b64 v[252:253], s[86:87]\n\t" \
+    "s_nop 0\n\t" \
+    SNK_RED2("row_bcast:15 row_mask:0xa bank_mask:0xf") \
+    "v_readlane_b32 s88, %[t1], 31\n\t" \
+    "v_readlane_b32 s89, %[t1], 63\n\t" \
+    "s_nop 0\n\t" \
+    "v_fma_f32 v254, s88, s88, %[EPS]\n\t" \
+    "v_fma_f32 v254, s89, s89, v254\n\t" \
+    "v_rsq_f32 v254, v254\n\t" \
+    "s_nop 0\n\t" \
+    "v_mul_f32_e64 v254, %[l1], v254 clamp\n\t" \
+    "v_pk_fma_f32 v[250:251], v[254:255], s[88:89], v[250:251] op_sel_hi:[0,1,1] neg_lo:[0,1,1] neg_hi:[0,1,1]\n\t" \
+    "v_fmac_f32_dpp %[t2], %[RJ2], v250 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+    "v_fmac_f32_dpp %[t2], %[RJ2], v251 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+    "v_cndmask_b32_e64 v250, v251, v250, %[lowmask]\n\t" \
+    "v_readlane_b32 s88, %[t2], 31\n\t" \
+    "v_readlane_b32 s89, %[t2], 63\n\t" \
+    "v_mul_f32 v251, %[RM1], v250\n\t" \
+    "v_fmac_f32 %[RJ1], %[E], v250\n\t" \
+    "v_fma_f32 v254, s88, s88, %[EPS]\n\t" \
+    "v_fma_f32 v254, s89, s89, v254\n\t" \
+    "v_rsq_f32 v254, v254\n\t" \
+    "s_nop 0\n\t" \
+    "v_mul_f32_e64 v254, %[l2], v254 clamp\n\t" \
+    "v_pk_fma_f32 v[252:253], v[254:255], s[88:89], v[252:253] op_sel_hi:[0,1,1] neg_lo:[0,1,1] neg_hi:[0,1,1]\n\t" \
+    "v_cndmask_b32_e64 v252, v253, v252, %[lowmask]\n\t" \
+    "v_mul_f32 v253, %[RM2], v252\n\t" \
+    "v_fmac_f32 %[RJ2], %[E], v252\n\t"
+#define SNK_CONE2_TAIL                           \
+    "v_add_f32 v251, v251, v253\n\t"           \
+    "v_mov_b32 v253, v251\n\t"                 \
+    "s_nop 1\n\t"                              \
+    "v_permlane32_swap_b32 v251, v253\n\t"     \
+    "v_add_f32 %[dv], %[dv], v251\n\t"         \
+    "v_add_f32 %[dv], %[dv], v253\n\t"
 template <bool RES>
 __device__ __forceinline__ void cone2_step(float& RJ1, const float RM1, float& RJ2, const float RM2, const float RJnorm,
                                            float& dv, float EPS, float E3163, unsigned long long lowmask, float& lsq) {
-    float t1, t2, x1A, x1B, x2A, x2B;
-    float a1A, a1B, a2A, a2B, l1, l2, s1A, s1B, s2A, s2B;
-    asm volatile(
-        "v_mul_f32 %[t1], %[RJ1], %[dv]\n\t"
-        "v_mul_f32 %[t2], %[RJ2], %[dv]\n\t"
-        "v_readlane_b32 %[a1A], %[RJ1], 31\n\t"
-        "v_readlane_b32 %[a1B], %[RJ1], 63\n\t"
-        SNK_RED2("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1")
-        "v_readlane_b32 %[a2A], %[RJ2], 31\n\t"
-        "v_readlane_b32 %[a2B], %[RJ2], 63\n\t"
-        SNK_RED2("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1")
-        "v_readlane_b32 %[l1], %[RJn], 31\n\t"
-        "v_readlane_b32 %[l2], %[RJn], 63\n\t"
-        SNK_RED2("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1")
-        "v_mov_b32 %[x1A], %[a1A]\n\t"
-        "v_mov_b32 %[x1B], %[a1B]\n\t"
-        SNK_RED2("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1")
-        "v_mov_b32 %[x2A], %[a2A]\n\t"
-        "v_mov_b32 %[x2B], %[a2B]\n\t"
-        SNK_RED2("row_bcast:15 row_mask:0xa bank_mask:0xf")
-        "v_readlane_b32 %[s1A], %[t1], 31\n\t"
-        "v_readlane_b32 %[s1B], %[t1], 63\n\t"
-        "s_nop 0\n\t"
-        // first pair: radial projection onto the disc of radius lambda_n (rows are in units of mu)
-        "v_fma_f32 %[t1], %[s1A], %[s1A], %[EPS]\n\t"
-        "v_fma_f32 %[t1], %[s1B], %[s1B], %[t1]\n\t"
-        "v_rsq_f32 %[t1], %[t1]\n\t"
-        "s_nop 0\n\t"
-        "v_mul_f32_e64 %[t1], %[l1], %[t1] clamp\n\t"
-        "v_fma_f32 %[x1A], %[t1], -%[s1A], -%[x1A]\n\t"
-        "v_fma_f32 %[x1B], %[t1], -%[s1B], -%[x1B]\n\t"
-        // the second pair sees it: lanes 31 / 63 of t2 += RJ2[30 / 62] dI_A1 + RJ2[29 / 61] dI_B1
-        "v_fmac_f32_dpp %[t2], %[RJ2], %[x1A] row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_fmac_f32_dpp %[t2], %[RJ2], %[x1B] row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_cndmask_b32_e64 %[x1A], %[x1B], %[x1A], %[lowmask]\n\t"
-        "v_readlane_b32 %[s2A], %[t2], 31\n\t"
-        "v_readlane_b32 %[s2B], %[t2], 63\n\t"
-        "v_mul_f32 %[x1B], %[RM1], %[x1A]\n\t"
-        "v_fmac_f32 %[RJ1], %[E], %[x1A]\n\t"
-        // second pair
-        "v_fma_f32 %[t1], %[s2A], %[s2A], %[EPS]\n\t"
-        "v_fma_f32 %[t1], %[s2B], %[s2B], %[t1]\n\t"
-        "v_rsq_f32 %[t1], %[t1]\n\t"
-        "s_nop 0\n\t"
-        "v_mul_f32_e64 %[t1], %[l2], %[t1] clamp\n\t"
-        "v_fma_f32 %[x2A], %[t1], -%[s2A], -%[x2A]\n\t"
-        "v_fma_f32 %[x2B], %[t1], -%[s2B], -%[x2B]\n\t"
-        "v_cndmask_b32_e64 %[x2A], %[x2B], %[x2A], %[lowmask]\n\t"
-        "v_mul_f32 %[x2B], %[RM2], %[x2A]\n\t"
-        "v_fmac_f32 %[RJ2], %[E], %[x2A]\n\t"
-        : [t1] "=&v"(t1), [t2] "=&v"(t2), [x1A] "=&v"(x1A), [x1B] "=&v"(x1B), [x2A] "=&v"(x2A), [x2B] "=&v"(x2B),
-          [a1A] "=&s"(a1A), [a1B] "=&s"(a1B), [a2A] "=&s"(a2A), [a2B] "=&s"(a2B), [l1] "=&s"(l1), [l2] "=&s"(l2),
-          [s1A] "=&s"(s1A), [s1B] "=&s"(s1B), [s2A] "=&s"(s2A), [s2B] "=&s"(s2B), [RJ1] "+v"(RJ1), [RJ2] "+v"(RJ2)
-        : [RM1] "v"(RM1), [RM2] "v"(RM2), [RJn] "v"(RJnorm), [dv] "v"(dv), [EPS] "v"(EPS), [E] "v"(E3163),
-          [lowmask] "s"(lowmask));
-    // x1B = RM1 dI_1, x2B = RM2 dI_2 (lane 24 / 56: den dI of the A / B rows: the residual)
-    if (RES) asm volatile("v_max3_f32 %[lsq], %[lsq], |%[p1]|, |%[p2]|" : [lsq] "+v"(lsq) : [p1] "v"(x1B), [p2] "v"(x2B));
-    asm volatile(
-        "v_add_f32 %[p1], %[p1], %[p2]\n\t"
-        "v_mov_b32 %[p2], %[p1]\n\t"
-        "s_nop 1\n\t"
-        "v_permlane32_swap_b32 %[p1], %[p2]\n\t"
-        "v_add_f32 %[dv], %[dv], %[p1]\n\t"
-        "v_add_f32 %[dv], %[dv], %[p2]\n\t"
-        : [p1] "+v"(x1B), [p2] "+v"(x2B), [dv] "+v"(dv));
+    float t1, t2;
+    float l1, l2;
+    // v[250:251] = (x1A, x1B), v[252:253] = (x2A, x2B), v254 = the pair's scale factor (v255: the pair's unused half)
+    // s[84:85] = (a1A, a1B), s[86:87] = (a2A, a2B), s[88:89] = the current pair's two sums.
+    // After the body v251 = RM1 dI_1, v253 = RM2 dI_2 (lane 24 / 56: den dI of the A / B rows: the residual); ONE asm
+    // statement, so that nothing can be scheduled into the pinned registers on the way
+    if (RES)
+        asm volatile(SNK_CONE2_BODY
+                     "v_max3_f32 %[lsq], %[lsq], |v251|, |v253|\n\t"
+                     SNK_CONE2_TAIL
+                     : [t1] "=&v"(t1), [t2] "=&v"(t2), [l1] "=&s"(l1), [l2] "=&s"(l2), [RJ1] "+v"(RJ1), [RJ2] "+v"(RJ2),
+                       [dv] "+v"(dv), [lsq] "+v"(lsq)
+                     : [RM1] "v"(RM1), [RM2] "v"(RM2), [RJn] "v"(RJnorm), [EPS] "v"(EPS), [E] "v"(E3163),
+                       [lowmask] "s"(lowmask)
+                     : "v250", "v251", "v252", "v253", "v254", "v255", "s84", "s85", "s86", "s87", "s88", "s89");
+    else
+        asm volatile(SNK_CONE2_BODY
+                     SNK_CONE2_TAIL
+                     : [t1] "=&v"(t1), [t2] "=&v"(t2), [l1] "=&s"(l1), [l2] "=&s"(l2), [RJ1] "+v"(RJ1), [RJ2] "+v"(RJ2),
+                       [dv] "+v"(dv)
+                     : [RM1] "v"(RM1), [RM2] "v"(RM2), [RJn] "v"(RJnorm), [EPS] "v"(EPS), [E] "v"(E3163),
+                       [lowmask] "s"(lowmask)
+                     : "v250", "v251", "v252", "v253", "v254", "v255", "s84", "s85", "s86", "s87", "s88", "s89");
 }
 
 // The four coupling scalars of cone2_step for the friction slots (S, S+1) of two consecutive contacts, written into
