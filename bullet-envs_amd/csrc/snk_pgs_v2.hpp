@@ -688,17 +688,17 @@ __device__ __forceinline__ void quad_step(float& RJ1, const float RM1, float& RJ
     float t1, t2, d1, d2, d3, d4;
     float a1, a2, a3, a4, s1, s2, s3, s4;
     asm volatile(
+        // (between two DPP steps of the same sum stand the other sum's step and ONE more instruction: the two wait
+        //  states a dependent DPP read needs; the four reads of the accumulated impulses are those instructions)
         "v_mul_f32 %[t1], %[RJ1], %[dv]\n\t"
         "v_mul_f32 %[t2], %[RJ2], %[dv]\n\t"
         "v_readlane_b32 %[a1], %[RJ1], 31\n\t"
-        "v_readlane_b32 %[a2], %[RJ1], 63\n\t"
         SNK_RED2("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1")
-        "v_readlane_b32 %[a3], %[RJ2], 31\n\t"
-        "v_readlane_b32 %[a4], %[RJ2], 63\n\t"
+        "v_readlane_b32 %[a2], %[RJ1], 63\n\t"
         SNK_RED2("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1")
-        "s_nop 0\n\t"
+        "v_readlane_b32 %[a3], %[RJ2], 31\n\t"
         SNK_RED2("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1")
-        "s_nop 0\n\t"
+        "v_readlane_b32 %[a4], %[RJ2], 63\n\t"
         SNK_RED2("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1")
         "s_nop 0\n\t"
         SNK_RED2("row_bcast:15 row_mask:0xa bank_mask:0xf")
@@ -817,10 +817,8 @@ __device__ __forceinline__ void cone_step(float& RJ, const float RM, const float
     "v_readlane_b32 %[l2], %[RJn], 63\n\t" \
     SNK_RED2("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1") \
     "v_mov_b64 v[250:251], s[84:85]\n\t" \
-    "s_nop 0\n\t" \
     SNK_RED2("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1") \
     "v_mov_b64 v[252:253], s[86:87]\n\t" \
-    "s_nop 0\n\t" \
     SNK_RED2("row_bcast:15 row_mask:0xa bank_mask:0xf") \
     "v_readlane_b32 s88, %[t1], 31\n\t" \
     "v_readlane_b32 s89, %[t1], 63\n\t" \
