@@ -193,12 +193,12 @@ struct Lds<N, false> : LdsCommon<N> {
     // The contact rows themselves (J and M^-1 J^T, 2 x 384 x 38 floats = 117 KB) do not fit LDS next
     // to anything else; they live in a per-resident-wave block of global memory that the solve
     // streams once per iteration (see pgs_v1), one 320-byte record [J | M^-1 J^T] per row.
-    static constexpr int kRing = 32;                       // contacts per loop trip of the solve
+    static constexpr int kRing = 32;                       // padding entries behind the ground contacts' impulses (the link-link contacts' live there)
     static constexpr int kResN = 32;                       // contacts whose normal rows stay in registers over the solve
     static constexpr int kRingN = 32;                      // normal rows in flight behind them
     static constexpr int kRingF = 16;                      // friction pairs in flight
     // link-link (self-collision) contacts follow the ground contacts in the compact list: at most kMaxSelf of them,
-    // geometry slots NC .. NC + kMaxSelf - 1; the per-contact scalars cN / cF already have kRing entries of padding
+    // geometry slots NC .. NC + kMaxSelf - 1
     static constexpr int kMaxSelf = kRing;
     static constexpr int NCT = NC + kMaxSelf;              // contact slots in all
     // record order: the NCT normal rows, then the NCT friction pairs (A, B) -- each phase of the solve streams its own
@@ -1056,15 +1056,15 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
     const float TARGV = (mot && DINVV > 0.f) ? L.nc_rhs[nlim + jm] * DENV : 0.f;
     float ACCV = 0.f;                               // accumulated motor impulses, motor j in lane 6+j
     const float EPS = 1e-30f;
-    // Row operands come from global memory, kRing contacts per loop trip, each contact's two (or
-    // four) row vectors requested kRing contacts before they are used (the next trip's loads are
+    // Row operands come from global memory through register rings (kRingN normals / kRingF friction pairs in flight), a
+    // contact's record requested a ring's depth before it is used (the next trip's loads are
     // issued one by one as this trip's slots are consumed).  Lane d < ND reads column d of a row, lanes kSpec and
     // kSpec + 1 the row's scalars (160 contiguous bytes per half row: coalesced); the other lanes sit the solve out.
     // The rows and impulses of the contacts between nc and the end of the last group are zeroed: resolving them
     // changes nothing (dI = 0 exactly).
     constexpr int kRN = LT::kRingN;      // normals in flight
     // contacts are resolved in groups of 8 behind one scalar branch: the rows between nc and the next multiple of 8
-    // are zeroed (inert), a ring trip ends at that multiple instead of running its full kRing steps (round 1 padded
+    // are zeroed (inert), a ring trip ends at that multiple instead of running its full depth (round 1 padded
     // to a whole trip: 144 contacts -- 128 on the ground + 16 link-link -- cost 160)
     const int nc_pad = __builtin_amdgcn_readfirstlane((nc + 7) / 8 * 8);
     {
@@ -1152,7 +1152,7 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
         else { motor_rows(std::false_type{}); limit_rows(false); }
         if (nc > 0) {
             // normals: slot k of the ring holds contact (trip base + k).  A slot is refilled with
-            // the contact kRing further on as soon as it has been consumed -- if there is one: round 1 refilled
+            // the contact kRingN further on as soon as it has been consumed -- if there is one: round 1 refilled
             // unconditionally, and with the usual 128 contacts the last trip of each phase fetched 32 (16) contacts'
             // worth of rows nobody used, 14 % of the stream this kernel is bound by; the contact's
             // accumulated impulse comes from LDS one step ahead.
