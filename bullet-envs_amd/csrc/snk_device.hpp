@@ -1343,16 +1343,35 @@ __device__ void substep_v1(LT& L, const DevModel& M, int lane, float mu, int& it
             f3 eN = mk3(0, 0, 0), eF = mk3(0, 0, 0);
             // contact slots of body b: cylinders 2b-1, 2b (body 0: cylinder 0) = slots 4b-2 .. 4b+1, in
             // contact order
+            if (M.contact_model == 1) {
+                // Bullet's manifolds: up to four points per cylinder, geometry stored by compact index;
+                // cidx[2c], cidx[2c + 1] = first index and count of cylinder c (find_contacts_manifold_v1)
     #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int slot = 4 * b - 2 + j;
-                const int ci = (slot >= 0 && slot < 4 * N) ? L.cidx[slot] : -1;
-                if (ci >= 0) {
-                    const float* geo = rows + LT::kGeoOff + (size_t)slot * LT::kGeo;
-                    f3 F = (mk3(0.f, 0.f, 1.f) * L.acc[ci][0] + ld3(geo + 4) * L.acc[ci][1] +
-                            ld3(geo + 7) * L.acc[ci][2]) * M.inv_dt;
-                    eF = eF + F;
-                    eN = eN + cross(ld3(geo) - ld3(L.o[b]), F);
+                for (int cc = 0; cc < 2; cc++) {
+                    const int c = 2 * b - 1 + cc;
+                    if (c < 0 || c >= 2 * N) continue;
+                    const int first = L.cidx[2 * c], cnt = L.cidx[2 * c + 1];
+                    for (int j = 0; j < cnt; j++) {
+                        const int ci = first + j;
+                        const float* geo = rows + LT::kGeoOff + (size_t)ci * LT::kGeo;
+                        f3 F = (mk3(0.f, 0.f, 1.f) * L.acc[ci][0] + ld3(geo + 4) * L.acc[ci][1] +
+                                ld3(geo + 7) * L.acc[ci][2]) * M.inv_dt;
+                        eF = eF + F;
+                        eN = eN + cross(ld3(geo) - ld3(L.o[b]), F);
+                    }
+                }
+            } else {
+    #pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int slot = 4 * b - 2 + j;
+                    const int ci = (slot >= 0 && slot < 4 * N) ? L.cidx[slot] : -1;
+                    if (ci >= 0) {
+                        const float* geo = rows + LT::kGeoOff + (size_t)slot * LT::kGeo;
+                        f3 F = (mk3(0.f, 0.f, 1.f) * L.acc[ci][0] + ld3(geo + 4) * L.acc[ci][1] +
+                                ld3(geo + 7) * L.acc[ci][2]) * M.inv_dt;
+                        eF = eF + F;
+                        eN = eN + cross(ld3(geo) - ld3(L.o[b]), F);
+                    }
                 }
             }
             // link-link contacts: equal and opposite forces on the two bodies (friction back from the solve's units)

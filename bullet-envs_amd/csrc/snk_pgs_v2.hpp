@@ -377,6 +377,10 @@ __device__ int find_contacts_manifold_v1(LT& L, const DevModel& M, int lane, flo
     if (lane < 2 * N) {
         if (base > LT::NC) base = LT::NC;
         if (base + cnt > LT::NC) cnt = LT::NC - base;
+        // the sensor pass finds a body's contacts through its cylinders: [first compact index, count] of cylinder `lane`
+        // (the slot -> contact table of the stateless model is not used in this one; its array holds these pairs)
+        L.cidx[2 * lane] = base;
+        L.cidx[2 * lane + 1] = cnt;
         f3 dA, dB;
         friction_dirs(M, Rw, dA, dB);
 #pragma unroll
