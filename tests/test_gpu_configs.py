@@ -261,3 +261,41 @@ def test_env_step_parity_random_actions(pkg, oracle_mod, n):
     print("random-action parity n =", n, "90th percentiles GPU-f32", w9, "| oracle-f32", c9)
     assert w9["q"] < max(1e-3, 3 * c9["q"]) and w9["qd"] < max(5e-2, 3 * c9["qd"]) and w9["r"] < max(5e-3, 3 * c9["r"])
     st.close()
+
+
+@pytest.mark.parametrize("over", [dict(n_modules=32), dict(n_modules=32, hull_sides=32, contact_model=1),
+                                  dict(n_modules=16, obstacle=1, obstacle_pos=[0.25, 0.0, 0.1]),
+                                  dict(n_modules=16, obstacle=1, obstacle_pos=[0.25, 0.0, 0.1], hull_sides=32, contact_model=1),
+                                  dict(n_modules=16, hull_sides=32, contact_model=1)])
+def test_outputs_do_not_depend_on_what_ran_before(pkg, over):
+    """Every output of a step -- observation incl. the force sensor, reward, done, substep count, the joint-3 read-out --
+    is a function of state and action only: two handles, one created after kernels of ANOTHER configuration have run on
+    the chip (their leftovers sit in LDS and in the recycled device allocations), give bit-identical results.  (Round 2:
+    the streamed-row constraint pass read an unwritten LDS table under contact_model 1; states matched, sensor and reward
+    differed from run to run.)"""
+    import bench
+    n = over["n_modules"]
+    B, A = 96, n // 2
+    ids = np.arange(B)
+
+    def run():
+        st = pkg.Stepper(B, **over)
+        st.reset()
+        out = []
+        for j in range(4):
+            a = bench.gait_actions(ids, j, A).astype(np.float32)
+            o, r, d, s = st.step(a, vec_mode=False)
+            out += [o.copy(), r.copy(), d.copy(), s.copy()]
+            if over.get("obstacle"):
+                out.append(st.joint3_reaction_fz().copy())
+        st.close()
+        return out
+
+    first = run()
+    other = pkg.Stepper(512, n_modules=48 - n, hull_sides=0, contact_model=0)      # the other chain length: other kernels, other LDS image
+    other.reset()
+    other.step(bench.gait_actions(np.arange(512), 0, (48 - n) // 2).astype(np.float32))
+    other.close()
+    second = run()
+    for x, y in zip(first, second):
+        assert np.array_equal(x, y, equal_nan=True)
