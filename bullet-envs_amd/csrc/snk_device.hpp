@@ -145,6 +145,8 @@ __device__ __forceinline__ float lane_bcast(float x, int src_lane_uniform) {
     "v_add_f32_dpp %[d], %[d], %[d] " MODE "\n\t"            \
     "v_add_f32_dpp %[e], %[e], %[e] " MODE "\n\t"            \
     "v_add_f32_dpp %[f], %[f], %[f] " MODE "\n\t"
+// (seven: operand g as well)
+#define SNK_RED64x7_STEP(MODE) SNK_RED64x6_STEP(MODE) "v_add_f32_dpp %[g], %[g], %[g] " MODE "\n\t"
 
 // ----------------------------------------------------------------------------------
 // LDS image of one environment
@@ -233,7 +235,7 @@ struct Lds<N, false> : LdsCommon<N> {
     static constexpr size_t kYOff = kMmOff + (size_t)(N + 6) * kMO;     // Y_k of every body (build_rows_v1), 6 x kMO floats each
     static constexpr size_t kRowFloats = kYOff + (size_t)(N + 1) * 6 * kMO;
     // accumulated impulses of contact ci: {normal, friction A, friction B, -}
-    alignas(16) float acc[NC + kRing + 1][4];
+    alignas(16) float acc[NC + kRing + 3][4];        // (+ the entries the solve reads ahead of the last pair)
     static_assert(NCT <= NC + kRing, "the impulses of the link-link contacts live in the ring's padding entries");
     int nplane;                  // ground contacts of this substep (the link-link contacts follow them)
 };
@@ -787,6 +789,10 @@ __device__ void build_rows_v1(LT& L, const DevModel& M, int lane, int nc, int& n
         return G;
     };
     const float spec0 = d == LT::kSpec ? 1.0f : 0.f, spec1 = d == LT::kSpec + 1 ? 1.0f : 0.f;    // the records' scalar columns
+    // The solve resolves the normals two at a time (row_step_normal2): the second row's dot is taken from the same
+    // delta-v as the first's and corrected by  c dI_first,  c = (J_2 / den_2) . (M^-1 J_1^T)  -- exactly the sequential
+    // sweep.  c of an odd contact with its predecessor rides in the spare float of its impulse entry.
+    float prevMn = 0.f;                             // M^-1 J^T of the previous contact's normal row (this lane's column)
     auto assemble = [&](int ci, const Geo& G, const f3 YtA, const f3 YfA, const f3 YtB, const f3 YfB, int kA, int kB,
                         auto two_c) {
         constexpr bool TWO = decltype(two_c)::value;       // a pair of bodies (link-link) or one body against the world
@@ -807,7 +813,7 @@ __device__ void build_rows_v1(LT& L, const DevModel& M, int lane, int nc, int& n
             Cj = Cj - Cb;
             Dj = Dj - (cross(YtB, PB - ld3(L.o[kB])) + YfB);
         }
-        float Jr[3], Mr[3], red[6];
+        float Jr[3], Mr[3], red[7];
 #pragma unroll
         for (int kind = 0; kind < 3; kind++) {
             const f3 dir = kind == 0 ? dn : (kind == 1 ? dA : dB);
@@ -817,16 +823,19 @@ __device__ void build_rows_v1(LT& L, const DevModel& M, int lane, int nc, int& n
             Jr[kind] = j; Mr[kind] = m;
             red[kind] = j * m; red[3 + kind] = j * vd;
         }
-        // six sums over the wave, their DPP steps interleaved (each instruction is the others' wait state)
+        red[6] = Jr[0] * prevMn;                                        // the normals' coupling with the previous contact
+        // seven sums over the wave, their DPP steps interleaved (each instruction is the others' wait state)
         asm volatile(
             "s_nop 1\n\t"      // the operands may have been written by the instructions just before (VALU write -> DPP read)
-            SNK_RED64x6_STEP("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1")
-            SNK_RED64x6_STEP("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1")
-            SNK_RED64x6_STEP("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1")
-            SNK_RED64x6_STEP("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1")
-            SNK_RED64x6_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")
-            SNK_RED64x6_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
-            : [a] "+v"(red[0]), [b] "+v"(red[1]), [c] "+v"(red[2]), [d] "+v"(red[3]), [e] "+v"(red[4]), [f] "+v"(red[5]));
+            SNK_RED64x7_STEP("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1")
+            SNK_RED64x7_STEP("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1")
+            SNK_RED64x7_STEP("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+            SNK_RED64x7_STEP("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+            SNK_RED64x7_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")
+            SNK_RED64x7_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
+            : [a] "+v"(red[0]), [b] "+v"(red[1]), [c] "+v"(red[2]), [d] "+v"(red[3]), [e] "+v"(red[4]), [f] "+v"(red[5]),
+              [g] "+v"(red[6]));
+        float cpl = 0.f;
         float Jo[3], Mo[3];
 #pragma unroll
         for (int kind = 0; kind < 3; kind++) {
@@ -843,12 +852,14 @@ __device__ void build_rows_v1(LT& L, const DevModel& M, int lane, int nc, int& n
             // (J and M^-1 J^T are zero in the pad columns as they come)
             Jo[kind] = dinv * (Jr[kind] - spec0 * target);
             Mo[kind] = Mr[kind] + spec1 * dn_;
+            if (kind == 0) cpl = (ci & 1) ? dinv * lane_bcast(red[6], 63) : 0.f;
         }
+        prevMn = Mo[0];
         if (colv) {
             *reinterpret_cast<float2*>(rows + (size_t)ci * LT::kRS + 2 * d) = make_float2(Jo[0], Mo[0]);
             *reinterpret_cast<float4*>(rows + (size_t)(LT::kFric + 2 * ci) * LT::kRS + 4 * d) = make_float4(Jo[1], Jo[2], Mo[1], Mo[2]);
         }
-        if (lane == 0) *reinterpret_cast<float4*>(L.acc[ci]) = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (lane == 0) *reinterpret_cast<float4*>(L.acc[ci]) = make_float4(0.f, 0.f, 0.f, cpl);
     };
     // ---- (c) ground contacts, in the order of their bodies: Y stays in registers
     const int nplane = L.nplane;
@@ -986,6 +997,48 @@ __device__ __forceinline__ float row_step_normal(float jv, float mv, float acc, 
         : [t] "=&v"(t), [x] "=&v"(x), [P] "=&v"(P), [s] "=&s"(s), [dv] "+v"(dv), [lsq] "+v"(lsq)
         : [jv] "v"(jv), [mv] "v"(mv), [acc] "v"(acc), [SL] "n"(SUM_LANE));
     return x;
+}
+
+// Two consecutive contact normals: both dots from the same delta-v, their reductions interleaved (one s_nop per stage
+// instead of two per stage and row), the second row's sum corrected by  c dI_first  (c: see build_rows_v1).  28 VALU,
+// 36 issue slots for the two rows against 2 x 30.
+template <int SUM_LANE>
+__device__ __forceinline__ void row_step_normal2(float jA, float mA, float jB, float mB, float& accA, float& accB, float c,
+                                                 float& dv, float& lsq) {
+    float tA, tB, xA, xB, dA, sA, sB;
+    asm volatile(
+        "v_mul_f32 %[tA], %[jA], %[dv]\n\t"
+        "v_mul_f32 %[tB], %[jB], %[dv]\n\t"
+        "s_nop 0\n\t"
+        SNK_RED64x2_STEP("%[tA]", "%[tB]", "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1")
+        SNK_RED64x2_STEP("%[tA]", "%[tB]", "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1")
+        SNK_RED64x2_STEP("%[tA]", "%[tB]", "row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+        SNK_RED64x2_STEP("%[tA]", "%[tB]", "row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+        SNK_RED64x2_STEP("%[tA]", "%[tB]", "row_bcast:15 row_mask:0xa bank_mask:0xf")
+        "v_add_f32_dpp %[tA], %[tA], %[tA] row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "v_add_f32_dpp %[tB], %[tB], %[tB] row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_readlane_b32 %[sA], %[tA], %[SL]\n\t"
+        "v_readlane_b32 %[sB], %[tB], %[SL]\n\t"
+        "s_nop 0\n\t"
+        "v_subrev_f32 %[xA], %[sA], %[accA]\n\t"
+        "v_subrev_f32 %[xB], %[sB], %[accB]\n\t"
+        "v_max_f32 %[xA], 0, %[xA]\n\t"
+        "v_sub_f32 %[dA], %[xA], %[accA]\n\t"
+        "v_fma_f32 %[xB], -%[c], %[dA], %[xB]\n\t"
+        "v_max_f32 %[xB], 0, %[xB]\n\t"
+        "v_mul_f32 %[tA], %[dA], %[mA]\n\t"
+        "v_sub_f32 %[dA], %[xB], %[accB]\n\t"
+        "v_add_f32 %[dv], %[dv], %[tA]\n\t"
+        "v_mul_f32 %[tB], %[dA], %[mB]\n\t"
+        "v_add_f32 %[dv], %[dv], %[tB]\n\t"
+        "v_max3_f32 %[lsq], %[lsq], |%[tA]|, |%[tB]|\n\t"
+        : [tA] "=&v"(tA), [tB] "=&v"(tB), [xA] "=&v"(xA), [xB] "=&v"(xB), [dA] "=&v"(dA), [sA] "=&s"(sA), [sB] "=&s"(sB),
+          [dv] "+v"(dv), [lsq] "+v"(lsq)
+        : [jA] "v"(jA), [mA] "v"(mA), [jB] "v"(jB), [mB] "v"(mB), [accA] "v"(accA), [accB] "v"(accB), [c] "v"(c),
+          [SL] "n"(SUM_LANE));
+    accA = xA;
+    accB = xB;
 }
 
 // Bullet's cone-friction pair of one contact: both dots from the same delta-v, the new pair (a - s) projected
@@ -1159,27 +1212,39 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
             float jr[kRN], mr[kRN];
 #pragma unroll
             for (int k = 0; k < kRN; k++) ldN((unsigned)(kResN + k) * kRecB, jr[k], mr[k]);
-            float an = L.acc[0][0];
+            // two contacts per step (row_step_normal2): {impulse of the even one, impulse and coupling of the odd one} come
+            // from LDS one step ahead
+            float a0n = L.acc[0][0];
+            float2 a1n = make_float2(L.acc[1][0], L.acc[1][3]);
 #pragma unroll
-            for (int k = 0; k < kResN; k++) {                                   // the resident rows
+            for (int k = 0; k < kResN; k += 2) {                                // the resident rows
                 if ((k & 7) == 0 && k > 0 && k >= nc_pad) break;                // wave-uniform
-                const float a = an;
-                an = L.acc[k + 1][0];
-                L.acc[k][0] = row_step_normal<LT::kMO - 1>(RNJ[k], RNM[k], a, dv, lsq);
+                float a0 = a0n, a1 = a1n.x;
+                const float c1 = a1n.y;
+                a0n = L.acc[k + 2][0];
+                a1n = make_float2(L.acc[k + 3][0], L.acc[k + 3][3]);
+                row_step_normal2<LT::kMO - 1>(RNJ[k], RNM[k], RNJ[k + 1], RNM[k + 1], a0, a1, c1, dv, lsq);
+                L.acc[k][0] = a0;
+                L.acc[k + 1][0] = a1;
             }
             unsigned rb = 0;           // record the current group of eight refills counts from (wave-uniform)
             for (int base = kResN; base < nc_pad; base += kRN) {
 #pragma unroll
-                for (int k = 0; k < kRN; k++) {
+                for (int k = 0; k < kRN; k += 2) {
                     if ((k & 7) == 0 && k > 0 && base + k >= nc_pad) break;      // wave-uniform
-                    const float a = an;
-                    an = L.acc[base + k + 1][0];
-                    L.acc[base + k][0] = row_step_normal<LT::kMO - 1>(jr[k], mr[k], a, dv, lsq);
-                    // the refill: the contact kRN further on if there is one, else this trip's contact once more
+                    float a0 = a0n, a1 = a1n.x;
+                    const float c1 = a1n.y;
+                    a0n = L.acc[base + k + 2][0];
+                    a1n = make_float2(L.acc[base + k + 3][0], L.acc[base + k + 3][3]);
+                    row_step_normal2<LT::kMO - 1>(jr[k], mr[k], jr[k + 1], mr[k + 1], a0, a1, c1, dv, lsq);
+                    L.acc[base + k][0] = a0;
+                    L.acc[base + k + 1][0] = a1;
+                    // the refill: the contacts kRN further on if there are any, else this trip's once more
                     // (a cache hit instead of a fetch of rows nobody uses; no branch, the load is issued either way).
-                    // Issued after the step: the register pair is free then and takes the new record as it is
+                    // Issued after the step: the register pairs are free then and take the new records as they are
                     if ((k & 7) == 0) rb = (unsigned)((base + kRN + k < nc_pad) ? base + kRN : base) * kRecB;
                     ldN(rb + (unsigned)k * kRecB, jr[k], mr[k]);
+                    ldN(rb + (unsigned)(k + 1) * kRecB, jr[k + 1], mr[k + 1]);
                 }
             }
             if (cone) {
