@@ -1042,7 +1042,7 @@ __device__ __forceinline__ void row_step_normal2(float jA, float mA, float jB, f
 }
 
 // Bullet's cone-friction pair of one contact: both dots from the same delta-v, the new pair (a - s) projected
-// radially onto the disc of radius lim.  30 VALU.
+// radially onto the disc of radius lim.  31 VALU.
 template <int SUM_LANE>
 __device__ __forceinline__ void row_step_cone(float jA, float mA, float jB, float mB, float& accA, float& accB, float lim,
                                               float EPS, float& dv, float& lsq) {
@@ -1074,9 +1074,10 @@ __device__ __forceinline__ void row_step_cone(float jA, float mA, float jB, floa
         "v_sub_f32 %[tA], %[xA], %[accA]\n\t"
         "v_sub_f32 %[tB], %[xB], %[accB]\n\t"
         "v_mul_f32 %[P], %[tA], %[mA]\n\t"
-        "v_fmac_f32 %[P], %[tB], %[mB]\n\t"
+        "v_mul_f32 %[r2], %[tB], %[mB]\n\t"
         "v_add_f32 %[dv], %[dv], %[P]\n\t"
-        "v_max_f32_e64 %[lsq], %[lsq], |%[P]|\n\t"
+        "v_add_f32 %[dv], %[dv], %[r2]\n\t"
+        "v_max3_f32 %[lsq], %[lsq], |%[P]|, |%[r2]|\n\t"        // the two rows' residuals separately (their sum could cancel)
         : [tA] "=&v"(tA), [tB] "=&v"(tB), [xA] "=&v"(xA), [xB] "=&v"(xB), [r2] "=&v"(r2), [P] "=&v"(P), [sA] "=&s"(sA),
           [sB] "=&s"(sB), [dv] "+v"(dv), [lsq] "+v"(lsq)
         : [jA] "v"(jA), [mA] "v"(mA), [jB] "v"(jB), [mB] "v"(mB), [accA] "v"(accA), [accB] "v"(accB), [lim] "v"(lim),
