@@ -14,7 +14,7 @@ names = ["contacts", "bias + ABA (factor, solve)", "sensor pass 1, v += a dt", "
 NL = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 if NL == 32:
     names = ["ground contacts", "link-link contacts (GJK)", "bias + ABA (factor, solve)", "sensor pass 1, v += a dt",
-             "rows: ABA delta sweeps, lane = row", "PGS, 50 iterations", "sensor pass 2", "integrate", "FK of the new pose"]
+             "rows: M^-1 columns (38 delta sweeps) + assembly, lane = dof", "PGS, 50 iterations", "sensor pass 2", "integrate", "FK of the new pose"]
 for B in (1024, 2048):
     st = pkg.Stepper(B, n_modules=NL, residual_threshold=0.0)
     st.reset()
