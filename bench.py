@@ -87,7 +87,7 @@ def env_friction(global_ids, seed):
     return 0.5 + (h >> np.uint64(11)).astype(np.float64) / float(1 << 53)
 
 
-def cpu_baseline(steps=2000, warmup=20, n_links=16, friction_seed=None, hull_sides=0, contact_model=0):
+def cpu_baseline(steps=2000, warmup=20, n_links=16, friction_seed=None, hull_sides=32, contact_model=1):
     """BASELINE.md row B3 / SURVEY 8(d): the float64 C++ oracle on the configs[0] action stream, timed from C++
     (oracle/snake_oracle.cpp: orc_bench_gait -- no Python in the timed loop), 1 thread and all cores, `steps`
     env-steps after `warmup` warm-up steps each.  PyBullet itself is probed at run time and reported, never
@@ -150,10 +150,14 @@ def main():
     ap.add_argument("--friction-seed", type=int, default=None,
                     help="BASELINE configs[4]: per-env ground friction mu_e ~ U[0.5, 1.5), counter-based generator with "
                          "this seed (the config says seed 1), keyed by the global env index")
-    ap.add_argument("--hull-sides", type=int, default=0,
-                    help="not a BASELINE config: 32 = cylinders as the 32-gon hulls PyBullet imports (DESIGN.md 3)")
-    ap.add_argument("--contact-model", type=int, default=0, choices=(0, 1),
-                    help="not a BASELINE config: 1 = Bullet's persistent <= 4-point contact manifold (DESIGN.md 3)")
+    ap.add_argument("--hull-sides", type=int, default=32,
+                    help="32 (default) = cylinders as the 32-gon hulls PyBullet imports; 0 = implicit cylinders, the "
+                         "round-1 model (DESIGN.md 3)")
+    ap.add_argument("--contact-model", type=int, default=1, choices=(0, 1),
+                    help="1 (default) = Bullet's persistent <= 4-point contact manifold; 0 = the stateless two-point "
+                         "manifold of round 1 (DESIGN.md 3)")
+    ap.add_argument("--warm-start", type=int, default=0, choices=(0, 1),
+                    help="1 = warm-started normal rows (off in Bullet's multibody solver, hence off by default)")
     ap.add_argument("--self-collision", type=int, default=1, choices=(0, 1),
                     help="link-link contacts (the reference's URDF_USE_SELF_COLLISION load flag, snake.py:93): evaluated by "
                          "the 32-link kernels; 0 switches them off (round-1 state of configs[3])")
@@ -162,7 +166,7 @@ def main():
     ap.add_argument("--streamed-rows", action="store_true",
                     help="diagnostic: 16 links on the streamed-row solve (the obstacle kernels, the box parked 50 m away)")
     ap.add_argument("--no-variants", action="store_true",
-                    help="skip the extra measurement of Bullet's own contact model (1 GPU, default configuration only)")
+                    help="skip the extra measurement of the round-1 contact model (1 GPU, default configuration only)")
     ap.add_argument("--policy", action="store_true",
                     help="not the BASELINE metric: actions sampled from an on-device 2x256 actor-critic "
                          "(bullet-envs_amd/rollout.py, SURVEY 8(f)-1) instead of the precomputed gait; 1 GPU")
@@ -204,6 +208,8 @@ def main():
             dist.init_process_group(backend)
 
     extra = dict(obstacle=1, obstacle_pos=[50.0, 0.0, 0.1]) if args.streamed_rows else {}
+    if args.warm_start:
+        extra["warm_start"] = 1
     local = pkg.DeviceVecEnv(E, device_index=local_rank, n_modules=NL, hull_sides=args.hull_sides,
                              contact_model=args.contact_model, self_collision=args.self_collision, **extra)
     if args.friction_seed is not None:      # configs[4]: this rank's shard of the per-env plane friction
@@ -282,12 +288,14 @@ def main():
     elapsed = float(t_el.item())
     substeps = float(subs.item())
 
-    # Not the headline: the same K steps under Bullet's own contact handling (32-gon hulls + persistent manifold,
-    # DESIGN.md 3), after and outside the timed region of the headline, so that the record shows what that model costs.
+    overflow = local.stepper.contact_overflow()      # contacts the solve had no room for: must be zeros
+    # Not the headline: the same K steps under the round-1 contact model (stateless two-point manifold on implicit
+    # cylinders), after and outside the timed region of the headline, so that the record stays comparable
+    # with the earlier rounds' numbers.
     variants = None
-    if (world == 1 and not args.no_variants and not args.policy and NL == 16 and not args.hull_sides
-            and not args.contact_model and args.friction_seed is None):
-        v_env = pkg.DeviceVecEnv(E, device_index=local_rank, n_modules=NL, hull_sides=32, contact_model=1)
+    if (world == 1 and not args.no_variants and not args.policy and NL == 16 and args.hull_sides == 32
+            and args.contact_model == 1 and not args.warm_start and args.friction_seed is None):
+        v_env = pkg.DeviceVecEnv(E, device_index=local_rank, n_modules=NL, hull_sides=0, contact_model=0)
         v_env.reset()
         v_sub = torch.zeros((), dtype=torch.int64, device=dev)
         for j in range(W):
@@ -299,11 +307,12 @@ def main():
             v_sub.add_(v_env.substeps.sum())
         torch.cuda.synchronize()
         tv = time.perf_counter() - tv
-        variants = {"bullet_contact_model": {
-            "value": E * K / tv, "unit": "env-steps/s", "hull_sides": 32, "contact_model": 1,
+        variants = {"round1_contact_model": {
+            "value": E * K / tv, "unit": "env-steps/s", "hull_sides": 0, "contact_model": 0,
             "mean_substeps_per_env_step": float(v_sub.item()) / (E * K),
-            "note": "same action stream; PyBullet's 32-gon hull import + Bullet's persistent <= 4-point manifold instead "
-                    "of the default stateless manifold on implicit cylinders (DESIGN.md 3)"}}
+            "note": "same action stream; the stateless two-point manifold on implicit cylinders that rounds 1 and 2 "
+                    "measured, instead of PyBullet's 32-gon hull import + Bullet's persistent <= 4-point manifold at "
+                    "the dispatcher's relative breaking threshold (the default since round 3, DESIGN.md 3)"}}
         v_env.close()
 
     if rank == 0:
@@ -319,14 +328,14 @@ def main():
         # rocprofv3 summaries of THIS configuration (profiles/README.md), replayed here -- they are measured in
         # separate --pmc runs of the same command, not in this run; the key names say so.
         cfg_key = ("c%d" % NL) + ("_fric" if args.friction_seed is not None else "") + ("_policy" if args.policy else "") + (
-            "_hull%d_cm%d" % (args.hull_sides, args.contact_model) if (args.hull_sides or args.contact_model) else "") + (
+            "_hull%d_cm%d" % (args.hull_sides, args.contact_model) if (args.hull_sides != 32 or args.contact_model != 1) else "") + (
+            "_warm" if args.warm_start else "") + (
             "_nosc" if (NL == 32 and not args.self_collision) else "") + ("_streamed" if args.streamed_rows else "")
         traffic, traffic_src, valu = None, None, None
         try:
             import glob
-            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_pmc_summary.json" % cfg_key)))
-            if not cands and cfg_key == "c16":
-                cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r01_v*_pmc_summary.json")))
+            # (round 3 changed the default contact model: summaries of earlier rounds describe other kernels)
+            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[3-9]_%s_pmc_summary.json" % cfg_key)))
             if cands:
                 with open(cands[-1]) as f:
                     pm = json.load(f)
@@ -366,6 +375,9 @@ def main():
                                                          if args.policy else "serpenoid gait actions", cfg_index)),
                 "envs_per_gpu": E, "n_links": NL, "friction_seed": args.friction_seed,
                 "hull_sides": args.hull_sides, "contact_model": args.contact_model,
+                "relative_breaking_threshold": int(local.params.relative_breaking_threshold),
+                "warm_start": int(local.params.warm_start),
+                "contact_overflow": {"substeps": overflow[0], "points": overflow[1], "link_link_or_obstacle": overflow[2]},
                 "self_collision": args.self_collision if NL == 32 else "flag on, inert and not evaluated for 16 links",
                 "world_size": (dist.get_world_size() if dist is not None else 1),
                 "backend": (dist.get_backend() if dist is not None else None),

@@ -29,8 +29,9 @@ class SnkParams(C.Structure):
         ("limit_erp", C.c_double), ("limit_max_impulse", C.c_double),
         ("mu_link", C.c_double), ("aniso", C.c_double * 3),
         ("contact_erp", C.c_double), ("linear_slop", C.c_double),
-        ("breaking_threshold", C.c_double), ("cone_friction", C.c_int32),
+        ("breaking_threshold", C.c_double), ("relative_breaking_threshold", C.c_int32), ("cone_friction", C.c_int32),
         ("n_iterations", C.c_int32), ("residual_threshold", C.c_double),
+        ("warm_start", C.c_int32), ("warmstarting_factor", C.c_double),
         ("scaling_factor", C.c_double), ("gait", C.c_int32),
         ("servo_tol", C.c_double), ("max_counter", C.c_int32),
         ("height_threshold", C.c_double), ("energy_dt", C.c_double),
@@ -66,6 +67,7 @@ SYMBOLS = {
     "snk_manifold_floats": (C.c_int32, [_vp]),
     "snk_get_manifold": (C.c_int, [_vp, _F]),
     "snk_set_manifold": (C.c_int, [_vp, _F]),
+    "snk_contact_overflow": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     "snk_get_obs": (C.c_int, [_vp, _F]),
     "snk_mean_height": (C.c_int, [_vp, _F]),
     "snk_link_positions": (C.c_int, [_vp, _F]),
@@ -214,17 +216,24 @@ class Stepper:
               "snk_set_state")
 
     def get_manifold(self):
-        """contact_model 1: [n_envs, 2n, 25] contact cache (see snk.h); None for a contact_model 0 handle."""
+        """contact_model 1: [n_envs, 2n, 29] contact cache (see snk.h); None for a contact_model 0 handle."""
         if self.lib.snk_manifold_floats(self.h) == 0:
             return None
-        m = np.zeros((self.n_envs, 2 * self.n, 25), dtype=np.float32)
+        m = np.zeros((self.n_envs, 2 * self.n, 29), dtype=np.float32)
         check(self.lib.snk_get_manifold(self.h, fptr(m)), "snk_get_manifold")
         return m
 
     def set_manifold(self, m):
         m = np.ascontiguousarray(m, dtype=np.float32)
-        assert m.shape == (self.n_envs, 2 * self.n, 25)
+        assert m.shape == (self.n_envs, 2 * self.n, 29)
         check(self.lib.snk_set_manifold(self.h, fptr(m)), "snk_set_manifold")
+
+    def contact_overflow(self):
+        """(substeps with more ground-contact points than slots, points left without rows, link-link / obstacle contacts
+        left out) since the handle was created -- snk_contact_overflow; all zero means Bullet's 'no limit' held."""
+        out = (C.c_uint64 * 3)()
+        check(self.lib.snk_contact_overflow(self.h, out), "snk_contact_overflow")
+        return int(out[0]), int(out[1]), int(out[2])
 
     def get_obs(self):
         o = np.zeros((self.n_envs, self.obs_dim), dtype=np.float32)

@@ -10,16 +10,20 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsnk.so")
-SOURCES = ["snk_api.hip", "snk_device.hpp", "snk_pgs_v2.hpp", "snk_model.hpp"]
 HEADER = os.path.join(os.path.dirname(HERE), "include", "snk.h")
+
+
+def sources():
+    """Every file under csrc/ is a dependency of the one translation unit (snk_api.hip includes the rest): a stale
+    libsnk.so after an edit of ANY of them would travel to the GPU box unnoticed (it is git-ignored, not gpurun-ignored)."""
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp", ".h")))
 
 
 def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [HEADER]
-    return any(os.path.getmtime(d) > t for d in deps)
+    return any(os.path.getmtime(d) > t for d in sources() + [HEADER, os.path.abspath(__file__)])
 
 
 def build(force=False, verbose=False, defines=(), out=None):

@@ -53,6 +53,7 @@ struct snk_handle {
     float* d_linkpos = nullptr;   // allocated on first snk_link_positions
     float* d_mf = nullptr;        // contact_model 1: the persistent contact manifolds, [n_envs][2n][kMfFloats]
     float* d_rows = nullptr;      // 32-link chains: constraint rows streamed from global memory (snk_device.hpp: pgs_v1)
+    unsigned long long* d_ovf = nullptr;   // contacts the solves had no room for (snk_contact_overflow): 3 counters
     int32_t* d_order = nullptr;
     bool plan = true;
     // in-launch scheduler of env_step_sched_kernel (snk_device.hpp): rings, counters, the host-mapped alarm word
@@ -76,20 +77,20 @@ int launch_step(snk_handle* h, float* act, float* obs, float* rew, uint8_t* done
         hipLaunchKernelGGL((snk::plan_sched_kernel<N>), dim3(1), dim3(1024), 0, st, h->d_model, h->d_recs, act, h->sched,
                            h->n_envs);
         hipLaunchKernelGGL((snk::env_step_sched_kernel<N, V2>), dim3(h->grid_waves), dim3(64), h->lds_bytes, st, h->model_slot,
-                           h->d_recs, h->d_mu, act, obs, rew, done, sub, vec_mode, h->n_envs, h->sched, h->d_rows, h->d_mf);
+                           h->d_recs, h->d_mu, act, obs, rew, done, sub, vec_mode, h->n_envs, h->sched, h->d_rows, h->d_mf, h->d_ovf);
         return 0;
     }
     if (h->plan)
         hipLaunchKernelGGL((snk::plan_kernel<N>), dim3(1), dim3(1024), 0, st, h->d_model, h->d_recs, act, h->d_order,
                            h->n_envs);
     hipLaunchKernelGGL((snk::env_step_kernel<N, V2>), dim3(h->n_envs), dim3(64), h->lds_bytes, st, h->d_model, h->d_recs,
-                       h->d_mu, act, obs, rew, done, sub, vec_mode, h->n_envs, h->plan ? h->d_order : nullptr, h->d_rows, h->d_mf);
+                       h->d_mu, act, obs, rew, done, sub, vec_mode, h->n_envs, h->plan ? h->d_order : nullptr, h->d_rows, h->d_mf, h->d_ovf);
     return 0;
 }
 template <int N, bool V2>
 int launch_substep(snk_handle* h, const float* tgt, int k, int32_t* info, hipStream_t st) {
     hipLaunchKernelGGL((snk::substep_kernel<N, V2>), dim3(h->n_envs), dim3(64), h->lds_bytes, st, h->d_model, h->d_recs,
-                       h->d_mu, tgt, k, info, h->n_envs, h->d_rows, h->d_mf);
+                       h->d_mu, tgt, k, info, h->n_envs, h->d_rows, h->d_mf, h->d_ovf);
     return 0;
 }
 template <int N, bool V2>
@@ -184,8 +185,8 @@ void snk_default_params(snk_params* p) {
     p->inertia_from_file = 0;
     p->default_mass = 1.0;
     p->collision_margin = 0.001;
-    p->hull_sides = 0;
-    p->contact_model = 0;
+    p->hull_sides = 32;         // PyBullet's import of a URDF <cylinder> [U]; snake.py:93 passes no URDF_USE_IMPLICIT_CYLINDER
+    p->contact_model = 1;       // Bullet's persistent manifold [U] (0 + hull_sides 0: the round-1 model)
     p->self_collision = 1;      // the reference loads the snake with URDF_USE_SELF_COLLISION (snake.py:93)
     p->obstacle = 0;            // snake.py:94 has add_obstacle commented out; snake_gait_test.py:51 loads it
     p->obstacle_pos[0] = 2.0; p->obstacle_pos[1] = 0.0; p->obstacle_pos[2] = 0.1;
@@ -209,9 +210,12 @@ void snk_default_params(snk_params* p) {
     p->contact_erp = 0.08;
     p->linear_slop = 1e-5;
     p->breaking_threshold = 0.02;
+    p->relative_breaking_threshold = 1;     // btCollisionDispatcher's default flags [U]
     p->cone_friction = 1;
     p->n_iterations = 50;
     p->residual_threshold = 1e-7;
+    p->warm_start = 0;          // disabled in btMultiBodyConstraintSolver [U]
+    p->warmstarting_factor = 0.85;
     p->scaling_factor = 3.14159265358979323846 / 6.0;
     p->gait = 1;
     p->servo_tol = 0.05;
@@ -264,6 +268,8 @@ int init_handle(snk_handle* h, const snk_params* p, int32_t n_envs, int32_t devi
         HIP_TRY(hipMalloc(&h->d_rows, bytes));
         HIP_TRY(hipMemset(h->d_rows, 0, bytes));     // the last three rows of every block stay zero for good
     }
+    HIP_TRY(hipMalloc(&h->d_ovf, 3 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(h->d_ovf, 0, 3 * sizeof(unsigned long long)));
     if (p->contact_model == 1) {
         const size_t bytes = ne * 2 * h->n * snk::kMfFloats * sizeof(float);
         HIP_TRY(hipMalloc(&h->d_mf, bytes));
@@ -318,8 +324,13 @@ int snk_create(const snk_params* p, int32_t n_envs, int32_t device, snk_handle**
     if (n_envs <= 0) return fail("snk_create: n_envs must be positive");
     if (n_envs >= (1 << 24)) return fail("snk_create: n_envs must be below 2^24 (the step queue packs the env index into 24 bits)");
     if (p->n_modules != 16 && p->n_modules != 32) return fail("snk_create: n_modules must be 16 or 32");
-    if (p->hull_sides < 0 || p->hull_sides > 32) return fail("snk_create: hull_sides must be 0 (implicit cylinder) .. 32");
+    if (p->hull_sides != 0 && (p->hull_sides < 3 || p->hull_sides > 32))
+        return fail("snk_create: hull_sides must be 0 (implicit cylinder) or 3 .. 32");
     if (p->contact_model != 0 && p->contact_model != 1) return fail("snk_create: contact_model must be 0 or 1");
+    if (p->warm_start != 0 && p->warm_start != 1) return fail("snk_create: warm_start must be 0 or 1");
+    if (p->warm_start && p->contact_model != 1)
+        return fail("snk_create: warm_start needs contact_model 1 (the impulses live in the persistent contact cache)");
+    if (!(p->breaking_threshold > 0.0)) return fail("snk_create: breaking_threshold must be positive");
     if (p->term_index < 0 || p->term_index >= 3 * p->n_modules + 8) return fail("snk_create: term_index out of range");
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
@@ -341,7 +352,7 @@ int snk_destroy(snk_handle* h) {
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
     void* bufs[] = {h->d_model, h->d_recs, h->d_mu, h->d_act, h->d_obs, h->d_rew, h->d_done,
-                    h->d_sub, h->d_mask, h->d_tgt, h->d_info, h->d_h, h->d_order, h->d_rows, h->d_linkpos, h->d_mf,
+                    h->d_sub, h->d_mask, h->d_tgt, h->d_info, h->d_h, h->d_order, h->d_rows, h->d_linkpos, h->d_mf, h->d_ovf,
                     h->sched.head, h->sched.tail, h->sched.ent, h->sched.waiting, h->sched.counter, h->sched.finished};
     for (void* b : bufs) (void)hipFree(b);
     if (h->h_alarm) (void)hipHostFree(h->h_alarm);
@@ -496,10 +507,11 @@ int snk_set_state(snk_handle* h, const float* state, const float* aux) {
     return 0;
 }
 
-int32_t snk_manifold_floats(const snk_handle* h) { return h->d_mf ? 2 * h->n * 25 : 0; }
+int32_t snk_manifold_floats(const snk_handle* h) { return (h && h->d_mf) ? 2 * h->n * 29 : 0; }
 
 // host layout per cylinder (same as the oracle's): [count, 4 x (point on the link in link coordinates 3, point on the
-// ground 3)] = 25 floats; device layout: [count, 3 pad, 4 x 6] = kMfFloats
+// ground 3, applied normal impulse)] = 29 floats; device layout: [count, 3 pad, 4 x (a3, b.x, b.y, lambda)] = kMfFloats
+// (the ground point's z is the plane's, 0)
 int snk_get_manifold(snk_handle* h, float* out) {
     if (!h || !out) return fail("snk_get_manifold: null argument");
     if (!h->d_mf) return fail("snk_get_manifold: this handle has contact_model 0 (no contact cache)");
@@ -509,8 +521,18 @@ int snk_get_manifold(snk_handle* h, float* out) {
     std::vector<float> dev(ncyl * snk::kMfFloats);
     HIP_TRY(hipMemcpy(dev.data(), h->d_mf, dev.size() * sizeof(float), hipMemcpyDeviceToHost));
     for (size_t c = 0; c < ncyl; c++) {
-        out[25 * c] = dev[snk::kMfFloats * c];
-        memcpy(out + 25 * c + 1, &dev[snk::kMfFloats * c + 4], 24 * sizeof(float));
+        const float* d = &dev[snk::kMfFloats * c];
+        float* o = out + 29 * c;
+        const int n = d[0] < 0.f ? 0 : (d[0] > 4.f ? 4 : (int)d[0]);
+        o[0] = (float)n;
+        for (int j = 0; j < 4; j++) {
+            const bool on = j < n;       // slots past the count hold stale points: reported as zeros
+            for (int r = 0; r < 3; r++) o[1 + 7 * j + r] = on ? d[4 + 6 * j + r] : 0.f;
+            o[4 + 7 * j] = on ? d[7 + 6 * j] : 0.f;
+            o[5 + 7 * j] = on ? d[8 + 6 * j] : 0.f;
+            o[6 + 7 * j] = 0.f;
+            o[7 + 7 * j] = on ? d[9 + 6 * j] : 0.f;
+        }
     }
     return 0;
 }
@@ -522,10 +544,27 @@ int snk_set_manifold(snk_handle* h, const float* in) {
     const size_t ncyl = (size_t)h->n_envs * 2 * h->n;
     std::vector<float> dev(ncyl * snk::kMfFloats, 0.f);
     for (size_t c = 0; c < ncyl; c++) {
-        dev[snk::kMfFloats * c] = in[25 * c];
-        memcpy(&dev[snk::kMfFloats * c + 4], in + 25 * c + 1, 24 * sizeof(float));
+        float* d = &dev[snk::kMfFloats * c];
+        const float* o = in + 29 * c;
+        d[0] = o[0];
+        for (int j = 0; j < 4; j++) {
+            for (int r = 0; r < 3; r++) d[4 + 6 * j + r] = o[1 + 7 * j + r];
+            d[7 + 6 * j] = o[4 + 7 * j];
+            d[8 + 6 * j] = o[5 + 7 * j];
+            d[9 + 6 * j] = o[7 + 7 * j];
+        }
     }
     HIP_TRY(hipMemcpy(h->d_mf, dev.data(), dev.size() * sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int snk_contact_overflow(snk_handle* h, uint64_t* out) {
+    if (!h || !out) return fail("snk_contact_overflow: null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipDeviceSynchronize());
+    unsigned long long v[3];
+    HIP_TRY(hipMemcpy(v, h->d_ovf, sizeof(v), hipMemcpyDeviceToHost));
+    for (int i = 0; i < 3; i++) out[i] = (uint64_t)v[i];
     return 0;
 }
 

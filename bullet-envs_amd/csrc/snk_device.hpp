@@ -151,7 +151,7 @@ __device__ __forceinline__ float lane_bcast(float x, int src_lane_uniform) {
 // ----------------------------------------------------------------------------------
 // LDS image of one environment
 // ----------------------------------------------------------------------------------
-template <int N>
+template <int N, int NL>
 struct LdsCommon {
     static constexpr int kN = N;
     static constexpr int NB = N + 1;     // composite bodies
@@ -163,15 +163,15 @@ struct LdsCommon {
     float rec[REC];
     // per body, world axes
     float R[NB][9], o[NB][3], r[NB][3], ax[NB][3], cw[NB][3];
-    float w[NB][3], v[NB][3], zeta[NB][6], p[NB][6], ext[NB][6];
+    float w[NB][3], v[NB][3], zeta[NB][6], p[NB][6];
     float IA[NB][21];            // articulated inertia: A(6 sym) B(9) C(6 sym)
     float Ua[NB][3], Ub[NB][3], Dinv[NB], u[NB];
     float Inv0[36];
     float qd_old[N], tauj[N], qdd[N], targets[N];
     float acc0[6];
-    // non-contact rows kept in LDS: in v1 limits + motors, in v2 only the (rare) limit rows
-    int nc_joint[2 * N];
-    float nc_sign[2 * N], nc_rhs[2 * N], nc_dinv[2 * N], nc_den[2 * N], nc_lo[2 * N], nc_hi[2 * N], nc_app[2 * N];
+    // non-contact rows kept in LDS (NL of them): in v1 limits + motors (2 N), in v2 only the (rare) limit rows (N)
+    int nc_joint[NL];
+    float nc_sign[NL], nc_rhs[NL], nc_dinv[NL], nc_den[NL], nc_lo[NL], nc_hi[NL], nc_app[NL];
 
     __device__ __forceinline__ float* base() { return rec; }
     __device__ __forceinline__ float* q() { return rec + 13; }
@@ -187,9 +187,11 @@ struct Lds;
 
 // v1: every constraint row staged in LDS (any chain length; used for the 32-link config)
 template <int N>
-struct Lds<N, false> : LdsCommon<N> {
+struct Lds<N, false> : LdsCommon<N, 2 * N> {
     static constexpr bool kV2 = false;
     static constexpr int NC = 4 * N, NR = 12 * N, ND = N + 6;
+    float ext_[LdsCommon<N, 2 * N>::NB][6];      // link forces of the constraint pass
+    __device__ __forceinline__ float* ext(int b) { return ext_[b]; }
     int clist[NC];               // compact contact index -> slot
     int cidx[NC];                // slot -> compact contact index (-1: not in contact)
     // The contact rows themselves (J and M^-1 J^T, 2 x 384 x 38 floats = 117 KB) do not fit LDS next
@@ -242,18 +244,33 @@ struct Lds<N, false> : LdsCommon<N> {
 
 // v2: rows live in VGPRs during the solve; LDS only stages one 64-row batch while they are built
 template <int N>
-struct Lds<N, true> : LdsCommon<N> {
+struct Lds<N, true> : LdsCommon<N, N> {
     static constexpr bool kV2 = true;
     static constexpr int NC = 4 * N, ND = N + 6;
     static_assert(N + 6 + 3 <= 32, "v2 packs two rows per 64-lane register");
     float Mm[N][ND];             // M^-1 e_j for the motor / limit rows
-    float ccP[NC][3], ccdist[NC], ccdir[NC][2][3];        // indexed by COMPACT contact index
-    int ccbody[NC];
+    static constexpr int kObs = 8;                        // room for contacts with the obstacle box (behind the ground's)
+    float ccP[NC][3], ccdist[NC];                         // indexed by COMPACT contact index
+    unsigned char ccbody[NC], ccds[NC];                   // ... the contact's body; its entry of cdir
+    // friction directions A, B: one entry per CYLINDER (all ground contacts of a cylinder share them), then one per
+    // obstacle contact, whose normals are obn (a ground contact's is +z)
+    float cdir[2 * N + kObs][2][3], obn[kObs][3];
     float stM[64][25];           // staging of one 64-row batch: M^-1 J^T [22], rhs, den, 1/den
+    // link forces of the constraint pass: columns 8..13 of the staging rows, which that pass uses in columns 0..5 only
+    __device__ __forceinline__ float* ext(int b) { return &stM[b][8]; }
     float MmS[N][4];             // the motors' rhs, den, 1/den, target velocity change (their M^-1 rows are Mm)
     float fz_park;               // first-pass part of the joint-0 force, parked across the solve
-    int cylbase[2 * N], cyln[2 * N];   // contacts of cylinder c: compact indices [cylbase[c], + cyln[c])
+    // contacts of cylinder c: compact indices [cylbase[c], + cyln[c]); cylkeep[c]: which of its cached manifold points
+    // they are (bit j = point j has rows; contact_model 1)
+    unsigned char cylbase[2 * N], cyln[2 * N], cylkeep[2 * N];
     float app[2 * (N / 2 + NC / 2 + NC)];   // accumulated impulses by (register slot, half)
+    // contact_model 1: the environment's persistent contact manifolds stay HERE while a wave holds the environment
+    // (read and updated every substep, lane = cylinder); they travel to and from global memory with the state record
+    // only -- at the start and the end of an env-step and at a hand-off between waves.  Component-major, so that lane
+    // = cylinder strides by one word: per cached point j the floats [6 j .. 6 j + 5] = point on the link in link
+    // coordinates (3), point on the ground x, y (its z is the plane's: 0), the normal impulse of the last substep
+    float mfl[24][2 * N];
+    unsigned char mfn[2 * N];    // cached points of cylinder c
 };
 
 __device__ __forceinline__ void lds_sync() { __syncthreads(); }
@@ -416,8 +433,8 @@ __device__ void body_bias(LT& L, const DevModel& M, int lane) {
             IA[12] = -hy; IA[13] = hx; IA[14] = 0.f;
             IA[15] = m; IA[16] = 0.f; IA[17] = 0.f; IA[18] = m; IA[19] = 0.f; IA[20] = m;
         } else {
-            pN = pN - ld3(&L.ext[b][0]);
-            pF = pF - ld3(&L.ext[b][3]);
+            pN = pN - ld3(L.ext(b));
+            pF = pF - ld3(L.ext(b) + 3);
         }
         st3(&L.p[b][0], pN);
         st3(&L.p[b][3], pF);
@@ -432,20 +449,19 @@ __device__ void body_bias(LT& L, const DevModel& M, int lane) {
 // ----------------------------------------------------------------------------------
 // defined in snk_pgs_v2.hpp (shared by both solves)
 __device__ __forceinline__ void rim_point(const DevModel& M, f3 dl, float& lx, float& ly);
-struct MPt;
-constexpr int kMfFloats = 28;      // per cylinder: [count, 3 pad, 4 x (a3, b3)]
-__device__ __forceinline__ int manifold_update(const DevModel& M, float* __restrict__ mfc, const float* Rw, f3 centre, f3 dl,
-                                               MPt (&p)[4], f3 (&wa)[4]);
+constexpr int kMfFloats = 28;      // per cylinder: [count, 3 pad, 4 x (a3, b.x, b.y, lambda)]
 __device__ __forceinline__ int lane_prefix3(int cnt, int lane, int& total);
 __device__ __forceinline__ void friction_dirs(const DevModel& M, const float* Rw, f3& dA, f3& dB);
 __device__ __forceinline__ void cyl_world_rot(const float* Rb, const float* Rc, float* Rw);
 template <class LT>
-__device__ int find_contacts_manifold_v1(LT& L, const DevModel& M, int lane, float* __restrict__ rows, float* __restrict__ mf);
+__device__ int find_contacts_manifold_v1(LT& L, const DevModel& M, int lane, float* __restrict__ rows, float* __restrict__ mf,
+                                         unsigned long long* __restrict__ ovf);
 
 template <class LT>
-__device__ int find_contacts_v1(LT& L, const DevModel& M, int lane, float* __restrict__ rows, float* __restrict__ mf) {
+__device__ int find_contacts_v1(LT& L, const DevModel& M, int lane, float* __restrict__ rows, float* __restrict__ mf,
+                                unsigned long long* __restrict__ ovf) {
     constexpr int N = LT::kN;
-    if (M.contact_model == 1) return find_contacts_manifold_v1(L, M, lane, rows, mf);
+    if (M.contact_model == 1) return find_contacts_manifold_v1(L, M, lane, rows, mf, ovf);
     int total = 0;
     for (int base = 0; base < 4 * N; base += 64) {
         const int slot = base + lane;
@@ -479,7 +495,7 @@ __device__ int find_contacts_v1(LT& L, const DevModel& M, int lane, float* __res
             st3(geo + 7, mulRv(Rw, mk3(l2.x * a.x, l2.y * a.y, l2.z * a.z)));
             st3(geo + 10, mk3(0.f, 0.f, 1.f));
             st3(geo + 13, mk3(0.f, 0.f, 0.f));
-            geo[16] = (float)b; geo[17] = -1.0f; geo[18] = 1.0f;
+            geo[16] = (float)b; geo[17] = -1.0f; geo[18] = 1.0f; geo[19] = 0.f;
         }
         unsigned long long bal = __ballot(active);
         if (slot < 4 * N) L.cidx[slot] = -1;
@@ -800,7 +816,7 @@ __device__ void build_rows_v1(LT& L, const DevModel& M, int lane, int nc, int& n
         const float dist = G.g[0].w;
         const f3 dA = mk3(G.g[1].x, G.g[1].y, G.g[1].z), dB = mk3(G.g[1].w, G.g[2].x, G.g[2].y);
         const f3 dn = mk3(G.g[2].z, G.g[2].w, G.g[3].x), PB = mk3(G.g[3].y, G.g[3].z, G.g[3].w);
-        const float fsc = G.g[4].z;
+        const float fsc = G.g[4].z, lam0 = G.g[4].w;     // lam0: where the normal row starts (warm starting; else 0)
         // J[d] = A_d . ((P - O_d) x dir) + B_d . dir = dir . (A_d x (P - O_d) + B_d), and likewise
         // M^-1 J^T [d] = Yt . ((P - o_k) x dir) + Yf . dir = dir . (Yt x (P - o_k) + Yf): one vector per contact and
         // lane for each, a dot product per row
@@ -859,7 +875,7 @@ __device__ void build_rows_v1(LT& L, const DevModel& M, int lane, int nc, int& n
             *reinterpret_cast<float2*>(rows + (size_t)ci * LT::kRS + 2 * d) = make_float2(Jo[0], Mo[0]);
             *reinterpret_cast<float4*>(rows + (size_t)(LT::kFric + 2 * ci) * LT::kRS + 4 * d) = make_float4(Jo[1], Jo[2], Mo[1], Mo[2]);
         }
-        if (lane == 0) *reinterpret_cast<float4*>(L.acc[ci]) = make_float4(0.f, 0.f, 0.f, cpl);
+        if (lane == 0) *reinterpret_cast<float4*>(L.acc[ci]) = make_float4(lam0, 0.f, 0.f, cpl);
     };
     // ---- (c) ground contacts, in the order of their bodies: Y stays in registers
     const int nplane = L.nplane;
@@ -1168,6 +1184,19 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
     float RNJ[kResN], RNM[kResN];
 #pragma unroll
     for (int k = 0; k < kResN; k++) ldN((unsigned)k * kRecB, RNJ[k], RNM[k]);
+    if (__builtin_amdgcn_readfirstlane(M.warm_start)) {
+        // warm starting: the normal rows start at the impulses build_rows_v1 took from the contact cache, delta-v at the
+        // sum of M^-1 J^T of those (the scalar columns' part of that sum is dropped again: lane kSpec stays 1, and
+        // lane kSpec + 1 is only ever read through lsq)
+        for (int ci = 0; ci < nc; ci++) {
+            const float a = L.acc[ci][0];
+            if (__builtin_amdgcn_readfirstlane(a != 0.f ? 1 : 0)) {
+                float jj, mm;
+                ldN((unsigned)ci * kRecB, jj, mm);
+                dv += (lane < ND) ? a * mm : 0.f;
+            }
+        }
+    }
     for (; it < n_iter; it++) {
         float lsq = 0.f;       // per lane max |M^-1 J^T dI| of the contact rows: lane kSpec + 1 holds max |dI * den|
         float lsq_nc = 0.f;    // max |dI * den| of the limit and motor rows
@@ -1342,7 +1371,7 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
 // ----------------------------------------------------------------------------------
 template <class LT>
 __device__ void substep_v1(LT& L, const DevModel& M, int lane, float mu, int& iters, int& ncontacts, float* __restrict__ rows,
-                           const SensorHint& hint, float* __restrict__ mf) {
+                           const SensorHint& hint, float* __restrict__ mf, unsigned long long* __restrict__ ovf) {
     constexpr int N = LT::kN;
     constexpr int ND = N + 6;
     const float dt = M.dt;
@@ -1351,12 +1380,12 @@ __device__ void substep_v1(LT& L, const DevModel& M, int lane, float mu, int& it
 #endif
     SNK_STAMP(0)
     // (1) contacts of the current pose, (2) bias forces with gravity, joint damping torque
-    int nc = find_contacts_v1(L, M, lane, rows, mf);
+    int nc = find_contacts_v1(L, M, lane, rows, mf, ovf);
     SNK_STAMP(1)
     if (lane == 0) L.nplane = nc;
     const int nplane = nc;
     if (M.self_collision || M.obstacle)
-        nc += find_self_contacts_v1(L, M, lane, mu, rows);   // link-link and obstacle contacts follow the ground's
+        nc += find_self_contacts_v1(L, M, lane, mu, rows, ovf);   // link-link and obstacle contacts follow the ground's
     ncontacts = nc;
     __threadfence();      // contact geometry: written lane = slot, read lane = row
     lds_sync();
@@ -1400,6 +1429,18 @@ __device__ void substep_v1(LT& L, const DevModel& M, int lane, float mu, int& it
     SNK_STAMP(5)
     float dv = pgs_v1(L, M, lane, nc, nn, mu, iters, rows);
     SNK_STAMP(6)
+    if (M.contact_model == 1 && lane < 2 * N) {
+        // the normal impulses go back into the contact cache (btManifoldPoint::m_appliedImpulse [U]), write-through
+        // like the cache itself
+        int idx = L.cidx[2 * lane];
+        const int mask = L.cidx[2 * lane + 1] >> 8;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if ((mask >> j) & 1) {
+                const float a = L.acc[idx++][0];
+                asm volatile("global_store_dword %0, %1, off sc1" : : "v"(mf + (size_t)lane * kMfFloats + 9 + 6 * j), "v"(a) : "memory");
+            }
+    }
     // only when this substep can be the last of its env-step (sensor_pass_needed)
     if (sensor_pass_needed(L, M, lane, dv, hint)) {
         // (6) constraint pass for the joint-0 sensor [U]: ABA at the velocities after (3) with the
@@ -1416,7 +1457,7 @@ __device__ void substep_v1(LT& L, const DevModel& M, int lane, float mu, int& it
                 for (int cc = 0; cc < 2; cc++) {
                     const int c = 2 * b - 1 + cc;
                     if (c < 0 || c >= 2 * N) continue;
-                    const int first = L.cidx[2 * c], cnt = L.cidx[2 * c + 1];
+                    const int first = L.cidx[2 * c], cnt = L.cidx[2 * c + 1] & 0xff;
                     for (int j = 0; j < cnt; j++) {
                         const int ci = first + j;
                         const float* geo = rows + LT::kGeoOff + (size_t)ci * LT::kGeo;
@@ -1451,8 +1492,8 @@ __device__ void substep_v1(LT& L, const DevModel& M, int lane, float mu, int& it
                 if (kA == b) { eF = eF + F; eN = eN + cross(ld3(geo) - ld3(L.o[b]), F); }
                 if (kB2 == b) { eF = eF - F; eN = eN - cross(ld3(geo + 13) - ld3(L.o[b]), F); }
             }
-            st3(&L.ext[b][0], eN);
-            st3(&L.ext[b][3], eF);
+            st3(L.ext(b), eN);
+            st3(L.ext(b) + 3, eF);
         }
         if (lane < N) L.tauj[lane] = -M.joint_damp * L.qd_old[lane];
         lds_sync();
@@ -1543,7 +1584,8 @@ namespace snk {
 
 template <class LT>
 __device__ __forceinline__ void substep(LT& L, const DevModel& M0, int lane_in, float mu, int& iters, int& ncontacts,
-                                        const SensorHint& hint, float* __restrict__ rows, float* __restrict__ mf) {
+                                        const SensorHint& hint, float* __restrict__ rows, float* __restrict__ mf,
+                                        unsigned long long* __restrict__ ovf) {
     int lane = lane_in;
     // Launder the model pointer once per substep: otherwise ~100 per-lane model constants are
     // hoisted out of the substep loop and stay live (or spilled) across the whole solve.
@@ -1553,8 +1595,8 @@ __device__ __forceinline__ void substep(LT& L, const DevModel& M0, int lane_in, 
     // ... and the lane id: hundreds of per-lane LDS addresses are loop-invariant and would
     // otherwise be computed in the kernel prologue and spilled.
     asm volatile("" : "+v"(lane));
-    if constexpr (LT::kV2) substep_v2(L, M, lane, mu, iters, ncontacts, hint, mf);
-    else substep_v1(L, M, lane, mu, iters, ncontacts, rows, hint, mf);
+    if constexpr (LT::kV2) substep_v2(L, M, lane, mu, iters, ncontacts, hint, ovf);
+    else substep_v1(L, M, lane, mu, iters, ncontacts, rows, hint, mf, ovf);
 }
 
 // ----------------------------------------------------------------------------------
@@ -1587,6 +1629,37 @@ __device__ __forceinline__ void store_rec_through(LT& L, float* __restrict__ rec
         asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(rec + 4 * lane), "v"(v) : "memory");
     }
 }
+// The register-resident kernels keep an environment's contact manifolds (contact_model 1) in LDS while a wave holds
+// it (Lds<N, true>::mfl); these move them from / to the environment's block of global memory
+// ([2n][kMfFloats] = per cylinder [count, 3 pad, 4 x (a3, b.x, b.y, lambda)]) together with the state record.
+template <class LT>
+__device__ __forceinline__ void load_mf(LT& L, const float* __restrict__ mf, int lane) {
+    if constexpr (LT::kV2) {
+        if (mf) {
+            for (int i = lane; i < 2 * LT::kN * kMfFloats; i += 64) {
+                const int c = i / kMfFloats, f = i - c * kMfFloats;
+                const float v = mf[i];
+                if (f == 0) L.mfn[c] = (unsigned char)(v < 0.f ? 0.f : (v > 4.f ? 4.f : v));
+                else if (f >= 4) L.mfl[f - 4][c] = v;
+            }
+            lds_sync();
+        }
+    }
+}
+template <class LT, bool THROUGH>
+__device__ __forceinline__ void store_mf(LT& L, float* __restrict__ mf, int lane) {
+    if constexpr (LT::kV2) {
+        if (mf) {
+            lds_sync();
+            for (int i = lane; i < 2 * LT::kN * kMfFloats; i += 64) {
+                const int c = i / kMfFloats, f = i - c * kMfFloats;
+                const float v = f == 0 ? (float)L.mfn[c] : (f >= 4 ? L.mfl[f - 4][c] : 0.f);
+                if (THROUGH) asm volatile("global_store_dword %0, %1, off sc1" : : "v"(mf + i), "v"(v) : "memory");
+                else mf[i] = v;
+            }
+        }
+    }
+}
 template <class LT>
 __device__ __forceinline__ void write_obs(LT& L, float* __restrict__ obs, int lane) {
     constexpr int N = LT::kN;
@@ -1616,7 +1689,7 @@ __global__ __launch_bounds__(64, 2) void env_step_kernel(const DevModel* __restr
                                                       float* __restrict__ rew, uint8_t* __restrict__ done,
                                                       int32_t* __restrict__ substeps, int vec_mode, int n_envs,
                                                       const int32_t* __restrict__ order, float* __restrict__ rows_all,
-                                                      float* __restrict__ mf_all) {
+                                                      float* __restrict__ mf_all, unsigned long long* __restrict__ ovf) {
     extern __shared__ float4 smem_raw[];
     using LT = Lds<N, V2>;
     LT& L = *reinterpret_cast<LT*>(smem_raw);
@@ -1647,6 +1720,7 @@ __global__ __launch_bounds__(64, 2) void env_step_kernel(const DevModel* __restr
     float* env_rows = nullptr;      // constraint rows of chains too long for the register-resident solve
     if constexpr (!LT::kV2) env_rows = rows_all + (size_t)env * LT::kRowFloats;
     float* env_mf = mf_all ? mf_all + (size_t)env * (2 * N * kMfFloats) : nullptr;   // contact cache (contact_model 1)
+    load_mf(L, env_mf, lane);
     fk_vel(L, M, lane);
     // Snake.step servo loop (snake.py:283-304)
     int counter = 0;
@@ -1660,7 +1734,7 @@ __global__ __launch_bounds__(64, 2) void env_step_kernel(const DevModel* __restr
         float nrm = sqrtf(wave_sum<64>(e * e));
         if (!(nrm > M.servo_tol)) break;
         hint.counter_next = counter + 1;
-        substep(L, M, lane, mu, it_dummy, nc_dummy, hint, env_rows, env_mf);
+        substep(L, M, lane, mu, it_dummy, nc_dummy, hint, env_rows, env_mf, ovf);
         counter++;
         hint.h_prev = mean_height(L, M, lane);
         if (hint.h_prev > M.height_thr) { end_height = true; break; }
@@ -1693,6 +1767,7 @@ __global__ __launch_bounds__(64, 2) void env_step_kernel(const DevModel* __restr
         if (substeps) substeps[env] = counter;
     }
     store_rec(L, recs + (size_t)env * LT::REC, lane);
+    store_mf<LT, false>(L, env_mf, lane);
 }
 
 template <int N, bool V2>
@@ -1700,7 +1775,7 @@ __global__ __launch_bounds__(64, 2) void substep_kernel(const DevModel* __restri
                                                      const float* __restrict__ mu_plane,
                                                      const float* __restrict__ targets, int k,
                                                      int32_t* __restrict__ info, int n_envs, float* __restrict__ rows_all,
-                                                     float* __restrict__ mf_all) {
+                                                     float* __restrict__ mf_all, unsigned long long* __restrict__ ovf) {
     extern __shared__ float4 smem_raw[];
     using LT = Lds<N, V2>;
     LT& L = *reinterpret_cast<LT*>(smem_raw);
@@ -1719,9 +1794,11 @@ __global__ __launch_bounds__(64, 2) void substep_kernel(const DevModel* __restri
     float* env_rows = nullptr;
     if constexpr (!LT::kV2) env_rows = rows_all + (size_t)env * LT::kRowFloats;
     float* env_mf = mf_all ? mf_all + (size_t)env * (2 * N * kMfFloats) : nullptr;
-    for (int s = 0; s < k; s++) substep(L, M, lane, mu, iters, nc, hint, env_rows, env_mf);
+    load_mf(L, env_mf, lane);
+    for (int s = 0; s < k; s++) substep(L, M, lane, mu, iters, nc, hint, env_rows, env_mf, ovf);
     if (info && lane == 0) { info[2 * env] = iters; info[2 * env + 1] = nc; }
     store_rec(L, recs + (size_t)env * LT::REC, lane);
+    store_mf<LT, false>(L, env_mf, lane);
 }
 
 template <int N, bool V2>
@@ -2037,7 +2114,7 @@ __global__ __launch_bounds__(64, 2) void env_step_sched_kernel(int model_slot, f
                                                             float* __restrict__ rew, uint8_t* __restrict__ done,
                                                             int32_t* __restrict__ substeps, int vec_mode, int n_envs,
                                                             Sched sc, float* __restrict__ rows_all,
-                                                            float* __restrict__ mf_all) {
+                                                            float* __restrict__ mf_all, unsigned long long* __restrict__ ovf) {
     extern __shared__ float4 smem_raw[];
     using LT = Lds<N, V2>;
     LT& L = *reinterpret_cast<LT*>(smem_raw);
@@ -2096,6 +2173,7 @@ __global__ __launch_bounds__(64, 2) void env_step_sched_kernel(int model_slot, f
         lds_sync();
         const float mu = fminf(M.mu_link * mu_plane[env], 10.0f);
         float* env_mf = mf_all ? mf_all + (size_t)env * (2 * N * kMfFloats) : nullptr;   // contact cache (contact_model 1)
+        load_mf(L, env_mf, lane);
         fk_vel(L, M, lane);
         // Snake.step servo loop (snake.py:283-304), `quantum` substeps at a time
         bool end_height = false, complete = false;
@@ -2116,6 +2194,7 @@ __global__ __launch_bounds__(64, 2) void env_step_sched_kernel(int model_slot, f
 #endif
                 if (top > remaining) {
                     store_rec_through(L, rec, lane);
+                    store_mf<LT, true>(L, env_mf, lane);        // the contact cache travels with the record
                     __hip_atomic_store(&sc.counter[env], counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     sched_push(sc, lane, env, remaining);
                     break;
@@ -2123,7 +2202,7 @@ __global__ __launch_bounds__(64, 2) void env_step_sched_kernel(int model_slot, f
                 in_slice = 0;
             }
             hint.counter_next = counter + 1;
-            substep(L, M, lane, mu, it_dummy, nc_dummy, hint, env_rows, env_mf);
+            substep(L, M, lane, mu, it_dummy, nc_dummy, hint, env_rows, env_mf, ovf);
 #ifdef SNK_SCHED_DEBUG
             n_sub++;
 #endif
@@ -2161,6 +2240,7 @@ __global__ __launch_bounds__(64, 2) void env_step_sched_kernel(int model_slot, f
             if (substeps) substeps[env] = counter;
         }
         store_rec(L, rec, lane);
+        store_mf<LT, false>(L, env_mf, lane);
         atomicAdd(sc.finished, lane == 0 ? 1 : 0);
     }
 }

@@ -56,6 +56,8 @@ struct DevModel {
     // r (sin, cos)(2 pi s / hull_sides), the importer's vertex order; contact_model 1 = persistent manifold;
     // cyl_zoff = cylinder centre in its link's frame (snake.urdf:807,863), the manifold keeps link coordinates
     int hull_sides, contact_model, self_collision;
+    int warm_start;                      // snk_params::warm_start; warm_factor = warmstarting_factor
+    float warm_factor;
     int obstacle;                        // a static box on the ground (snake/block.urdf), contacts through the streamed-row solve
     float obs_c[3], obs_h[3], mu_obs;    // its centre, half extents, lateral friction
     float cyl_zoff;
@@ -218,7 +220,18 @@ inline void build_dev_model(const snk_params& P, const HostModel& H, DevModel& D
     D.mu_link = (float)P.mu_link;
     for (int i = 0; i < 3; i++) D.aniso[i] = (float)P.aniso[i];
     D.contact_erp = (float)P.contact_erp; D.slop = (float)P.linear_slop;
-    D.break_thr = (float)P.breaking_threshold; D.margin = (float)P.collision_margin;
+    D.margin = (float)P.collision_margin;
+    {
+        // [U] btCollisionDispatcher::getNewManifold with CD_USE_RELATIVE_CONTACT_BREAKING_THRESHOLD (the dispatcher's
+        // default): gContactBreakingThreshold x the smaller shape's angular-motion disc = |centre| + bounding-sphere
+        // radius of its AABB.  A link collider is a compound with the cylinder's hull (margin included) 0.0183 m from
+        // the link's inertial frame (snake.urdf:807,813,863,869); the plane's and the box's discs are larger.
+        const double ax = 0.026 + P.collision_margin, az = 0.033 / 2 + P.collision_margin;
+        const double disc = 0.0183 + std::sqrt(ax * ax + ax * ax + az * az);
+        D.break_thr = (float)(P.relative_breaking_threshold ? P.breaking_threshold * disc : P.breaking_threshold);
+    }
+    D.warm_start = (P.warm_start && P.contact_model == 1) ? 1 : 0;
+    D.warm_factor = (float)P.warmstarting_factor;
     D.cyl_r = 0.026f; D.cyl_hl = 0.0165f;                               // snake.urdf:809
     D.hull_sides = P.hull_sides; D.contact_model = P.contact_model;
     D.self_collision = (P.self_collision && n == 32) ? 1 : 0;    // only the streamed-row solve builds link-link rows

@@ -51,6 +51,15 @@ namespace snk {
 // overwrite the motor-torque outputs of the substep (tools/profile_phases.py reads them).
 // (SNK_STAMP: snk_device.hpp)
 
+// slot map (two rows per slot) and the layout of the accumulated impulses handed back in L.app
+constexpr int kSlotNormal = 0;    // 32 slots: contacts 2s (lower half), 2s+1 (upper half)
+constexpr int kSlotFric = 32;     // 64 slots: contact s, direction A lower / B upper
+constexpr int kSlots = 96;
+constexpr int kAppMotor = 0;      // app[j]                motor j
+constexpr int kAppNormal = 16;    // app[16 + ci]          normal of contact ci
+constexpr int kAppFric = 80;      // app[80 + 2 ci + {0,1}] friction A / B of contact ci
+constexpr unsigned long long kLowMask = 0x00000000FFFFFFFFull;
+
 struct swap2 {
     float a, b;
 };
@@ -85,7 +94,7 @@ __device__ __forceinline__ float rdlane(float x, int l) {
 //      one new support point per step merged into a cache of <= 4 points that lives in global memory
 //      (manifold_update below); every cached point gets rows.
 // Both leave the same description behind: contact ci = 0..nc-1 in (cylinder, point) order with L.ccP / ccdist /
-// ccbody / ccdir, and per cylinder the range [L.cylbase[c], + L.cyln[c]) of its contacts (the sensor pass sums a
+// ccbody / ccds -> cdir, and per cylinder the range [L.cylbase[c], + L.cyln[c]) of its contacts (the sensor pass sums a
 // body's contact forces over the ranges of its cylinders).  At most 4 N contacts get rows (the register-resident
 // solve has that many slots): further manifold points are left out, in manifold order.
 // ------------------------------------------------------------------------------------
@@ -122,12 +131,24 @@ __device__ __forceinline__ void friction_dirs(const DevModel& M, const float* Rw
 }
 
 // One cached manifold point: the point on the link in the LINK's coordinates (cylinder frame + cyl_zoff along z),
-// the point on the ground in world coordinates, the refreshed distance.
+// the point on the ground in world coordinates (z = 0: the plane's), the refreshed distance, and the normal impulse
+// the point carried in the last substep (btManifoldPoint::m_appliedImpulse [U]; warm starting reads it).
 struct MPt {
     f3 a, b;
-    float d;
+    float d, lam;
 };
 typedef float mf_v4 __attribute__((ext_vector_type(4)));
+// dst = c ? src : dst, field by field.  (A conditional struct assignment inside an unrolled `if (j == where)` chain gets
+// its stores merged into ONE store at a computed address, which puts the whole point cache into scratch memory: ~100
+// scratch round trips per substep, measured in the ISA of round 3's first build.)
+__device__ __forceinline__ void mpt_sel(MPt& dst, const MPt& src, bool c) {
+    dst.a.x = c ? src.a.x : dst.a.x; dst.a.y = c ? src.a.y : dst.a.y; dst.a.z = c ? src.a.z : dst.a.z;
+    dst.b.x = c ? src.b.x : dst.b.x; dst.b.y = c ? src.b.y : dst.b.y; dst.b.z = c ? src.b.z : dst.b.z;
+    dst.d = c ? src.d : dst.d; dst.lam = c ? src.lam : dst.lam;
+}
+__device__ __forceinline__ void f3_sel(f3& dst, f3 src, bool c) {
+    dst.x = c ? src.x : dst.x; dst.y = c ? src.y : dst.y; dst.z = c ? src.z : dst.z;
+}
 
 // btPersistentManifold::sortCachedPoints with gContactCalcArea3Points [U]: which cached point the new one replaces
 __device__ __forceinline__ int manifold_sort_cached(const MPt (&p)[4], const MPt& np) {
@@ -150,13 +171,125 @@ __device__ __forceinline__ int manifold_sort_cached(const MPt (&p)[4], const MPt
     return best;
 }
 
-// The manifold of this lane's cylinder, updated for the current pose (see the oracle's find_contacts_manifold for the
-// Bullet calls restated).  mfc -> the cylinder's kMfFloats floats in global memory, read and written write-through
-// (sc1): an env-step moves between waves at substep boundaries, and the bytes must be where the next wave's loads
-// look (same rule as the state record, store_rec_through).  Returns the number of cached points; their world
-// positions on the link and distances in wa / p[].d.
-__device__ __forceinline__ int manifold_update(const DevModel& M, float* __restrict__ mfc, const float* Rw, f3 centre, f3 dl,
-                                               MPt (&p)[4], f3 (&wa)[4]) {
+// The manifold of this lane's cylinder (n cached points p[0 .. n-1], registers), updated for the current pose -- see
+// the oracle's find_contacts_manifold for the Bullet calls restated: a link's collider is a btCompoundShape, so
+// btCompoundCollisionAlgorithm first REFRESHES the child's manifold from the new pose (positions, distances, and the
+// removal of points that lifted off or drifted: refreshContactPoints), then the child's convex-plane algorithm adds
+// this step's support point (getCacheEntry / replaceContactPoint / addManifoldPoint with sortCachedPoints, which sees
+// the refreshed distances) [U].  Returns the new number of cached points; their world positions on the link and
+// distances in wa / p[].d.  Everything is a select (mpt_sel): the cache stays in registers.
+__device__ __forceinline__ int manifold_core(const DevModel& M, int n, MPt (&p)[4], const float* Rw, f3 centre, f3 dl,
+                                             f3 (&wa)[4]) {
+    n = n < 0 ? 0 : (n > 4 ? 4 : n);
+    const float thr = M.break_thr;
+    const f3 zoff = mk3(0.f, 0.f, M.cyl_zoff);
+    // refresh from the current pose, then drop what lifted off or drifted (last to first, the last one moves in)
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        wa[j] = centre + mulRv(Rw, p[j].a - zoff);
+        p[j].d = wa[j].z - p[j].b.z;
+    }
+#pragma unroll
+    for (int j = 3; j >= 0; j--) {
+        bool drop = !(p[j].d <= thr);
+        {
+            const float dx = p[j].b.x - wa[j].x, dy = p[j].b.y - wa[j].y, dz = p[j].b.z - (wa[j].z - p[j].d);
+            drop = drop || (dx * dx + dy * dy + dz * dz > thr * thr);
+        }
+        drop = drop && j < n;
+        const int last = n - 1;
+        MPt pl = p[0];
+        f3 wl = wa[0];
+#pragma unroll
+        for (int k = 1; k < 4; k++) { mpt_sel(pl, p[k], k == last); f3_sel(wl, wa[k], k == last); }
+        mpt_sel(p[j], pl, drop && j != last);
+        f3_sel(wa[j], wl, drop && j != last);
+        n = drop ? n - 1 : n;
+    }
+    // the new point: support vertex towards the plane (+ margin along that direction)
+    f3 sv;
+    if (M.hull_sides > 0) {
+        float best = -3.0e38f;
+        sv = mk3(0.f, 0.f, 0.f);
+        for (int k = 0; k < 2 * M.hull_sides; k++) {      // the importer's order: (+z, -z) of vertex 0, 1, ...
+            const f3 c = mk3(M.hull_xy[k >> 1][0], M.hull_xy[k >> 1][1], (k & 1) ? -M.cyl_hl : M.cyl_hl);
+            const float val = dot(dl, c);
+            if (val > best) { best = val; sv = c; }
+        }
+    } else {                                              // btCylinderShapeZ's support function [U]
+        const float rr = sqrtf(dl.x * dl.x + dl.y * dl.y);
+        sv = rr != 0.f ? mk3(M.cyl_r * dl.x / rr, M.cyl_r * dl.y / rr, 0.f) : mk3(M.cyl_r, 0.f, 0.f);
+        sv.z = dl.z < 0.f ? -M.cyl_hl : M.cyl_hl;
+    }
+    MPt np;
+    const f3 loc = sv + dl * M.margin;                    // in the cylinder's own (centred) frame
+    np.a = loc + zoff;
+    const f3 wnew = centre + mulRv(Rw, loc);
+    np.d = wnew.z;
+    np.b = mk3(wnew.x, wnew.y, 0.f);
+    np.lam = 0.f;
+    {
+        const bool add = np.d < thr;
+        int nearest = -1;
+        float shortest = thr * thr;
+        float lam_near = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const f3 d = p[j].a - np.a;
+            const float dd = dot(d, d);
+            const bool nr = j < n && dd < shortest;
+            shortest = nr ? dd : shortest; nearest = nr ? j : nearest; lam_near = nr ? p[j].lam : lam_near;
+        }
+        const int evict = manifold_sort_cached(p, np);
+        // replaceContactPoint keeps the cached point's applied impulse; a point that is added, or that evicts another
+        // one (addManifoldPoint -> sortCachedPoints), starts at zero [U]
+        np.lam = nearest >= 0 ? lam_near : 0.f;
+        const int where = nearest >= 0 ? nearest : (n < 4 ? n : evict);
+        n = (add && nearest < 0 && n < 4) ? n + 1 : n;
+#pragma unroll
+        for (int j = 0; j < 4; j++) { mpt_sel(p[j], np, add && j == where); f3_sel(wa[j], wnew, add && j == where); }
+    }
+    return n;
+}
+
+// Which of a cylinder's n cached points get rows when the environment holds more points than the solve has slots for
+// (`room` of them; Bullet has no such limit, snk_contact_overflow counts how often this build's is hit): every
+// cylinder's deepest point first, in cylinder order, then every cylinder's second deepest, ... until the slots are
+// used up (ties: manifold order).  Lane = cylinder; returns the lane's bit mask of kept points (the oracle's
+// max_contacts mirrors the rule for the tests).
+__device__ __forceinline__ int manifold_keep_mask(int n, const MPt (&p)[4], int lane, int total, int room) {
+    if (total <= room) return (1 << n) - 1;
+    int rank[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        int r = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (j < n && (p[j].d < p[i].d || (p[j].d == p[i].d && j < i))) r++;
+        rank[i] = r;
+    }
+    int granted = 0;                       // passes in which this cylinder got a slot (monotone: once refused, refused)
+    int left = room;
+#pragma unroll
+    for (int pass = 0; pass < 4; pass++) {
+        const unsigned long long el = __ballot(n > pass);
+        const int before = __popcll(el & ((1ull << lane) - 1ull));
+        if (n > pass && before < left) granted = pass + 1;
+        left -= __popcll(el);
+        left = left < 0 ? 0 : left;
+    }
+    int mask = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        if (i < n && rank[i] < granted) mask |= 1 << i;
+    return mask;
+}
+
+// The streamed-row kernels keep the manifolds in global memory: mfc -> the cylinder's kMfFloats floats
+// [count, 3 pad, 4 x (a3, b.x, b.y, lambda)], read and written write-through (sc1): an env-step moves between waves at
+// substep boundaries, and the bytes must be where the next wave's loads look (same rule as the state record,
+// store_rec_through).
+__device__ __forceinline__ int manifold_load_global(const float* __restrict__ mfc, MPt (&p)[4]) {
     mf_v4 v[7];
     asm volatile(
         "global_load_dwordx4 %0, %7, off sc1\n\t"
@@ -173,87 +306,23 @@ __device__ __forceinline__ int manifold_update(const DevModel& M, float* __restr
     float f[kMfFloats];
 #pragma unroll
     for (int i = 0; i < 7; i++) { f[4 * i] = v[i].x; f[4 * i + 1] = v[i].y; f[4 * i + 2] = v[i].z; f[4 * i + 3] = v[i].w; }
-    int n = (int)f[0];
-    n = n < 0 ? 0 : (n > 4 ? 4 : n);
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         p[j].a = mk3(f[4 + 6 * j], f[5 + 6 * j], f[6 + 6 * j]);
-        p[j].b = mk3(f[7 + 6 * j], f[8 + 6 * j], f[9 + 6 * j]);
+        p[j].b = mk3(f[7 + 6 * j], f[8 + 6 * j], 0.f);
+        p[j].lam = f[9 + 6 * j];
         p[j].d = 0.f;
     }
-    const float thr = M.break_thr;
-    // the new point: support vertex towards the plane (+ margin along that direction)
-    f3 sv;
-    if (M.hull_sides > 0) {
-        float best = -3.0e38f;
-        sv = mk3(0.f, 0.f, 0.f);
-        for (int k = 0; k < 2 * M.hull_sides; k++) {      // the importer's order: (+z, -z) of vertex 0, 1, ...
-            const f3 c = mk3(M.hull_xy[k >> 1][0], M.hull_xy[k >> 1][1], (k & 1) ? -M.cyl_hl : M.cyl_hl);
-            const float val = dot(dl, c);
-            if (val > best) { best = val; sv = c; }
-        }
-    } else {                                              // btCylinderShapeZ's support function [U]
-        const float rr = sqrtf(dl.x * dl.x + dl.y * dl.y);
-        sv = rr != 0.f ? mk3(M.cyl_r * dl.x / rr, M.cyl_r * dl.y / rr, 0.f) : mk3(M.cyl_r, 0.f, 0.f);
-        sv.z = dl.z < 0.f ? -M.cyl_hl : M.cyl_hl;
-    }
-    const f3 zoff = mk3(0.f, 0.f, M.cyl_zoff);
-    MPt np;
-    const f3 loc = sv + dl * M.margin;                    // in the cylinder's own (centred) frame
-    np.a = loc + zoff;
-    const f3 wnew = centre + mulRv(Rw, loc);
-    np.d = wnew.z;
-    np.b = mk3(wnew.x, wnew.y, 0.f);
-    if (np.d < thr) {
-        int nearest = -1;
-        float shortest = thr * thr;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const f3 d = p[j].a - np.a;
-            const float dd = dot(d, d);
-            if (j < n && dd < shortest) { shortest = dd; nearest = j; }
-        }
-        int where = nearest;
-        if (where < 0) {
-            if (n < 4) where = n++;
-            else where = manifold_sort_cached(p, np);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-            if (j == where) p[j] = np;
-    }
-    // refresh from the current pose, then drop what lifted off or drifted (last to first, the last one moves in)
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        wa[j] = centre + mulRv(Rw, p[j].a - zoff);
-        p[j].d = wa[j].z - p[j].b.z;
-    }
-#pragma unroll
-    for (int j = 3; j >= 0; j--) {
-        if (j < n) {
-            bool drop = !(p[j].d <= thr);
-            if (!drop) {
-                const float dx = p[j].b.x - wa[j].x, dy = p[j].b.y - wa[j].y, dz = p[j].b.z - (wa[j].z - p[j].d);
-                drop = dx * dx + dy * dy + dz * dz > thr * thr;
-            }
-            if (drop) {
-                const int last = n - 1;
-                MPt pl = p[0];
-                f3 wl = wa[0];
-#pragma unroll
-                for (int k = 1; k < 4; k++)
-                    if (k == last) { pl = p[k]; wl = wa[k]; }
-                if (j != last) { p[j] = pl; wa[j] = wl; }
-                n--;
-            }
-        }
-    }
-    // back to memory
+    return (int)f[0];
+}
+__device__ __forceinline__ void manifold_store_global(float* __restrict__ mfc, int n, const MPt (&p)[4]) {
+    mf_v4 v[7];
+    float f[kMfFloats];
     f[0] = (float)n; f[1] = 0.f; f[2] = 0.f; f[3] = 0.f;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         f[4 + 6 * j] = p[j].a.x; f[5 + 6 * j] = p[j].a.y; f[6 + 6 * j] = p[j].a.z;
-        f[7 + 6 * j] = p[j].b.x; f[8 + 6 * j] = p[j].b.y; f[9 + 6 * j] = p[j].b.z;
+        f[7 + 6 * j] = p[j].b.x; f[8 + 6 * j] = p[j].b.y; f[9 + 6 * j] = p[j].lam;
     }
 #pragma unroll
     for (int i = 0; i < 7; i++) { v[i].x = f[4 * i]; v[i].y = f[4 * i + 1]; v[i].z = f[4 * i + 2]; v[i].w = f[4 * i + 3]; }
@@ -268,7 +337,6 @@ __device__ __forceinline__ int manifold_update(const DevModel& M, float* __restr
         :
         : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(mfc)
         : "memory");
-    return n;
 }
 
 // exclusive prefix sum over lanes of a small count (0..7), wave-uniform total in `total`
@@ -280,11 +348,11 @@ __device__ __forceinline__ int lane_prefix3(int cnt, int lane, int& total) {
 }
 
 template <class LT>
-__device__ int find_contacts_v2(LT& L, const DevModel& M, int lane, float* __restrict__ mf) {
+__device__ int find_contacts_v2(LT& L, const DevModel& M, int lane, unsigned long long* __restrict__ ovf) {
     constexpr int N = LT::kN;
     static_assert(4 * N == 64, "one contact slot per lane");
     if (M.contact_model == 1) {
-        // lane = cylinder
+        // lane = cylinder; its manifold lives in LDS while this wave holds the environment (Lds<N, true>::mfl)
         int cnt = 0;
         MPt p[4];
         f3 wa[4];
@@ -292,34 +360,60 @@ __device__ int find_contacts_v2(LT& L, const DevModel& M, int lane, float* __res
         const int c = lane < 2 * N ? lane : 0;
         const int b = (c + 1) >> 1;
         if (lane < 2 * N) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                p[j].a = mk3(L.mfl[6 * j][c], L.mfl[6 * j + 1][c], L.mfl[6 * j + 2][c]);
+                p[j].b = mk3(L.mfl[6 * j + 3][c], L.mfl[6 * j + 4][c], 0.f);
+                p[j].lam = L.mfl[6 * j + 5][c];
+                p[j].d = 0.f;
+            }
             const float* Rb = L.R[b];
             cyl_world_rot(Rb, M.cyl_R[c], Rw);
             const f3 dl = mk3(-Rw[6], -Rw[7], -Rw[8]);
             const f3 centre = ld3(L.o[b]) + mulRv(Rb, ld3(M.cyl_c[c]));
-            cnt = manifold_update(M, mf + (size_t)c * kMfFloats, Rw, centre, dl, p, wa);
+            cnt = manifold_core(M, (int)L.mfn[c], p, Rw, centre, dl, wa);
         }
         int total;
-        int base = lane_prefix3(cnt, lane, total);
+        (void)lane_prefix3(cnt, lane, total);
+        const int room = 4 * N;                      // the solve's contact slots
+        const int mask = manifold_keep_mask(cnt, p, lane, total, room);
+        const int kept = __popc(mask);
+        int tk;
+        const int base = lane_prefix3(kept, lane, tk);
+        if (total > room && lane == 0) {             // counted, never silent (snk_contact_overflow)
+            atomicAdd(ovf, 1ull);
+            atomicAdd(ovf + 1, (unsigned long long)(total - tk));
+        }
         if (lane < 2 * N) {
-            if (base > 4 * N) base = 4 * N;
-            if (base + cnt > 4 * N) cnt = 4 * N - base;       // the solve has 4 N contact slots
-            L.cylbase[c] = base;
-            L.cyln[c] = cnt;
+            L.cylbase[c] = (unsigned char)base;
+            L.cyln[c] = (unsigned char)kept;
+            L.cylkeep[c] = (unsigned char)mask;
+            L.mfn[c] = (unsigned char)cnt;
             f3 dA, dB;
             friction_dirs(M, Rw, dA, dB);
+            st3(L.cdir[c][0], dA);
+            st3(L.cdir[c][1], dB);
+            int idx = base;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
+                const bool on = (mask >> j) & 1;
+                if (!on) p[j].lam = 0.f;             // a point without rows carries no impulse
                 if (j < cnt) {
-                    const int idx = base + j;
+                    L.mfl[6 * j][c] = p[j].a.x; L.mfl[6 * j + 1][c] = p[j].a.y; L.mfl[6 * j + 2][c] = p[j].a.z;
+                    L.mfl[6 * j + 3][c] = p[j].b.x; L.mfl[6 * j + 4][c] = p[j].b.y; L.mfl[6 * j + 5][c] = p[j].lam;
+                }
+                if (on) {
                     st3(L.ccP[idx], wa[j]);
                     L.ccdist[idx] = p[j].d;
-                    L.ccbody[idx] = b;
-                    st3(L.ccdir[idx][0], dA);
-                    st3(L.ccdir[idx][1], dB);
+                    L.ccbody[idx] = (unsigned char)b;
+                    L.ccds[idx] = (unsigned char)c;
+                    // where the normal row starts (warm starting); the solve leaves the row's final impulse here
+                    L.app[kAppNormal + idx] = M.warm_start ? p[j].lam * M.warm_factor : 0.f;
+                    idx++;
                 }
             }
         }
-        return total > 4 * N ? 4 * N : total;
+        return tk;
     }
     const int slot = lane;
     const int c = slot >> 1;
@@ -340,23 +434,32 @@ __device__ int find_contacts_v2(LT& L, const DevModel& M, int lane, float* __res
         const int idx = __popcll(bal & ((1ull << lane) - 1ull));
         st3(L.ccP[idx], P);
         L.ccdist[idx] = dist;
-        L.ccbody[idx] = b;
+        L.ccbody[idx] = (unsigned char)b;
+        L.ccds[idx] = (unsigned char)c;
+        L.app[kAppNormal + idx] = 0.f;       // no contact cache, nothing to warm-start from
+    }
+    if (lane < 2 * N) {      // lane = cylinder: the friction directions its contacts share
+        float Rc[9];
+        cyl_world_rot(L.R[(lane + 1) >> 1], M.cyl_R[lane], Rc);
         f3 dA, dB;
-        friction_dirs(M, Rw, dA, dB);
-        st3(L.ccdir[idx][0], dA);
-        st3(L.ccdir[idx][1], dB);
+        friction_dirs(M, Rc, dA, dB);
+        st3(L.cdir[lane][0], dA);
+        st3(L.cdir[lane][1], dB);
     }
     if (lane < 2 * N) {      // lane = cylinder: where its (up to two) contacts sit in the compact list
-        L.cylbase[lane] = __popcll(bal & ((1ull << (2 * lane)) - 1ull));
-        L.cyln[lane] = (int)((bal >> (2 * lane)) & 1ull) + (int)((bal >> (2 * lane + 1)) & 1ull);
+        L.cylbase[lane] = (unsigned char)__popcll(bal & ((1ull << (2 * lane)) - 1ull));
+        L.cyln[lane] = (unsigned char)((int)((bal >> (2 * lane)) & 1ull) + (int)((bal >> (2 * lane + 1)) & 1ull));
     }
     return __popcll(bal);
 }
 
 // The same persistent-manifold contacts for the streamed-row solve (chains up to 32 links: one cylinder per lane):
-// geometry records written at the COMPACT index (clist is the identity), at most NC ground contacts.
+// the manifolds in global memory, geometry records written at the COMPACT index (clist is the identity), at most NC
+// ground contacts (the same rule for which points keep their rows, the same counters).  geo[19] of a record: the
+// impulse its normal row starts from (warm starting).
 template <class LT>
-__device__ int find_contacts_manifold_v1(LT& L, const DevModel& M, int lane, float* __restrict__ rows, float* __restrict__ mf) {
+__device__ int find_contacts_manifold_v1(LT& L, const DevModel& M, int lane, float* __restrict__ rows, float* __restrict__ mf,
+                                         unsigned long long* __restrict__ ovf) {
     constexpr int N = LT::kN;
     static_assert(2 * N <= 64, "one cylinder per lane");
     int cnt = 0;
@@ -370,23 +473,34 @@ __device__ int find_contacts_manifold_v1(LT& L, const DevModel& M, int lane, flo
         cyl_world_rot(Rb, M.cyl_R[c], Rw);
         const f3 dl = mk3(-Rw[6], -Rw[7], -Rw[8]);
         const f3 centre = ld3(L.o[b]) + mulRv(Rb, ld3(M.cyl_c[c]));
-        cnt = manifold_update(M, mf + (size_t)c * kMfFloats, Rw, centre, dl, p, wa);
+        const int n0 = manifold_load_global(mf + (size_t)c * kMfFloats, p);
+        cnt = manifold_core(M, n0, p, Rw, centre, dl, wa);
     }
     int total;
-    int base = lane_prefix3(cnt, lane, total);
+    (void)lane_prefix3(cnt, lane, total);
+    const int room = LT::NC;
+    const int mask = manifold_keep_mask(cnt, p, lane, total, room);
+    const int kept = __popc(mask);
+    int tk;
+    const int base = lane_prefix3(kept, lane, tk);
+    if (total > room && lane == 0) {
+        atomicAdd(ovf, 1ull);
+        atomicAdd(ovf + 1, (unsigned long long)(total - tk));
+    }
     if (lane < 2 * N) {
-        if (base > LT::NC) base = LT::NC;
-        if (base + cnt > LT::NC) cnt = LT::NC - base;
         // the sensor pass finds a body's contacts through its cylinders: [first compact index, count] of cylinder `lane`
-        // (the slot -> contact table of the stateless model is not used in this one; its array holds these pairs)
+        // (the slot -> contact table of the stateless model is not used in this one; its array holds these pairs) and,
+        // in the upper bits of the count word, which cached points they are (for the impulses' way back into the cache)
         L.cidx[2 * lane] = base;
-        L.cidx[2 * lane + 1] = cnt;
+        L.cidx[2 * lane + 1] = kept | (mask << 8);
         f3 dA, dB;
         friction_dirs(M, Rw, dA, dB);
+        int idx = base;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            if (j < cnt) {
-                const int idx = base + j;
+            const bool on = (mask >> j) & 1;
+            if (!on) p[j].lam = 0.f;
+            if (on) {
                 float* geo = rows + LT::kGeoOff + (size_t)idx * LT::kGeo;
                 st3(geo, wa[j]);
                 geo[3] = p[j].d;
@@ -395,11 +509,14 @@ __device__ int find_contacts_manifold_v1(LT& L, const DevModel& M, int lane, flo
                 st3(geo + 10, mk3(0.f, 0.f, 1.f));
                 st3(geo + 13, mk3(0.f, 0.f, 0.f));
                 geo[16] = (float)b; geo[17] = -1.0f; geo[18] = 1.0f;
+                geo[19] = M.warm_start ? p[j].lam * M.warm_factor : 0.f;
                 L.clist[idx] = idx;
+                idx++;
             }
         }
+        manifold_store_global(mf + (size_t)c * kMfFloats, cnt, p);
     }
-    return total > LT::NC ? LT::NC : total;
+    return tk;
 }
 
 // ------------------------------------------------------------------------------------
@@ -424,7 +541,7 @@ __device__ void build_batch_v2(LT& L, const DevModel& M, int lane, int nc, int b
         } else {
             k = L.ccbody[ci];
             P = ld3(L.ccP[ci]);
-            d = KIND == 1 ? mk3(0.f, 0.f, 1.f) : ld3(L.ccdir[ci][lane >> 5]);
+            d = KIND == 1 ? mk3(0.f, 0.f, 1.f) : ld3(L.cdir[L.ccds[ci]][lane >> 5]);
         }
         f3 pN = mk3(0, 0, 0), pF = mk3(0, 0, 0);
 #pragma unroll 4
@@ -498,20 +615,13 @@ __device__ void build_batch_v2(LT& L, const DevModel& M, int lane, int nc, int b
     lds_sync();
 }
 
-// slot map (two rows per slot) and the layout of the accumulated impulses handed back in L.app
-constexpr int kSlotNormal = 0;    // 32 slots: contacts 2s (lower half), 2s+1 (upper half)
-constexpr int kSlotFric = 32;     // 64 slots: contact s, direction A lower / B upper
-constexpr int kSlots = 96;
-constexpr int kAppMotor = 0;      // app[j]                motor j
-constexpr int kAppNormal = 16;    // app[16 + ci]          normal of contact ci
-constexpr int kAppFric = 80;      // app[80 + 2 ci + {0,1}] friction A / B of contact ci
-constexpr unsigned long long kLowMask = 0x00000000FFFFFFFFull;
 
 // per-lane constants of the (half, d) layout
 struct LaneK {
     int h, d;
     bool isdof;
     float m22, m24;  // -1 at d==22 / +1 at d==24, else 0
+    float m31;       // 1 at d==31 (the accumulated impulse's lane), else 0
     int spoff;       // staging column that feeds this lane's special value (22 rhs, 23 den)
     f3 oL, aL;       // for d < 3 and d >= 6:  J[d] = aL . ((P - oL) x dir);  3 <= d < 6: dir[d-3]
     int bL;          // joint index (body) of lane d, 0 for the base components
@@ -528,7 +638,7 @@ struct LaneK {
 // The LDS reads of a slot (issued one slot ahead of the arithmetic that consumes them: a
 // dependent ds_read round trip costs ~200 clocks, as much as the whole slot's arithmetic).
 struct SlotRaw {
-    float mval, dinv, sp;
+    float mval, dinv, sp, lam;
     f3 P, dir;
     int k;
     bool valid;
@@ -548,18 +658,24 @@ __device__ __forceinline__ SlotRaw fetch_slot(LT& L, const LaneK& K, int s, int 
     r.dinv = st[24];
     r.sp = st[22 + K.spoff];
     r.P = ld3(L.ccP[rs]);
-    r.dir = KIND == 1 ? mk3(0.f, 0.f, 1.f) : ld3(L.ccdir[rs][K.h]);
+    r.dir = KIND == 1 ? mk3(0.f, 0.f, 1.f) : ld3(L.cdir[L.ccds[rs]][K.h]);
     r.k = L.ccbody[rs];
+    r.lam = (KIND == 1 && r.valid) ? L.app[kAppNormal + rs] : 0.f;     // where the normal row starts (warm starting)
     return r;
 }
 template <int KIND>
-__device__ __forceinline__ void finish_slot(const SlotRaw& r, const LaneK& K, float sJ, float sM, float& RJ, float& RM) {
+__device__ __forceinline__ void finish_slot(const SlotRaw& r, const LaneK& K, float sJ, float sM, float& RJ, float& RM,
+                                            float& wsum) {
     float v = dot(K.aL, cross(r.P - K.oL, r.dir));
     v = K.d == 3 ? r.dir.x : (K.d == 4 ? r.dir.y : (K.d == 5 ? r.dir.z : v));
     const float jd = (K.bL <= r.k) ? v : 0.0f;
     float rj = (K.isdof ? jd * r.dinv : r.sp * K.m22) * sJ;
     float rm = (K.isdof ? r.mval : r.sp * K.m24) * sM;
     if (!r.valid) { rj = 0.f; rm = 0.f; }
+    if (KIND == 1) {
+        rj += K.m31 * r.lam;
+        wsum += rm * r.lam;
+    }
     RJ = rj;
     RM = rm;
 }
@@ -567,13 +683,13 @@ __device__ __forceinline__ void finish_slot(const SlotRaw& r, const LaneK& K, fl
 // measured the same and spills)
 template <class LT, int KIND, int BASE, int DST>
 __device__ __forceinline__ void load_slots8(LT& L, const LaneK& K, int count, int base, float sJ, float sM,
-                                            float (&RJ)[kSlots], float (&RM)[kSlots]) {
+                                            float (&RJ)[kSlots], float (&RM)[kSlots], float& wsum) {
     SlotRaw cur = fetch_slot<LT, KIND>(L, K, BASE, count, base);
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         SlotRaw nxt = cur;
         if (i < 7) nxt = fetch_slot<LT, KIND>(L, K, BASE + i + 1, count, base);
-        finish_slot<KIND>(cur, K, sJ, sM, RJ[DST + BASE + i], RM[DST + BASE + i]);
+        finish_slot<KIND>(cur, K, sJ, sM, RJ[DST + BASE + i], RM[DST + BASE + i], wsum);
         cur = nxt;
     }
 }
@@ -1028,7 +1144,7 @@ __device__ __forceinline__ void contact_rows(float (&RJ)[kSlots], float (&RM)[kS
 
 template <class LT>
 __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane, float mu, int& iters, int& ncontacts,
-                                           const SensorHint& hint, float* __restrict__ mf) {
+                                           const SensorHint& hint, unsigned long long* __restrict__ ovf) {
     constexpr int N = LT::kN;
     constexpr int ND = N + 6;
     static_assert(N == 16, "v2 is laid out for the 16-link chain");
@@ -1038,7 +1154,7 @@ __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane, f
 #endif
     SNK_STAMP(0)
     // (1) contacts of the current pose, (2) bias forces with gravity, joint damping torque
-    const int nc = __builtin_amdgcn_readfirstlane(find_contacts_v2(L, M, lane, mf));
+    const int nc = __builtin_amdgcn_readfirstlane(find_contacts_v2(L, M, lane, ovf));
     ncontacts = nc;
     SNK_STAMP(1)
     if (lane < N) {
@@ -1076,6 +1192,7 @@ __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane, f
     float RJ[kSlots], RM[kSlots];
     float RMm[16], TARGV, PMIV;   // PMIV: per-lane bound on y = dI * den (clamped motors only)
     bool malive;                  // every motor row has a positive denominator
+    float wsum = 0.f;             // sum over the normal rows of M^-1 J^T x (the impulse the row starts from), per half
     {
         LaneK K;
         K.h = lane >> 5;
@@ -1083,6 +1200,7 @@ __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane, f
         K.isdof = K.d < ND;
         K.m22 = K.d == 22 ? -1.0f : 0.0f;
         K.m24 = K.d == 24 ? 1.0f : 0.0f;
+        K.m31 = K.d == 31 ? 1.0f : 0.0f;
         K.spoff = K.d == 24 ? 1 : 0;
         K.bL = (K.d >= 6 && K.isdof) ? K.d - 5 : 0;
         K.oL = ld3(L.o[K.bL]);
@@ -1096,18 +1214,18 @@ __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane, f
         for (int s = 0; s < kSlots - kSlotFric; s++) { RJ[kSlotFric + s] = 0.f; RM[kSlotFric + s] = 0.f; }
         build_batch_v2<LT, 4>(L, M, lane, nc, 0);
         SNK_STAMP(5)
-        if (nc > 0) load_slots8<LT, 4, 0, kSlotFric>(L, K, nc, 0, fJ, fM, RJ, RM);
-        if (nc > 8) load_slots8<LT, 4, 8, kSlotFric>(L, K, nc, 0, fJ, fM, RJ, RM);
-        if (nc > 16) load_slots8<LT, 4, 16, kSlotFric>(L, K, nc, 0, fJ, fM, RJ, RM);
-        if (nc > 24) load_slots8<LT, 4, 24, kSlotFric>(L, K, nc, 0, fJ, fM, RJ, RM);
+        if (nc > 0) load_slots8<LT, 4, 0, kSlotFric>(L, K, nc, 0, fJ, fM, RJ, RM, wsum);
+        if (nc > 8) load_slots8<LT, 4, 8, kSlotFric>(L, K, nc, 0, fJ, fM, RJ, RM, wsum);
+        if (nc > 16) load_slots8<LT, 4, 16, kSlotFric>(L, K, nc, 0, fJ, fM, RJ, RM, wsum);
+        if (nc > 24) load_slots8<LT, 4, 24, kSlotFric>(L, K, nc, 0, fJ, fM, RJ, RM, wsum);
         lds_sync();
         SNK_STAMP(6)
         build_batch_v2<LT, 4>(L, M, lane, nc, 32);      // no active lanes when nc <= 32
         SNK_STAMP(7)
-        if (nc > 32) load_slots8<LT, 4, 32, kSlotFric>(L, K, nc, 32, fJ, fM, RJ, RM);
-        if (nc > 40) load_slots8<LT, 4, 40, kSlotFric>(L, K, nc, 32, fJ, fM, RJ, RM);
-        if (nc > 48) load_slots8<LT, 4, 48, kSlotFric>(L, K, nc, 32, fJ, fM, RJ, RM);
-        if (nc > 56) load_slots8<LT, 4, 56, kSlotFric>(L, K, nc, 32, fJ, fM, RJ, RM);
+        if (nc > 32) load_slots8<LT, 4, 32, kSlotFric>(L, K, nc, 32, fJ, fM, RJ, RM, wsum);
+        if (nc > 40) load_slots8<LT, 4, 40, kSlotFric>(L, K, nc, 32, fJ, fM, RJ, RM, wsum);
+        if (nc > 48) load_slots8<LT, 4, 48, kSlotFric>(L, K, nc, 32, fJ, fM, RJ, RM, wsum);
+        if (nc > 56) load_slots8<LT, 4, 56, kSlotFric>(L, K, nc, 32, fJ, fM, RJ, RM, wsum);
         lds_sync();
         SNK_STAMP(8)
         build_batch_v2<LT, 1>(L, M, lane, nc);
@@ -1115,10 +1233,10 @@ __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane, f
 #pragma unroll
         for (int s = 0; s < kSlotFric; s++) { RJ[kSlotNormal + s] = 0.f; RM[kSlotNormal + s] = 0.f; }
         // a normal slot holds contacts 2s, 2s+1: 8 slots per 16 contacts
-        if (nc > 0) load_slots8<LT, 1, 0, kSlotNormal>(L, K, nc, 0, 1.0f, 1.0f, RJ, RM);
-        if (nc > 16) load_slots8<LT, 1, 8, kSlotNormal>(L, K, nc, 0, 1.0f, 1.0f, RJ, RM);
-        if (nc > 32) load_slots8<LT, 1, 16, kSlotNormal>(L, K, nc, 0, 1.0f, 1.0f, RJ, RM);
-        if (nc > 48) load_slots8<LT, 1, 24, kSlotNormal>(L, K, nc, 0, 1.0f, 1.0f, RJ, RM);
+        if (nc > 0) load_slots8<LT, 1, 0, kSlotNormal>(L, K, nc, 0, 1.0f, 1.0f, RJ, RM, wsum);
+        if (nc > 16) load_slots8<LT, 1, 8, kSlotNormal>(L, K, nc, 0, 1.0f, 1.0f, RJ, RM, wsum);
+        if (nc > 32) load_slots8<LT, 1, 16, kSlotNormal>(L, K, nc, 0, 1.0f, 1.0f, RJ, RM, wsum);
+        if (nc > 48) load_slots8<LT, 1, 24, kSlotNormal>(L, K, nc, 0, 1.0f, 1.0f, RJ, RM, wsum);
         // motors: column 6+j of M^-1 (divided by the row's denominator) in both halves;
         // target velocity change of motor j in lane 6+j
 #pragma unroll
@@ -1212,6 +1330,15 @@ __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane, f
     {
         const int d = lane & 31;
         dv = d == 22 ? 1.0f : (d == 31 ? -1.0f : 0.0f);
+        // warm starting (snk_params::warm_start): every normal row starts at the impulse find_contacts_v2 left for its
+        // contact (factor x what its cached point carried; zero without warm starting) -- finish_slot put it into lane 31
+        // / 63 of the row's RJ -- and delta-v at the sum of M^-1 J^T of those (wsum, collected while the slots were
+        // loaded).  No branch on the switch here: a conditional update of 32 row registers in front of the solve makes
+        // the compiler keep two of them in scratch memory for the whole loop (round-3 measurement in the ISA).
+        {
+            const swap2 sw = half_swap(wsum, wsum);     // a = the lower half's rows' part in both halves, b = the upper's
+            dv += sw.a + sw.b;
+        }
         const float E3163 = d == 31 ? 1.0f : 0.0f;
         const float EPS = 1e-30f;
         const float mi = M.max_motor_imp;
@@ -1285,6 +1412,14 @@ __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane, f
         if (lane >= 6 && lane < ND) L.app[kAppMotor + lane - 6] = ACCV * L.MmS[lane - 6][2];   // y / den = impulse
     }
     lds_sync();
+    if (M.contact_model == 1 && lane < 2 * N) {
+        // the normal impulses go back into the contact cache (btManifoldPoint::m_appliedImpulse [U])
+        int idx = L.cylbase[lane];
+        const int mask = L.cylkeep[lane];
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if ((mask >> j) & 1) L.mfl[6 * j + 5][lane] = L.app[kAppNormal + idx++];
+    }
 
     SNK_STAMP(13)
     // (6) constraint pass for the joint-0 sensor [U] -- only when this substep can be the last of
@@ -1302,8 +1437,8 @@ __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane, f
         if (lane < nc) {
             const int ci = lane, k = L.ccbody[ci];
             f3 F = (mk3(0.f, 0.f, 1.f) * L.app[kAppNormal + ci] +
-                    ld3(L.ccdir[ci][0]) * L.app[kAppFric + 2 * ci] +
-                    ld3(L.ccdir[ci][1]) * L.app[kAppFric + 2 * ci + 1]) * M.inv_dt;
+                    ld3(L.cdir[L.ccds[ci]][0]) * L.app[kAppFric + 2 * ci] +
+                    ld3(L.cdir[L.ccds[ci]][1]) * L.app[kAppFric + 2 * ci + 1]) * M.inv_dt;
             st3(&L.stM[ci][0], cross(ld3(L.ccP[ci]) - ld3(L.o[k]), F));
             st3(&L.stM[ci][3], F);
         }
@@ -1320,8 +1455,8 @@ __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane, f
                     eF = eF + ld3(&L.stM[ci][3]);
                 }
             }
-            st3(&L.ext[b][0], eN);
-            st3(&L.ext[b][3], eF);
+            st3(L.ext(b), eN);
+            st3(L.ext(b) + 3, eF);
         }
         if (lane < N) L.tauj[lane] = -M.joint_damp * L.qd_old[lane] + L.app[lane] * M.inv_dt;
         lds_sync();

@@ -10,7 +10,7 @@
 //                 (more than both margins deep, where Bullet switches to EPA): a second GJK on cores shrunk by
 //                 kShrink with the margin enlarged by as much; if even those overlap, the line of centres.
 // One point per pair per step (stateless; Bullet caches up to four per pair), kept when closer than the breaking
-// threshold, at most kMaxSelf per environment, ordered by (b - a, a) -- the same rules as oracle/snake_oracle.cpp
+// threshold, at most kMaxSelf per environment (what does not fit is counted: snk_contact_overflow), ordered by (b - a, a) -- the same rules as oracle/snake_oracle.cpp
 // (find_self_contacts), restated independently here in float32.
 //
 // Only the streamed-row solve (32-link chains) builds rows for these contacts: for the 16-link snake they can never
@@ -226,7 +226,8 @@ __device__ __forceinline__ f3 aniso_scale(const DevModel& M, const float* Rw, f3
 // Link-link contacts of the current pose, appended behind the ground contacts: geometry records at slots
 // NC .. NC + count - 1 of the environment's global block.  Returns their number (<= kMaxSelf).
 template <class LT>
-__device__ int find_self_contacts_v1(LT& L, const DevModel& M, int lane, float mu_ground, float* __restrict__ rows) {
+__device__ int find_self_contacts_v1(LT& L, const DevModel& M, int lane, float mu_ground, float* __restrict__ rows,
+                                     unsigned long long* __restrict__ ovf) {
     constexpr int N = LT::kN;
     constexpr int NCYL = 2 * N;
     const float rb = sqrtf(M.cyl_r * M.cyl_r + M.cyl_hl * M.cyl_hl) + M.margin;
@@ -255,6 +256,59 @@ __device__ int find_self_contacts_v1(LT& L, const DevModel& M, int lane, float m
     const int a = lane < NCYL ? lane : NCYL - 1;
     const int ba = (a + 1) >> 1;
     const f3 ca = ld3(L.o[ba]) + mulRv(L.R[ba], ld3(M.cyl_c[a]));
+    // The obstacle box (static): lane = cylinder, one point per (cylinder, box) pair, normal from the box to the link,
+    // friction mu_link x mu_obstacle, directions scaled by the link's anisotropy only.  Its records FOLLOW the link-link
+    // ones (row order: ground, link-link, obstacle -- the oracle's), but the narrow phase runs first: when the room for
+    // these contacts (kMaxSelf) runs out, the obstacle's are kept and link-link contacts go (in pair order, last first).
+    bool ob_hit = false;
+    f3 ob_P = mk3(0, 0, 0), ob_n = mk3(0, 0, 1);
+    float ob_dist = 0.f;
+    float ob_R[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) ob_R[i] = 0.f;
+    int n_ob = 0;
+    if (M.obstacle) {
+        Cvx Bx;
+        Bx.c = mk3(M.obs_c[0], M.obs_c[1], M.obs_c[2]);
+#pragma unroll
+        for (int i = 0; i < 9; i++) Bx.R[i] = (i % 4 == 0) ? 1.f : 0.f;
+        Bx.box = 1;
+        Bx.half = mk3(M.obs_h[0], M.obs_h[1], M.obs_h[2]);
+        const float rbox = sqrtf(dot(Bx.half, Bx.half));
+        const f3 d = ca - Bx.c;
+        const float reach_ob = rb + rbox + M.break_thr;
+        const bool cand = lane < NCYL && dot(d, d) <= reach_ob * reach_ob;
+        if (__any(cand)) {
+            if (cand) {
+                Cvx A;
+                frame(a, A);
+#pragma unroll
+                for (int i = 0; i < 9; i++) ob_R[i] = A.R[i];
+                f3 pa, pb;
+                float mg = M.margin;
+                float dd = gjk_distance(M, A, Bx, 0.f, pa, pb);
+                if (dd < 0.f) {
+                    dd = gjk_distance(M, A, Bx, kShrink, pa, pb);
+                    mg = M.margin + kShrink;
+                }
+                if (dd < 0.f) {
+                    const float nn = sqrtf(dot(d, d));
+                    ob_n = nn > 0.f ? d * (1.0f / nn) : mk3(-1.f, 0.f, 0.f);
+                    ob_P = A.c;
+                    ob_dist = -2.0f * mg;
+                } else {
+                    ob_n = (pa - pb) * (1.0f / dd);
+                    ob_dist = dd - 2.0f * mg;
+                    ob_P = pa - ob_n * mg;
+                }
+                ob_hit = ob_dist < M.break_thr;
+            }
+        }
+    }
+    const unsigned long long ob_bal = __ballot(ob_hit);
+    n_ob = __popcll(ob_bal);
+    const int ob_kept = n_ob < LT::kMaxSelf ? n_ob : LT::kMaxSelf;
+    const int self_room = LT::kMaxSelf - ob_kept;
     int nself = 0;
     for (int delta = 2; delta < (M.self_collision ? NCYL : 0); delta++) {
         const int bc = a + delta;
@@ -301,7 +355,7 @@ __device__ int find_self_contacts_v1(LT& L, const DevModel& M, int lane, float m
         const unsigned long long bal = __ballot(hit);
         if (hit) {
             const int idx = nself + __popcll(bal & ((1ull << lane) - 1ull));
-            if (idx < LT::kMaxSelf) {
+            if (idx < self_room) {
                 float* geo = rows + LT::kGeoOff + (size_t)(LT::NC + idx) * LT::kGeo;
                 f3 dA, dB;
                 plane_space(nrm, dA, dB);
@@ -316,75 +370,38 @@ __device__ int find_self_contacts_v1(LT& L, const DevModel& M, int lane, float m
                 geo[16] = (float)((a + 1) >> 1);
                 geo[17] = (float)((bc + 1) >> 1);
                 geo[18] = rho;
+                geo[19] = 0.f;        // (no contact cache for these pairs: nothing to warm-start from)
             }
         }
         nself += __popcll(bal);
     }
-    // the obstacle box (static): lane = cylinder, one point per (cylinder, box) pair, normal from the box to the link,
-    // friction mu_link x mu_obstacle, directions scaled by the link's anisotropy only; the records follow the link-link ones
-    if (M.obstacle) {
-        Cvx Bx;
-        Bx.c = mk3(M.obs_c[0], M.obs_c[1], M.obs_c[2]);
-#pragma unroll
-        for (int i = 0; i < 9; i++) Bx.R[i] = (i % 4 == 0) ? 1.f : 0.f;
-        Bx.box = 1;
-        Bx.half = mk3(M.obs_h[0], M.obs_h[1], M.obs_h[2]);
-        const float rbox = sqrtf(dot(Bx.half, Bx.half));
-        const float mu_ob = fminf(M.mu_link * M.mu_obs, 10.0f);
-        const float rho_ob = mu_ground > 0.f ? mu_ob / mu_ground : 0.f;
-        const f3 d = ca - Bx.c;
-        const float reach_ob = rb + rbox + M.break_thr;
-        const bool cand = lane < NCYL && dot(d, d) <= reach_ob * reach_ob;
-        if (__any(cand)) {
-            bool hit = false;
-            f3 P = mk3(0, 0, 0), nrm = mk3(0, 0, 1);
-            float dist = 0.f;
-            Cvx A;
-            if (cand) {
-                frame(a, A);
-                f3 pa, pb;
-                float mg = M.margin;
-                float dd = gjk_distance(M, A, Bx, 0.f, pa, pb);
-                if (dd < 0.f) {
-                    dd = gjk_distance(M, A, Bx, kShrink, pa, pb);
-                    mg = M.margin + kShrink;
-                }
-                if (dd < 0.f) {
-                    const float nn = sqrtf(dot(d, d));
-                    nrm = nn > 0.f ? d * (1.0f / nn) : mk3(-1.f, 0.f, 0.f);
-                    P = A.c;
-                    dist = -2.0f * mg;
-                } else {
-                    nrm = (pa - pb) * (1.0f / dd);
-                    dist = dd - 2.0f * mg;
-                    P = pa - nrm * mg;
-                }
-                hit = dist < M.break_thr;
-            }
-            const unsigned long long bal = __ballot(hit);
-            if (hit) {
-                const int idx = nself + __popcll(bal & ((1ull << lane) - 1ull));
-                if (idx < LT::kMaxSelf) {
-                    float* geo = rows + LT::kGeoOff + (size_t)(LT::NC + idx) * LT::kGeo;
-                    f3 dA, dB;
-                    plane_space(nrm, dA, dB);
-                    dA = aniso_scale(M, A.R, dA);
-                    dB = aniso_scale(M, A.R, dB);
-                    st3(geo, P);
-                    geo[3] = dist;
-                    st3(geo + 4, dA);
-                    st3(geo + 7, dB);
-                    st3(geo + 10, nrm);
-                    st3(geo + 13, mk3(0.f, 0.f, 0.f));
-                    geo[16] = (float)((a + 1) >> 1);
-                    geo[17] = -1.0f;
-                    geo[18] = rho_ob;
-                }
-            }
-            nself += __popcll(bal);
+    const int self_kept = nself < self_room ? nself : self_room;
+    if ((nself > self_kept || n_ob > ob_kept) && lane == 0)      // counted, never silent (snk_contact_overflow)
+        atomicAdd(ovf + 2, (unsigned long long)((nself - self_kept) + (n_ob - ob_kept)));
+    if (ob_hit) {
+        const int k = __popcll(ob_bal & ((1ull << lane) - 1ull));
+        if (k < ob_kept) {
+            const float mu_ob = fminf(M.mu_link * M.mu_obs, 10.0f);
+            const float rho_ob = mu_ground > 0.f ? mu_ob / mu_ground : 0.f;
+            float* geo = rows + LT::kGeoOff + (size_t)(LT::NC + self_kept + k) * LT::kGeo;
+            f3 dA, dB;
+            plane_space(ob_n, dA, dB);
+            dA = aniso_scale(M, ob_R, dA);
+            dB = aniso_scale(M, ob_R, dB);
+            st3(geo, ob_P);
+            geo[3] = ob_dist;
+            st3(geo + 4, dA);
+            st3(geo + 7, dB);
+            st3(geo + 10, ob_n);
+            st3(geo + 13, mk3(0.f, 0.f, 0.f));
+            geo[16] = (float)((a + 1) >> 1);
+            geo[17] = -1.0f;
+            geo[18] = rho_ob;
+            geo[19] = 0.f;
         }
     }
-    return nself > LT::kMaxSelf ? LT::kMaxSelf : nself;
+    return self_kept + ob_kept;
+
 }
 
 }  // namespace snk

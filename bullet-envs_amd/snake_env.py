@@ -163,6 +163,11 @@ class SnakeGymEnv(object):
         if hardReset:
             self._stepper.close()
             self._stepper = _lib.Stepper(1, device=self._stepper.device, params=self.params)
+            # the test-mode replay handle was built for the old world (params, obstacle, contact cache): a new one is
+            # made on the next test-mode step
+            if getattr(self, "_scratch", None) is not None:
+                self._scratch.close()
+                self._scratch = None
         else:
             self._stepper.reset()
 
@@ -178,7 +183,7 @@ class SnakeGymEnv(object):
         if a32.shape[1] != self._stepper.act_dim:
             raise SystemError("Action not executed!")
         if self.mode == 'test':
-            before = self._stepper.get_state()
+            before = self._stepper.get_state() + (self._stepper.get_manifold(),)
         obs, rew, done, sub = self._stepper.step(a32, vec_mode=False)
         if self.mode == 'test':
             self._record_telemetry(before, a32[0], int(sub[0]), obs[0])
@@ -210,6 +215,8 @@ class SnakeGymEnv(object):
             self._scratch = _lib.Stepper(1, device=self._stepper.device, params=self.params)
         sc = self._scratch
         sc.set_state(before[0], before[1])
+        if before[2] is not None:             # contact_model 1: the contact cache is part of the state the step started in
+            sc.set_manifold(before[2])
         n = self.params.n_modules
         # createAction + convertActionToJointCommand with the gait and scale the DEVICE uses (self.params: they
         # may have been overridden through **over, which the robot facade does not see)

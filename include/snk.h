@@ -29,13 +29,13 @@ typedef struct snk_params {
                                    URDF_USE_INERTIA_FROM_FILE); 1: urdf:815,871 values       */
     double  default_mass;       /* links without <inertial> (urdf:7,14,818): mass 1 [U]       */
     double  collision_margin;   /* 0.001 [U]                                                  */
-    int32_t hull_sides;         /* 0: implicit cylinder (default here); 32: the 32-gon prism PyBullet
-                                   builds for a URDF <cylinder> unless URDF_USE_IMPLICIT_CYLINDER [U]
-                                   (snake.py:93 passes no such flag); at most 32                     */
-    int32_t contact_model;      /* 0: stateless -- both end-cap points of every cylinder, every step
-                                   (default here); 1: Bullet's persistent manifold [U] -- one new
-                                   support point per cylinder per step merged into a cache of <= 4,
-                                   refreshed / dropped at breaking_threshold            */
+    int32_t hull_sides;         /* 32 (default): the 32-gon prism PyBullet builds for a URDF <cylinder> unless
+                                   URDF_USE_IMPLICIT_CYLINDER [U] (snake.py:93 passes no such flag); 0: implicit
+                                   cylinder (the round-1 model); 0 or 3..32                           */
+    int32_t contact_model;      /* 1 (default): Bullet's persistent manifold [U] -- one new support point per
+                                   cylinder per step merged into a cache of <= 4, refreshed / dropped at the
+                                   breaking threshold; 0: stateless -- both end-cap points of
+                                   every cylinder, every step (the round-1 model)                      */
     int32_t self_collision;     /* 1 (default): link-link contacts between non-adjacent cylinder links, what
                                    URDF_USE_SELF_COLLISION (snake.py:93) switches on [U].  Evaluated for
                                    n_modules 32; for the 16-link snake they can never act inside the joint
@@ -66,10 +66,21 @@ typedef struct snk_params {
     double  aniso[3];           /* anisotropicFriction = [1, 0.1, 0.01] (snake.py:25)         */
     double  contact_erp;        /* 0.08 [U]                                                   */
     double  linear_slop;        /* 1e-5 [U]                                                   */
-    double  breaking_threshold; /* 0.02 [U]                                                   */
+    double  breaking_threshold; /* 0.02 [U] gContactBreakingThreshold                         */
+    int32_t relative_breaking_threshold; /* 1 (default) [U]: btCollisionDispatcher's default flag
+                                   CD_USE_RELATIVE_CONTACT_BREAKING_THRESHOLD -- a manifold's threshold is
+                                   breaking_threshold x the smaller angular-motion disc of its two shapes, computed
+                                   from the link collider's AABB (0.0603 m -> 1.206 mm); 0: breaking_threshold itself */
     int32_t cone_friction;      /* 1 [U]                                                      */
     int32_t n_iterations;       /* 50 [U]                                                     */
     double  residual_threshold; /* 1e-7 [U]; 0 disables the early exit                        */
+    int32_t warm_start;         /* 0 (default) [U]: btMultiBodyConstraintSolver::setupMultiBodyContactConstraint has its
+                                   warm start disabled, every row starts at zero impulse.  1: SOLVER_USE_WARMSTARTING as
+                                   the rigid-body solver does it -- a cached point's normal row starts at
+                                   warmstarting_factor x the impulse it carried in the last substep (the contact cache
+                                   keeps it: btManifoldPoint::m_appliedImpulse), delta-v at the sum of M^-1 J^T of those;
+                                   friction rows start at zero.  Needs contact_model 1                            */
+    double  warmstarting_factor;/* 0.85 [U] btContactSolverInfo::m_warmstartingFactor            */
     /* Snake / SnakeGymEnv */
     double  scaling_factor;     /* snake.py:63   pi/6                                         */
     int32_t gait;               /* snake.py:62   1: actions drive odd motor slots             */
@@ -144,9 +155,10 @@ int snk_substep_host(snk_handle* h, const float* targets, int32_t k, int32_t* in
 int snk_get_state(snk_handle* h, float* state, float* aux);
 int snk_set_state(snk_handle* h, const float* state, const float* aux);
 /* contact_model 1 only: the persistent contact manifolds (part of the simulator state, like Bullet's contact cache,
- * which a soft reset does not clear [U]).  Host buffers [n_envs x 2n x 25]: per cylinder (in link order)
- * [count, 4 x (point on the link in link coordinates 3, point on the ground in world coordinates 3)].
- * snk_manifold_floats = 2n * 25, or 0 for a contact_model 0 handle (then get/set fail). */
+ * which a soft reset does not clear [U]).  Host buffers [n_envs x 2n x 29]: per cylinder (in link order)
+ * [count, 4 x (point on the link in link coordinates 3, point on the ground in world coordinates 3, the normal impulse
+ * the point carried in the last substep)].
+ * snk_manifold_floats = 2n * 29, or 0 for a contact_model 0 handle or a null handle (then get/set fail). */
 int32_t snk_manifold_floats(const snk_handle* h);
 int snk_get_manifold(snk_handle* h, float* out);
 int snk_set_manifold(snk_handle* h, const float* in);
@@ -164,6 +176,17 @@ int snk_link_positions(snk_handle* h, float* out);
  * (getJointState(robot, 3)[2][2], "> 20: the snake has hit the wall").  Host buffer [n_envs].  Evaluated by the
  * streamed-row solve (32 links, or 16 links with an obstacle); fails for a register-resident 16-link handle. */
 int snk_joint3_reaction_fz(snk_handle* h, float* out);
+
+/* Contacts the solves had no room for, counted on the device since snk_create (Bullet has no such limit; these
+ * counters say when this build's structural limits were hit -- DESIGN.md 3):
+ *   out[0] physics substeps in which an environment held more ground-contact points than the solve has slots for
+ *          (4n; 4n minus the obstacle's contacts for a 16-link handle with an obstacle),
+ *   out[1] the manifold points that got no rows in those substeps (the shallowest of their cylinders go first, every
+ *          cylinder keeps its deepest point before any keeps a second, and so on),
+ *   out[2] link-link / obstacle contacts beyond the room for them (32; 8 obstacle contacts on a register-resident
+ *          16-link handle) -- obstacle contacts are kept before link-link ones.
+ * Host buffer of 3. */
+int snk_contact_overflow(snk_handle* h, uint64_t* out);
 
 /* BASELINE config 5: per-env lateral friction of the ground plane (reference: plane.urdf = 1). */
 int snk_set_ground_friction(snk_handle* h, const float* mu /* host [n_envs] */);

@@ -28,8 +28,9 @@ class OrcParams(C.Structure):
         ("limit_erp", C.c_double), ("limit_max_impulse", C.c_double),
         ("mu_link", C.c_double), ("aniso", C.c_double * 3),
         ("contact_erp", C.c_double), ("linear_slop", C.c_double),
-        ("breaking_threshold", C.c_double), ("cone_friction", C.c_int32),
+        ("breaking_threshold", C.c_double), ("relative_breaking_threshold", C.c_int32), ("cone_friction", C.c_int32),
         ("n_iterations", C.c_int32), ("residual_threshold", C.c_double),
+        ("warm_start", C.c_int32), ("warmstarting_factor", C.c_double),
         ("scaling_factor", C.c_double), ("gait", C.c_int32),
         ("servo_tol", C.c_double), ("max_counter", C.c_int32),
         ("height_threshold", C.c_double), ("energy_dt", C.c_double),
@@ -184,15 +185,27 @@ class OracleEnv:
     def hard_reset(self):
         self.lib.orc_hard_reset(self.h)
 
+    def sync(self, state, aux=None, manifold=None):
+        """Everything the simulator carries from one substep to the next, taken from the product's accessors of one env:
+        state (snk_get_state), aux = [motor torques n, joint-0 Fz, prev obs x] and, for contact_model 1, the env's
+        contact cache (snk_get_manifold)."""
+        self.set_state(np.asarray(state, dtype=np.float64))
+        if aux is not None:
+            aux = np.asarray(aux, dtype=np.float64)
+            self.set_aux(aux[:self.n], float(aux[self.n]), float(aux[self.n + 1]))
+        if manifold is not None and self.params.contact_model == 1:
+            self.set_manifold(np.asarray(manifold, dtype=np.float64))
+
     def get_manifold(self):
-        """Contact cache of contact_model 1: [2n, 25] = per cylinder [count, 4 x (local point 3, ground point 3)]."""
-        m = np.zeros((2 * self.n, 25))
+        """Contact cache of contact_model 1: [2n, 29] = per cylinder [count, 4 x (local point 3, ground point 3, applied
+        normal impulse)]."""
+        m = np.zeros((2 * self.n, 29))
         self.lib.orc_get_manifold(self.h, _dp(m))
         return m
 
     def set_manifold(self, m):
         m = np.ascontiguousarray(m, dtype=np.float64)
-        assert m.shape == (2 * self.n, 25)
+        assert m.shape == (2 * self.n, 29)
         self.lib.orc_set_manifold(self.h, _dp(m))
 
     def reset(self):

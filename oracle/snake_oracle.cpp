@@ -191,12 +191,14 @@ struct Contact {
     Real PB[3], n[3];
     Real mu;     /* combined friction coefficient of the pair */
     int kind;    /* 0 ground, 1 link-link, 2 obstacle box */
+    int mpoint;  /* contact_model 1, ground contacts: index of its cached point in the link's manifold (else -1) */
 };
 
 /* btPersistentManifold of one (ground, link collider) pair [U]: up to 4 cached points, each kept as the point
  * on the link in link coordinates and the point on the ground in world coordinates (the ground does not move). */
 struct ManifoldPoint {
     Real localA[3], worldB[3], dist;
+    Real lambda;   /* btManifoldPoint::m_appliedImpulse [U]: the normal impulse of the last solve (warm starting) */
 };
 struct Manifold {
     int n;
@@ -211,6 +213,7 @@ struct orc_env {
     std::vector<Link> links;
     std::vector<int> dof_link;   /* dof -> link index */
     Real cyl_r, cyl_len;
+    Real break_thr;           /* the manifolds' contact breaking threshold in force (build_model) */
     double mu_plane;
     /* state */
     Real pos[3], quat[4], omega[3], vel[3];
@@ -245,6 +248,17 @@ void build_model(orc_env* e) {
     const double m_link = 0.103;                                  /* snake.urdf:814,870 */
     const double I_file[3] = {5.4796e-05, 5.4796e-05, 3.4814e-05}; /* snake.urdf:815,871 */
     const double mg = P.collision_margin;
+    /* [U] btCollisionDispatcher::getNewManifold: with CD_USE_RELATIVE_CONTACT_BREAKING_THRESHOLD (the dispatcher's
+     * default flags) a manifold's breaking threshold is gContactBreakingThreshold x the smaller of the two shapes'
+     * getAngularMotionDisc() = |centre| + radius of the bounding sphere btCollisionShape::getBoundingSphere takes from
+     * the shape's AABB.  A link's collider is a btCompoundShape with one child (the cylinder's hull, margin included in
+     * the AABB) 0.0183 m from the link's inertial frame along z (snake.urdf:807,813,863,869: both link kinds); the
+     * plane's and the obstacle box's discs are larger, so every pair of this world gets the link's value. */
+    {
+        const double ax = 0.026 + mg, az = 0.033 / 2 + mg;
+        const double disc = 0.0183 + std::sqrt(ax * ax + ax * ax + az * az);
+        e->break_thr = (Real)(P.relative_breaking_threshold ? P.breaking_threshold * disc : P.breaking_threshold);
+    }
 
     /* [U] Bullet import rule: inertia from the collision compound's AABB box
      * (btCompoundShape::calculateLocalInertia).  Half extents: the hull's cached local
@@ -690,11 +704,11 @@ void find_contacts_stateless(orc_env* e) {
             Real w[3];
             mat3_vec(Rw, loc, w);
             Contact c;
-            c.link = i; c.linkB = -1; c.mu = 0; c.kind = 0;
+            c.link = i; c.linkB = -1; c.mu = 0; c.kind = 0; c.mpoint = -1;
             c.n[0] = 0; c.n[1] = 0; c.n[2] = 1; c.PB[0] = c.PB[1] = c.PB[2] = 0;
             for (int r = 0; r < 3; r++) c.P[r] = e->ow[3 * i + r] + w[r];
             c.dist = c.P[2];
-            if (c.dist < (Real)P.breaking_threshold) e->contacts.push_back(c);
+            if (c.dist < e->break_thr) e->contacts.push_back(c);
         }
     }
 }
@@ -728,7 +742,7 @@ int manifold_sort_cached(const Manifold& m, const ManifoldPoint& pt) {
 
 void find_contacts_manifold(orc_env* e) {
     const orc_params& P = e->P;
-    const Real thr = (Real)P.breaking_threshold;
+    const Real thr = e->break_thr;
     e->contacts.clear();
     if ((int)e->manifolds.size() != e->L) {
         Manifold z;
@@ -742,6 +756,29 @@ void find_contacts_manifold(orc_env* e) {
         const Real* Rw = &e->Rw[9 * i];
         const Real* o = &e->ow[3 * i];
         Real dl[3] = {-Rw[6], -Rw[7], -Rw[8]};   /* plane normal, negated, in link coords (unit) */
+        /* A link's collider is a btCompoundShape (one child: the cylinder's hull), so btCompoundCollisionAlgorithm::
+         * processCollision first refreshes the child's manifold from the new pose -- refreshContactPoints: positions and
+         * distances, then removal (last to first) of what lifted off or drifted -- and only then the child's
+         * convex-plane algorithm adds this step's point [U] (its own refresh afterwards changes nothing more). */
+        Real wa[4][3];
+        for (int j = 0; j < m.n; j++) {
+            mat3_vec(Rw, m.p[j].localA, wa[j]);
+            for (int r = 0; r < 3; r++) wa[j][r] += o[r];
+            m.p[j].dist = wa[j][2] - m.p[j].worldB[2];
+        }
+        for (int j = m.n - 1; j >= 0; j--) {
+            bool drop = !(m.p[j].dist <= thr);
+            if (!drop) {
+                Real dx = m.p[j].worldB[0] - wa[j][0], dy = m.p[j].worldB[1] - wa[j][1];
+                Real dz = m.p[j].worldB[2] - (wa[j][2] - m.p[j].dist);
+                drop = dx * dx + dy * dy + dz * dz > thr * thr;
+            }
+            if (drop) {
+                int last = m.n - 1;
+                if (j != last) { m.p[j] = m.p[last]; for (int r = 0; r < 3; r++) wa[j][r] = wa[last][r]; }
+                m.n--;
+            }
+        }
         /* support vertex towards the plane (localGetSupportingVertex: vertex + margin * direction) */
         Real v[3];
         if (P.hull_sides > 0) {
@@ -764,6 +801,7 @@ void find_contacts_manifold(orc_env* e) {
         Real w[3];
         mat3_vec(Rw, np.localA, w);
         np.dist = o[2] + w[2];
+        np.lambda = 0;
         if (np.dist < thr) {
             np.worldB[0] = o[0] + w[0]; np.worldB[1] = o[1] + w[1]; np.worldB[2] = 0;   /* projection onto the plane */
             /* getCacheEntry: nearest cached point (in link coordinates) closer than the threshold */
@@ -774,33 +812,18 @@ void find_contacts_manifold(orc_env* e) {
                 Real dd = dot3(d, d);
                 if (dd < shortest) { shortest = dd; nearest = j; }
             }
-            if (nearest >= 0) m.p[nearest] = np;
-            else if (m.n < 4) m.p[m.n++] = np;
-            else m.p[manifold_sort_cached(m, np)] = np;
-        }
-        /* refreshContactPoints: positions and distances from the current pose, then removal (last to first) */
-        Real wa[4][3];
-        for (int j = 0; j < m.n; j++) {
-            mat3_vec(Rw, m.p[j].localA, wa[j]);
-            for (int r = 0; r < 3; r++) wa[j][r] += o[r];
-            m.p[j].dist = wa[j][2] - m.p[j].worldB[2];
-        }
-        for (int j = m.n - 1; j >= 0; j--) {
-            bool drop = !(m.p[j].dist <= thr);
-            if (!drop) {
-                Real dx = m.p[j].worldB[0] - wa[j][0], dy = m.p[j].worldB[1] - wa[j][1];
-                Real dz = m.p[j].worldB[2] - (wa[j][2] - m.p[j].dist);
-                drop = dx * dx + dy * dy + dz * dz > thr * thr;
-            }
-            if (drop) {
-                int last = m.n - 1;
-                if (j != last) { m.p[j] = m.p[last]; for (int r = 0; r < 3; r++) wa[j][r] = wa[last][r]; }
-                m.n--;
-            }
+            /* btPersistentManifold::replaceContactPoint keeps the cached point's applied impulse; a point that is added
+             * (or that evicts another one, addManifoldPoint -> sortCachedPoints) starts at zero [U] */
+            int where;
+            if (nearest >= 0) { np.lambda = m.p[nearest].lambda; where = nearest; }
+            else if (m.n < 4) where = m.n++;
+            else where = manifold_sort_cached(m, np);
+            m.p[where] = np;
+            for (int r = 0; r < 3; r++) wa[where][r] = o[r] + w[r];
         }
         for (int j = 0; j < m.n; j++) {
             Contact c;
-            c.link = i; c.linkB = -1; c.mu = 0; c.kind = 0;
+            c.link = i; c.linkB = -1; c.mu = 0; c.kind = 0; c.mpoint = j;
             c.n[0] = 0; c.n[1] = 0; c.n[2] = 1; c.PB[0] = c.PB[1] = c.PB[2] = 0;
             for (int r = 0; r < 3; r++) c.P[r] = wa[j][r];
             c.dist = m.p[j].dist;
@@ -975,7 +998,7 @@ void find_self_contacts(orc_env* e) {
     std::vector<int> cyl;
     for (int i = 0; i < e->L; i++)
         if (e->links[i].has_cyl) cyl.push_back(i);
-    const Real mg = (Real)P.collision_margin, thr = (Real)P.breaking_threshold;
+    const Real mg = (Real)P.collision_margin, thr = e->break_thr;
     const Real rb = std::sqrt(e->cyl_r * e->cyl_r + e->cyl_len * e->cyl_len / 4) + mg;
     Real mu = (Real)(P.mu_link * P.mu_link);
     if (mu > 10) mu = 10;
@@ -1004,7 +1027,7 @@ void find_self_contacts(orc_env* e) {
                 mgx = mg + (Real)kShrink;
             }
             Contact c;
-            c.link = cv[a].link; c.linkB = cv[b].link; c.mu = mu; c.kind = 1;
+            c.link = cv[a].link; c.linkB = cv[b].link; c.mu = mu; c.kind = 1; c.mpoint = -1;
             if (dist < 0) {
                 Real nn = std::sqrt(dot3(d, d));
                 for (int r = 0; r < 3; r++) {
@@ -1027,7 +1050,7 @@ void find_self_contacts(orc_env* e) {
 void find_obstacle_contacts(orc_env* e) {
     const orc_params& P = e->P;
     static const Real Rid[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-    const Real mg = (Real)P.collision_margin, thr = (Real)P.breaking_threshold;
+    const Real mg = (Real)P.collision_margin, thr = e->break_thr;
     Convex box;
     box.e = e; box.link = -1; box.R = Rid; box.shrink = 0; box.box = 1;
     for (int r = 0; r < 3; r++) { box.c[r] = (Real)P.obstacle_pos[r]; box.half[r] = (Real)P.obstacle_half[r]; }
@@ -1055,7 +1078,7 @@ void find_obstacle_contacts(orc_env* e) {
             mgx = mg + (Real)kShrink;
         }
         Contact c;
-        c.link = i; c.linkB = -1; c.mu = mu; c.kind = 2;
+        c.link = i; c.linkB = -1; c.mu = mu; c.kind = 2; c.mpoint = -1;
         c.PB[0] = c.PB[1] = c.PB[2] = 0;
         if (dist < 0) {
             Real nn = std::sqrt(dot3(d, d));
@@ -1073,12 +1096,46 @@ void find_obstacle_contacts(orc_env* e) {
 void find_contacts(orc_env* e) {
     if (e->P.contact_model == 1) find_contacts_manifold(e);
     else find_contacts_stateless(e);
-    if (e->P.max_contacts > 0 && (int)e->contacts.size() > e->P.max_contacts) e->contacts.resize(e->P.max_contacts);
+    if (e->P.max_contacts > 0 && (int)e->contacts.size() > e->P.max_contacts) {
+        /* Test-only mirror of the product's slot limit (Bullet has none; the product counts what it leaves out:
+         * snk_contact_overflow).  Which points keep their rows: every cylinder's deepest point first, in cylinder
+         * order, then every cylinder's second deepest, ... until the slots are used up (ties: manifold order); the
+         * kept points stay in manifold order.  A point without rows carries no impulse. */
+        const int nc0 = (int)e->contacts.size();
+        std::vector<int> rank(nc0, 0), keep(nc0, 0);
+        for (int a0 = 0; a0 < nc0;) {
+            int a1 = a0;
+            while (a1 < nc0 && e->contacts[a1].link == e->contacts[a0].link) a1++;
+            for (int i = a0; i < a1; i++)
+                for (int j = a0; j < a1; j++)
+                    if (e->contacts[j].dist < e->contacts[i].dist || (e->contacts[j].dist == e->contacts[i].dist && j < i)) rank[i]++;
+            a0 = a1;
+        }
+        int room = e->P.max_contacts;
+        for (int pass = 0; pass < 4 && room > 0; pass++)
+            for (int i = 0; i < nc0 && room > 0; i++)
+                if (rank[i] == pass) { keep[i] = 1; room--; }
+        std::vector<Contact> kept;
+        for (int i = 0; i < nc0; i++) {
+            const Contact& c = e->contacts[i];
+            if (keep[i]) kept.push_back(c);
+            else if (c.mpoint >= 0) e->manifolds[c.link].p[c.mpoint].lambda = 0;
+        }
+        e->contacts.swap(kept);
+    }
     size_t before = e->contacts.size();
     if (e->P.self_collision) find_self_contacts(e);
+    const size_t n_self = e->contacts.size() - before;
     if (e->P.obstacle) find_obstacle_contacts(e);
-    if (e->P.max_self_contacts > 0 && e->contacts.size() > before + (size_t)e->P.max_self_contacts)
-        e->contacts.resize(before + e->P.max_self_contacts);
+    const size_t n_ob = e->contacts.size() - before - n_self;
+    if (e->P.max_self_contacts > 0 && n_self + n_ob > (size_t)e->P.max_self_contacts) {
+        /* (test-only mirror of the product's room for these contacts) the obstacle's contacts are kept before the
+         * link-link ones; the order of the rows stays ground, link-link, obstacle */
+        const size_t cap = (size_t)e->P.max_self_contacts;
+        const size_t keep_ob = n_ob < cap ? n_ob : cap, keep_self = n_self < cap - keep_ob ? n_self : cap - keep_ob;
+        e->contacts.erase(e->contacts.begin() + before + n_self + keep_ob, e->contacts.end());
+        e->contacts.erase(e->contacts.begin() + before + keep_self, e->contacts.begin() + before + n_self);
+    }
 }
 
 void apply_dv(orc_env* e, const Real* dvec, Real mult) {
@@ -1237,6 +1294,10 @@ void substep(orc_env* e, const Real* targets) {
         else poserr = -pen * (Real)P.contact_erp / dt;
         finish_row(row, velerr + poserr);
         row.lo = 0; row.hi = Real(1e10);
+        /* warm starting (SOLVER_USE_WARMSTARTING as btSequentialImpulseConstraintSolver does it; disabled in Bullet's
+         * multibody solver [U], hence a switch): the row starts at factor x the impulse its cached point carried */
+        if (P.warm_start && c.mpoint >= 0)
+            row.applied = e->manifolds[c.link].p[c.mpoint].lambda * (Real)P.warmstarting_factor;
         normals.push_back(row);
         /* two friction directions from btPlaneSpace1(n) ((0,-1,0), (1,0,0) for the ground's n = (0,0,1)),
          * each scaled by the link's anisotropic friction in link axes:
@@ -1278,6 +1339,10 @@ void substep(orc_env* e, const Real* targets) {
 
     /* (5) projected Gauss-Seidel (btMultiBodyConstraintSolver::solveSingleIteration [U]) */
     std::vector<Real> dv(nd, 0);
+    if (P.warm_start)
+        for (int ci = 0; ci < nc; ci++)
+            if (normals[ci].applied != 0)
+                for (int i = 0; i < nd; i++) dv[i] += normals[ci].M[i] * normals[ci].applied;
     int iters = 0;
     for (int it = 0; it < P.n_iterations; it++) {
         Real lsq = 0;
@@ -1355,6 +1420,7 @@ void substep(orc_env* e, const Real* targets) {
             ext.push_back(fb);
         }
         e->last_normal_impulse[ci] = normals[ci].applied;
+        if (c.mpoint >= 0) e->manifolds[c.link].p[c.mpoint].lambda = normals[ci].applied;   /* m_appliedImpulse */
     }
     velocities(e, e->omega, e->vel, e->qd.data());
     bias_forces(e, true, true, false, &ext);
@@ -1421,7 +1487,7 @@ void orc_default_params(orc_params* p) {
     p->inertia_from_file = 0;
     p->default_mass = 1.0;
     p->collision_margin = 0.001;
-    p->hull_sides = 0;   /* implicit cylinder: see find_contacts and DESIGN.md §3 */
+    p->hull_sides = 32;  /* PyBullet's import of a URDF <cylinder> [U]: find_contacts, DESIGN.md §3 (0: implicit cylinder) */
     p->max_contacts = 0;
     p->self_collision = 0;   /* 1 = link-link contacts (URDF_USE_SELF_COLLISION, snake.py:93); tests switch it on */
     p->max_self_contacts = 0;
@@ -1429,7 +1495,7 @@ void orc_default_params(orc_params* p) {
     p->obstacle_pos[0] = 2.0; p->obstacle_pos[1] = 0.0; p->obstacle_pos[2] = 0.1;      /* snake.py:94 */
     p->obstacle_half[0] = 0.1; p->obstacle_half[1] = 0.4; p->obstacle_half[2] = 0.1;   /* snake/block.urdf:16 */
     p->mu_obstacle = 0.5;
-    p->contact_model = 0;/* stateless two-point manifold (default here); 1 = Bullet's persistent manifold [U] */
+    p->contact_model = 1;/* Bullet's persistent manifold [U]; 0 = the stateless two-point manifold of round 1 */
     p->dt = 1.0 / 240.0;
     p->gravity_z = -9.8;
     p->lin_damping = 0.04;
@@ -1448,9 +1514,12 @@ void orc_default_params(orc_params* p) {
     p->contact_erp = 0.08;
     p->linear_slop = 1e-5;
     p->breaking_threshold = 0.02;
+    p->relative_breaking_threshold = 1;
     p->cone_friction = 1;
     p->n_iterations = 50;
     p->residual_threshold = 1e-7;
+    p->warm_start = 0;
+    p->warmstarting_factor = 0.85;
     p->scaling_factor = kPi / 6.0;
     p->gait = 1;
     p->servo_tol = 0.05;
@@ -1518,19 +1587,22 @@ void orc_hard_reset(orc_env* e) {
     e->manifolds.clear();    /* resetSimulation + loadURDF: a new world (a soft reset keeps the contact cache [U]) */
 }
 
-/* contact cache, per cylinder in link order: [count, 4 x (point on the link in link coords 3, point on the ground 3)] */
-int32_t orc_manifold_floats(const orc_env* e) { return 2 * e->n * 25; }
+/* contact cache, per cylinder in link order: [count, 4 x (point on the link in link coords 3, point on the ground 3,
+ * applied normal impulse)] */
+int32_t orc_manifold_floats(const orc_env* e) { return 2 * e->n * 29; }
 void orc_get_manifold(const orc_env* e, double* out) {
     int c = 0;
     for (int i = 0; i < e->L; i++) {
         if (!e->links[i].has_cyl) continue;
-        double* o = out + 25 * c++;
-        for (int r = 0; r < 25; r++) o[r] = 0;
+        double* o = out + 29 * c++;
+        for (int r = 0; r < 29; r++) o[r] = 0;
         if ((int)e->manifolds.size() != e->L) continue;
         const Manifold& m = e->manifolds[i];
         o[0] = m.n;
-        for (int j = 0; j < m.n; j++)
-            for (int r = 0; r < 3; r++) { o[1 + 6 * j + r] = m.p[j].localA[r]; o[4 + 6 * j + r] = m.p[j].worldB[r]; }
+        for (int j = 0; j < m.n; j++) {
+            for (int r = 0; r < 3; r++) { o[1 + 7 * j + r] = m.p[j].localA[r]; o[4 + 7 * j + r] = m.p[j].worldB[r]; }
+            o[7 + 7 * j] = m.p[j].lambda;
+        }
     }
 }
 void orc_set_manifold(orc_env* e, const double* in) {
@@ -1540,11 +1612,13 @@ void orc_set_manifold(orc_env* e, const double* in) {
     int c = 0;
     for (int i = 0; i < e->L; i++) {
         if (!e->links[i].has_cyl) continue;
-        const double* o = in + 25 * c++;
+        const double* o = in + 29 * c++;
         Manifold& m = e->manifolds[i];
         m.n = (int)o[0];
-        for (int j = 0; j < m.n; j++)
-            for (int r = 0; r < 3; r++) { m.p[j].localA[r] = (Real)o[1 + 6 * j + r]; m.p[j].worldB[r] = (Real)o[4 + 6 * j + r]; }
+        for (int j = 0; j < m.n; j++) {
+            for (int r = 0; r < 3; r++) { m.p[j].localA[r] = (Real)o[1 + 7 * j + r]; m.p[j].worldB[r] = (Real)o[4 + 7 * j + r]; }
+            m.p[j].lambda = (Real)o[7 + 7 * j];
+        }
     }
 }
 

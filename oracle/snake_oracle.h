@@ -39,13 +39,14 @@ typedef struct orc_params {
     int32_t inertia_from_file;/* 0: Bullet default, inertia from collision AABB [U]      */
     double  default_mass;     /* mass given to links without <inertial> [U] = 1          */
     double  collision_margin; /* gUrdfDefaultCollisionMargin [U] = 0.001                 */
-    int32_t hull_sides;       /* 0 = implicit cylinder (default here); 32 = PyBullet's
-                               * default 32-gon hull import [U] (rocks with a 2-point manifold) */
-    int32_t contact_model;    /* 0 = stateless: both end-cap points of every cylinder, every step (default here);
-                               * 1 = Bullet's persistent manifold [U]: one new support point per cylinder per
-                               *     step merged into a cache of <= 4, refreshed / dropped at breaking_threshold */
+    int32_t hull_sides;       /* 32 (default) = PyBullet's 32-gon hull import of a URDF <cylinder> [U] (snake.py:93 passes
+                               * no URDF_USE_IMPLICIT_CYLINDER); 0 = implicit cylinder (the round-1 model)       */
+    int32_t contact_model;    /* 1 (default) = Bullet's persistent manifold [U]: one new support point per cylinder
+                               *     per step merged into a cache of <= 4, refreshed / dropped at the breaking threshold;
+                               * 0 = stateless: both end-cap points of every cylinder, every step (the round-1 model) */
     int32_t max_contacts;     /* 0 = no limit; > 0: only the first max_contacts points (in manifold order) get
-                               * rows -- mirrors the product's structural limit of 4n contacts (tests only)   */
+                               * rows -- mirrors the product's structural limit of 4n contacts (tests only; the
+                               * product counts what it drops: snk_contact_overflow)                           */
     int32_t self_collision;   /* 1: link-link contacts of non-adjacent cylinder links (URDF_USE_SELF_COLLISION,
                                * snake.py:93 [U]) for any chain length; 0 (default of this test tool): none.
                                * For the 16-link snake the rows are speculative only and never carry an impulse
@@ -77,10 +78,20 @@ typedef struct orc_params {
     double  contact_erp;      /* solver m_erp2 [U] (PyBullet sets 0.08? default 0.2)     */
     double  linear_slop;      /* PyBullet m_linearSlop 1e-5 [U]                          */
     double  breaking_threshold;/* gContactBreakingThreshold 0.02 [U]                     */
+    int32_t relative_breaking_threshold; /* 1 (default): btCollisionDispatcher's CD_USE_RELATIVE_CONTACT_BREAKING_THRESHOLD
+                               * [U], on by default in Bullet: a manifold's threshold is breaking_threshold x the smaller
+                               * angular-motion disc of its two shapes (|AABB centre| + AABB half diagonal of a link's
+                               * compound: 0.0603 m -> 1.206 mm); 0: breaking_threshold itself                     */
     int32_t cone_friction;    /* 1: implicit cone on the 2 friction rows [U]; 0: pyramid */
     /* solver */
     int32_t n_iterations;     /* numSolverIterations 50 [U]                              */
     double  residual_threshold;/* m_leastSquaresResidualThreshold 1e-7 [U]; 0 = never exit */
+    int32_t warm_start;       /* 0 (default): btMultiBodyConstraintSolver starts every contact row at zero impulse [U]
+                               * (setupMultiBodyContactConstraint has its warm start disabled); 1: SOLVER_USE_WARMSTARTING
+                               * as the rigid-body solver does it -- a cached point's normal row starts at
+                               * warmstarting_factor x the impulse it carried last step, delta-v starts at
+                               * sum M^-1 J^T of those; friction rows start at zero.  contact_model 1 only             */
+    double  warmstarting_factor; /* btContactSolverInfo m_warmstartingFactor 0.85 [U]     */
     /* task (snake.py / SnakeGymEnv.py) */
     double  scaling_factor;   /* snake.py:63  pi/6                                       */
     int32_t gait;             /* snake.py:62  1 -> odd slots                             */
@@ -123,8 +134,9 @@ double   orc_mean_height(orc_env* e);                 /* snake.py:237-245 (value
 double   orc_joint3_reaction_fz(const orc_env* e);
 
 /* contact cache of contact_model 1, per cylinder in link order:
- * [count, 4 x (point on the link in link coordinates 3, point on the ground in world coordinates 3)] */
-int32_t  orc_manifold_floats(const orc_env* e);                 /* 2n * 25 */
+ * [count, 4 x (point on the link in link coordinates 3, point on the ground in world coordinates 3, the normal impulse
+ *  the point carried in the last substep: btManifoldPoint::m_appliedImpulse)] */
+int32_t  orc_manifold_floats(const orc_env* e);                 /* 2n * 29 */
 void     orc_get_manifold(const orc_env* e, double* out);
 void     orc_set_manifold(orc_env* e, const double* in);
 

@@ -41,6 +41,7 @@ def test_c5_env_step_parity_friction_config(pkg, oracle_mod):
     dones = 0
     for j in range(J):
         S, X = st.get_state()
+        Mf = st.get_manifold()
         a = bench.gait_actions(ids, j).astype(np.float32)
         obs, rew, done, sub = st.step(a.copy(), vec_mode=True)
         dones += int(done.sum())
@@ -48,8 +49,7 @@ def test_c5_env_step_parity_friction_config(pkg, oracle_mod):
             band = "high" if mu32[i] > 1.25 else "low"
             out = []
             for e in (refs[i], refs32[i]):
-                e.set_state(S[i].astype(np.float64))
-                e.set_aux(X[i, :n].astype(np.float64), float(X[i, n]), float(X[i, n + 1]))
+                e.sync(S[i], X[i], None if Mf is None else Mf[i])
                 out.append(e.env_step(a[i].astype(np.float64), vec_mode=True))
             (o, r, d, k, _), (o32, r32, d32, k32, _) = out
 
@@ -208,6 +208,7 @@ def test_env_step_parity_random_actions(pkg, oracle_mod, n):
     mism = cal_mism = compared = 0
     for j in range(J):
         S, X = st.get_state()
+        Mf = st.get_manifold()
         a = rng.uniform(-1.5, 1.5, (B, A)).astype(np.float32)
         a_in = a.copy()
         obs, rew, done, sub = st.step(a_in, vec_mode=True)
@@ -215,8 +216,7 @@ def test_env_step_parity_random_actions(pkg, oracle_mod, n):
         for i in range(B):
             out = []
             for e in (refs[i], refs32[i]):
-                e.set_state(S[i].astype(np.float64))
-                e.set_aux(X[i, :n].astype(np.float64), float(X[i, n]), float(X[i, n + 1]))
+                e.sync(S[i], X[i], None if Mf is None else Mf[i])
                 out.append(e.env_step(a[i].astype(np.float64), vec_mode=True))
             (o, r, d, k, _), (o32, r32, d32, k32, _) = out
 
@@ -264,10 +264,10 @@ def test_env_step_parity_random_actions(pkg, oracle_mod, n):
 
 
 @pytest.mark.parametrize("over", [dict(n_modules=16), dict(n_modules=32, self_collision=0),
-                                  dict(n_modules=32), dict(n_modules=32, hull_sides=32, contact_model=1),
+                                  dict(n_modules=32), dict(n_modules=32, hull_sides=0, contact_model=0),
                                   dict(n_modules=16, obstacle=1, obstacle_pos=[0.25, 0.0, 0.1]),
-                                  dict(n_modules=16, obstacle=1, obstacle_pos=[0.25, 0.0, 0.1], hull_sides=32, contact_model=1),
-                                  dict(n_modules=16, hull_sides=32, contact_model=1)])
+                                  dict(n_modules=16, obstacle=1, obstacle_pos=[0.25, 0.0, 0.1], hull_sides=0, contact_model=0),
+                                  dict(n_modules=16, hull_sides=0, contact_model=0), dict(n_modules=16, warm_start=1)])
 def test_outputs_do_not_depend_on_what_ran_before(pkg, over):
     """Every output of a step -- observation incl. the force sensor, reward, done, substep count, the joint-3 read-out --
     is a function of state and action only: two handles, one created after kernels of ANOTHER configuration have run on

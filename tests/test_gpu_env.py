@@ -47,16 +47,15 @@ def test_env_step_parity_resynced(pkg, oracle_mod, n):
     mism = 0
     for j in range(J):
         S, X = st.get_state()
+        Mf = st.get_manifold()
         a = gait(range(B), j, A)
         obs, rew, done, sub = st.step(a.copy(), vec_mode=False)
         for i in range(B):
             e = refs[i]
-            e.set_state(S[i].astype(np.float64))
-            e.set_aux(X[i, :n].astype(np.float64), float(X[i, n]), float(X[i, n + 1]))
+            e.sync(S[i], X[i], None if Mf is None else Mf[i])
             o, r, d, k, _ = e.env_step(a[i].astype(np.float64), vec_mode=False)
             # calibration: the float32 build of the oracle on the same step
-            ref32.set_state(S[i].astype(np.float64))
-            ref32.set_aux(X[i, :n].astype(np.float64), float(X[i, n]), float(X[i, n + 1]))
+            ref32.sync(S[i], X[i], None if Mf is None else Mf[i])
             o32, r32, d32, k32, _ = ref32.env_step(a[i].astype(np.float64), vec_mode=False)
             if k32 == k and d32 == d:
                 cal["q"] = max(cal["q"], np.abs(o32[:n] - o[:n]).max(), np.abs(o32[3 * n:3 * n + 7] - o[3 * n:3 * n + 7]).max())
@@ -330,8 +329,8 @@ def test_test_mode_telemetry(pkg, oracle_mod):
     for j in range(3):
         a = gait(range(1), j, 8)[0].astype(np.float64) * 1.3       # some components get clipped
         S, X = env._stepper.get_state()
-        ref.set_state(S[0].astype(np.float64))
-        ref.set_aux(X[0, :16].astype(np.float64), float(X[0, 16]), float(X[0, 17]))
+        Mf = env._stepper.get_manifold()
+        ref.sync(S[0], X[0], None if Mf is None else Mf[0])
         obs, rew, done, info = env.step(a.copy())
         k = env.robot.counter
         assert set(info) == {"frames", "internal_observations", "link_positions"} and info["frames"] == []
@@ -371,14 +370,14 @@ def test_env_step_variants(pkg, oracle_mod, variant):
     compared = 0
     for j in range(3):
         S, X = st.get_state()
+        Mf = st.get_manifold()
         a = rng.uniform(-1.2, 1.2, (B, A)).astype(np.float32)
         a_in = a.copy()
         obs, rew, done, sub = st.step(a, vec_mode=False)
         assert np.array_equal(a, np.clip(a_in, -1, 1))                  # clipped in place
         for i in range(B):
             e = refs[i]
-            e.set_state(S[i].astype(np.float64))
-            e.set_aux(X[i, :16].astype(np.float64), float(X[i, 16]), float(X[i, 17]))
+            e.sync(S[i], X[i], None if Mf is None else Mf[i])
             o, r, d, k, _ = e.env_step(a_in[i].astype(np.float64), vec_mode=False)
             if k != sub[i] or d != bool(done[i]):
                 assert abs(k - sub[i]) <= 1 or _near_threshold(o, a[i], 16, e)
@@ -480,22 +479,30 @@ def test_sensor_pass_only_when_observable(pkg, n):
     for j in range(6 if n == 16 else 3):
         a = gait_actions(np.arange(B), j, A).astype(np.float32) if j % 2 == 0 else rng.uniform(-1, 1, (B, A)).astype(np.float32)
         S, X = st.get_state()
+        Mf = st.get_manifold()                                           # the contact cache is simulator state too
         obs, rew, done, sub = st.step(a.copy(), vec_mode=False)          # terminal obs even when done
         # replay with the substep API: group envs by their substep count
         T = np.zeros((B, n), np.float32)
         T[:, 1::2] = np.clip(a, -1, 1) * np.float32(np.pi / 6)
         rp.set_state(S, X)
+        if Mf is not None:
+            rp.set_manifold(Mf)
         left = sub.copy()
         # advance all envs together; an env that is finished is restored afterwards (it must not move)
         final = {}
         for k in range(int(sub.max())):
             Sb, Xb = rp.get_state()
+            Mb = rp.get_manifold()
             rp.substep(T, 1)
             Sa, Xa = rp.get_state()
             stop = left <= 0
             if stop.any():
                 Sa[stop], Xa[stop] = Sb[stop], Xb[stop]
                 rp.set_state(Sa, Xa)
+                if Mb is not None:
+                    Ma = rp.get_manifold()
+                    Ma[stop] = Mb[stop]
+                    rp.set_manifold(Ma)
             left -= 1
         _, Xf = rp.get_state()
         moved = sub > 0

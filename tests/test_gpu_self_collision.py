@@ -125,13 +125,15 @@ def test_self_collision_switch_and_gait_invariance(pkg):
     assert np.abs(out[0][0] - out[1][0]).max() > 1e-3
 
 
-def test_sixteen_link_self_contacts_are_inert_in_the_oracle(oracle_mod):
-    """The product builds no link-link rows for 16 links.  The oracle can: over a gait rollout with the flag on, the
-    rows exist (bends above ~18 deg bring neighbouring cylinders within the breaking threshold) and every one of them
-    keeps a zero impulse, so the results equal those without the flag."""
+@pytest.mark.parametrize("relative", [1, 0])
+def test_sixteen_link_self_contacts_are_inert_in_the_oracle(oracle_mod, relative):
+    """The product builds no link-link rows for 16 links.  The oracle can: over a gait rollout with the flag on, under
+    the dispatcher's relative breaking threshold (1.2 mm, the default) no pair ever comes close enough for a row; with
+    the absolute 0.02 m the rows exist (bends above ~18 deg bring neighbouring cylinders within the threshold) and
+    every one of them keeps a zero impulse.  Either way the results equal those without the flag."""
     import bench
-    a_env = oracle_mod.OracleEnv(self_collision=1)
-    b_env = oracle_mod.OracleEnv(self_collision=0)
+    a_env = oracle_mod.OracleEnv(self_collision=1, relative_breaking_threshold=relative)
+    b_env = oracle_mod.OracleEnv(self_collision=0, relative_breaking_threshold=relative)
     a_env.reset(); b_env.reset()
     seen = 0
     for j in range(12):
@@ -143,4 +145,4 @@ def test_sixteen_link_self_contacts_are_inert_in_the_oracle(oracle_mod):
             seen += 1
             extra = a_env.last_normal_impulses(512)[b_env.last_num_contacts:]
             assert np.all(extra == 0.0)
-    assert seen > 0
+    assert (seen == 0) if relative else (seen > 0)

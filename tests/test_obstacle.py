@@ -35,17 +35,18 @@ def test_oracle_box_stops_the_snake_and_trips_the_wall_signal(oracle_mod):
 
 
 @gpu
-@pytest.mark.parametrize("n,model", [(16, "default"), (32, "default"), (32, "bullet")])
+@pytest.mark.parametrize("n,model", [(16, "default"), (32, "default"), (16, "round1"), (32, "round1")])
 def test_obstacle_env_step_parity(pkg, oracle_mod, n, model):
-    """model "bullet": everything at once on the streamed-row path -- 32-gon hulls, persistent ground manifolds (the
-    cache is handed to the oracle with the state), link-link contacts and the box."""
+    """model "default": everything at once -- 32-gon hulls, persistent ground manifolds (the cache is handed to the
+    oracle with the state), link-link contacts (32 links) and the box; "round1": the stateless two-point manifold on
+    implicit cylinders."""
     import bench
     B, J = 8, 6
     A = n // 2
     ids = np.arange(B)
     over = dict(BOX, n_modules=n)
-    if model == "bullet":
-        over.update(hull_sides=32, contact_model=1)
+    if model == "round1":
+        over.update(hull_sides=0, contact_model=0)
     st = pkg.Stepper(B, **over)
     st.reset()
     sc = 1 if n == 32 else 0                       # what the kernels evaluate for this chain length

@@ -168,16 +168,25 @@ def test_motor_row_free_space(oracle_mod):
     assert np.all(np.isfinite(tau)) and np.abs(tau).max() > 0
 
 
-def test_rest_on_plane_supports_weight(oracle_mod):
-    e = oracle_mod.OracleEnv()
-    for _ in range(480):
+@pytest.mark.parametrize("model", ["default", "round1"])
+def test_rest_on_plane_supports_weight(oracle_mod, model):
+    """default: hulls + persistent manifolds at the relative threshold -- a resting snake ends with all four cached
+    points of every cylinder (vertices 5 mm apart no longer merge at a 1.2-mm threshold) and the 50 unconverged sweeps
+    over 128 contacts leave a jitter of a few tenths of a newton: the MEAN over the last 60 substeps carries the
+    weight.  round1: two end-cap points per cylinder."""
+    over = dict(hull_sides=0, contact_model=0) if model == "round1" else {}
+    e = oracle_mod.OracleEnv(**over)
+    totals = []
+    for k in range(480):
         e.substep(np.zeros(16))
-    total = e.last_normal_impulses().sum() * 240.0
-    assert abs(total - 21.296 * 9.8) < 0.5
+        if k >= 420:
+            totals.append(e.last_normal_impulses().sum() * 240.0)
+    assert abs(np.mean(totals) - 21.296 * 9.8) < 0.5
+    assert np.abs(np.array(totals) - 21.296 * 9.8).max() < (0.5 if model == "round1" else 2.0)
     s = e.get_state()
     assert np.abs(s[7:13]).max() < 1e-2 and np.abs(s[13:29]).max() < 1e-3
     assert abs(s[2]) < 2e-3                      # sinks ~1 mm (margin) and stays
-    assert e.last_num_contacts == 64             # 32 cylinders x 2 end points
+    assert e.last_num_contacts == (64 if model == "round1" else 128)      # 32 cylinders x 2 end points / x 4 cached points
 
 
 def test_anisotropic_friction_ratio(oracle_mod):
