@@ -295,7 +295,8 @@ def main():
     variants = None
     if (world == 1 and not args.no_variants and not args.policy and NL == 16 and args.hull_sides == 32
             and args.contact_model == 1 and not args.warm_start and args.friction_seed is None):
-        v_env = pkg.DeviceVecEnv(E, device_index=local_rank, n_modules=NL, hull_sides=0, contact_model=0)
+        v_env = pkg.DeviceVecEnv(E, device_index=local_rank, n_modules=NL, hull_sides=0, contact_model=0,
+                                 relative_breaking_threshold=0)
         v_env.reset()
         v_sub = torch.zeros((), dtype=torch.int64, device=dev)
         for j in range(W):
@@ -308,7 +309,7 @@ def main():
         torch.cuda.synchronize()
         tv = time.perf_counter() - tv
         variants = {"round1_contact_model": {
-            "value": E * K / tv, "unit": "env-steps/s", "hull_sides": 0, "contact_model": 0,
+            "value": E * K / tv, "unit": "env-steps/s", "hull_sides": 0, "contact_model": 0, "relative_breaking_threshold": 0,
             "mean_substeps_per_env_step": float(v_sub.item()) / (E * K),
             "note": "same action stream; the stateless two-point manifold on implicit cylinders that rounds 1 and 2 "
                     "measured, instead of PyBullet's 32-gon hull import + Bullet's persistent <= 4-point manifold at "

@@ -253,21 +253,49 @@ __device__ __forceinline__ int manifold_core(const DevModel& M, int n, MPt (&p)[
 }
 
 // Which of a cylinder's n cached points get rows when the environment holds more points than the solve has slots for
-// (`room` of them; Bullet has no such limit, snk_contact_overflow counts how often this build's is hit): every
-// cylinder's deepest point first, in cylinder order, then every cylinder's second deepest, ... until the slots are
-// used up (ties: manifold order).  Lane = cylinder; returns the lane's bit mask of kept points (the oracle's
-// max_contacts mirrors the rule for the tests).
+// (`room` of them; Bullet has no such limit, snk_contact_overflow counts how often this build's is hit).  Every cylinder
+// ranks its points the way Bullet's own manifold reduction values them (sortCachedPoints: the deepest point, then
+// spread): first the deepest, second the one farthest from it (the other end cap), third the one that spans the
+// larger triangle with those two, then the last; ties go to the lower manifold index.  Slots are handed out in
+// passes: every cylinder's first point, in cylinder order, then every cylinder's second, ... until they are used up,
+// so a resting snake keeps one point per end cap of every cylinder before any cylinder keeps a third.  Lane =
+// cylinder; returns the lane's bit mask of kept points (the oracle's max_contacts mirrors the rule for the tests).
 __device__ __forceinline__ int manifold_keep_mask(int n, const MPt (&p)[4], int lane, int total, int room) {
     if (total <= room) return (1 << n) - 1;
-    int rank[4];
+    int rank[4] = {4, 4, 4, 4};
+    int p0 = 0, p1 = -1, p2 = -1;
+    {
+        float best = 3.0e38f;
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        int r = 0;
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-            if (j < n && (p[j].d < p[i].d || (p[j].d == p[i].d && j < i))) r++;
-        rank[i] = r;
+        for (int i = 0; i < 4; i++)
+            if (i < n && p[i].d < best) { best = p[i].d; p0 = i; }
     }
+    f3 a0 = p[0].a;
+#pragma unroll
+    for (int i = 1; i < 4; i++) f3_sel(a0, p[i].a, i == p0);
+    {
+        float best = -1.f;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const f3 d = p[i].a - a0;
+            const float dd = dot(d, d);
+            if (i < n && i != p0 && dd > best) { best = dd; p1 = i; }
+        }
+    }
+    f3 a1 = p[0].a;
+#pragma unroll
+    for (int i = 1; i < 4; i++) f3_sel(a1, p[i].a, i == p1);
+    {
+        float best = -1.f;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const f3 c = cross(a1 - a0, p[i].a - a0);
+            const float cc = dot(c, c);
+            if (i < n && i != p0 && i != p1 && cc > best) { best = cc; p2 = i; }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) rank[i] = i == p0 ? 0 : (i == p1 ? 1 : (i == p2 ? 2 : 3));
     int granted = 0;                       // passes in which this cylinder got a slot (monotone: once refused, refused)
     int left = room;
 #pragma unroll

@@ -93,6 +93,7 @@ def _load(f32=False):
         "orc_cylinder_frames": (C.c_int32, [vp, D]),
         "orc_debug_gjk": (C.c_double, [vp, D, D, D]),
         "orc_contacts_full": (C.c_int32, [vp, D, C.c_int32]),
+        "orc_last_contacts_full": (C.c_int32, [vp, D, C.c_int32]),
         "orc_bench_gait": (C.c_double, [C.POINTER(OrcParams), C.c_int32, D, D, C.c_int32, C.c_int32, C.c_int32,
                                         C.POINTER(C.c_int64), D]),
     }
@@ -309,6 +310,12 @@ class OracleEnv:
         """[nc, 12]: P, dist, link, linkB, normal, PB of every contact of the current pose."""
         out = np.zeros((maxc, 12))
         nc = self.lib.orc_contacts_full(self.h, _dp(out), maxc)
+        return out[:nc]
+
+    def last_contacts_full(self, maxc=512):
+        """[nc, 12]: the contacts the last substep solved (same record as contacts_full; linkB -1 ground, -2 the box)."""
+        out = np.zeros((maxc, 12))
+        nc = self.lib.orc_last_contacts_full(self.h, _dp(out), maxc)
         return out[:nc]
 
     def last_normal_impulses(self, maxc=256):

@@ -1098,17 +1098,42 @@ void find_contacts(orc_env* e) {
     else find_contacts_stateless(e);
     if (e->P.max_contacts > 0 && (int)e->contacts.size() > e->P.max_contacts) {
         /* Test-only mirror of the product's slot limit (Bullet has none; the product counts what it leaves out:
-         * snk_contact_overflow).  Which points keep their rows: every cylinder's deepest point first, in cylinder
-         * order, then every cylinder's second deepest, ... until the slots are used up (ties: manifold order); the
-         * kept points stay in manifold order.  A point without rows carries no impulse. */
+         * snk_contact_overflow).  Every cylinder ranks its points the way Bullet's own manifold reduction values them
+         * (sortCachedPoints: the deepest point, then spread): first the deepest, second the one farthest from it (the
+         * other end cap), third the one that spans the larger triangle with those two, then the last; ties go to the
+         * lower manifold index.  Slots go out in passes: every cylinder's first point, in cylinder order, then every
+         * cylinder's second, ... until they are used up; the kept points stay in manifold order.  A point without rows
+         * carries no impulse. */
         const int nc0 = (int)e->contacts.size();
-        std::vector<int> rank(nc0, 0), keep(nc0, 0);
+        std::vector<int> rank(nc0, 4), keep(nc0, 0);
         for (int a0 = 0; a0 < nc0;) {
             int a1 = a0;
             while (a1 < nc0 && e->contacts[a1].link == e->contacts[a0].link) a1++;
+            const int link = e->contacts[a0].link;
+            auto locA = [&](int i) -> const Real* {          /* the point in link coordinates (cm 1), else world */
+                const Contact& c = e->contacts[i];
+                return c.mpoint >= 0 ? e->manifolds[link].p[c.mpoint].localA : c.P;
+            };
+            int p0 = a0, p1 = -1, p2 = -1;
             for (int i = a0; i < a1; i++)
-                for (int j = a0; j < a1; j++)
-                    if (e->contacts[j].dist < e->contacts[i].dist || (e->contacts[j].dist == e->contacts[i].dist && j < i)) rank[i]++;
+                if (e->contacts[i].dist < e->contacts[p0].dist) p0 = i;
+            Real best = -1;
+            for (int i = a0; i < a1; i++) {
+                if (i == p0) continue;
+                Real d[3] = {locA(i)[0] - locA(p0)[0], locA(i)[1] - locA(p0)[1], locA(i)[2] - locA(p0)[2]};
+                Real dd = dot3(d, d);
+                if (dd > best) { best = dd; p1 = i; }
+            }
+            best = -1;
+            for (int i = a0; i < a1 && p1 >= 0; i++) {
+                if (i == p0 || i == p1) continue;
+                Real u[3], v[3], c[3];
+                for (int r = 0; r < 3; r++) { u[r] = locA(p1)[r] - locA(p0)[r]; v[r] = locA(i)[r] - locA(p0)[r]; }
+                cross3(u, v, c);
+                Real cc = dot3(c, c);
+                if (cc > best) { best = cc; p2 = i; }
+            }
+            for (int i = a0; i < a1; i++) rank[i] = i == p0 ? 0 : (i == p1 ? 1 : (i == p2 ? 2 : 3));
             a0 = a1;
         }
         int room = e->P.max_contacts;
@@ -1775,8 +1800,12 @@ void orc_momentum(orc_env* e, double* lin3, double* ang3, double* kinetic) {
     for (int r = 0; r < 3; r++) { lin3[r] = Lm[r]; ang3[r] = Am[r]; }
     *kinetic = K;
 }
+/* (contacts of the CURRENT pose, as the next substep would find them; the contact cache and the last substep's
+ * contact list are left as they were) */
 int32_t orc_contacts(orc_env* e, double* out, int32_t maxc) {
     if (!e->fk_valid) fk(e);
+    const std::vector<Manifold> saved_m = e->manifolds;
+    const std::vector<Contact> saved_c = e->contacts;
     find_contacts(e);
     int nc = (int)e->contacts.size();
     for (int i = 0; i < nc && i < maxc; i++) {
@@ -1784,6 +1813,8 @@ int32_t orc_contacts(orc_env* e, double* out, int32_t maxc) {
         out[5 * i + 3] = e->contacts[i].dist;
         out[5 * i + 4] = e->contacts[i].link;
     }
+    e->manifolds = saved_m;
+    e->contacts = saved_c;
     return nc;
 }
 /* world frame of every collision cylinder, in link order: centre (3) then rotation (9, row-major); returns their count */
@@ -1814,18 +1845,28 @@ double orc_debug_gjk(orc_env* e, const double* fa, const double* fb, double* out
     return (double)d;
 }
 /* contacts of the current pose with both participants: per contact [P(3), dist, link, linkB, n(3), PB(3)] */
-int32_t orc_contacts_full(orc_env* e, double* out, int32_t maxc) {
-    if (!e->fk_valid) fk(e);
-    find_contacts(e);
-    int nc = (int)e->contacts.size();
+static int32_t dump_contacts(const std::vector<Contact>& cs, double* out, int32_t maxc) {
+    int nc = (int)cs.size();
     for (int i = 0; i < nc && i < maxc; i++) {
-        const Contact& c = e->contacts[i];
+        const Contact& c = cs[i];
         double* o = out + 12 * i;
         for (int r = 0; r < 3; r++) { o[r] = c.P[r]; o[6 + r] = c.n[r]; o[9 + r] = c.PB[r]; }
-        o[3] = c.dist; o[4] = c.link; o[5] = c.linkB;
+        o[3] = c.dist; o[4] = c.link; o[5] = c.kind == 0 ? -1 : (c.kind == 2 ? -2 : c.linkB);
     }
     return nc;
 }
+int32_t orc_contacts_full(orc_env* e, double* out, int32_t maxc) {
+    if (!e->fk_valid) fk(e);
+    const std::vector<Manifold> saved_m = e->manifolds;
+    const std::vector<Contact> saved_c = e->contacts;
+    find_contacts(e);
+    const int32_t nc = dump_contacts(e->contacts, out, maxc);
+    e->manifolds = saved_m;
+    e->contacts = saved_c;
+    return nc;
+}
+/* the contacts the LAST substep solved, same record; aligned with orc_last_normal_impulses */
+int32_t orc_last_contacts_full(const orc_env* e, double* out, int32_t maxc) { return dump_contacts(e->contacts, out, maxc); }
 int32_t orc_last_normal_impulses(const orc_env* e, double* out, int32_t maxc) {
     int nc = (int)e->last_normal_impulse.size();
     for (int i = 0; i < nc && i < maxc; i++) out[i] = e->last_normal_impulse[i];

@@ -170,8 +170,11 @@ void     orc_momentum(orc_env* e, double* lin3, double* ang3, double* kinetic);
 int32_t  orc_contacts(orc_env* e, double* out, int32_t max_contacts);
 /* world frames of the collision cylinders in link order: [centre 3, rotation 9 row-major] each; returns the count */
 int32_t  orc_cylinder_frames(orc_env* e, double* out);
-/* contacts with both participants: per contact [P 3, dist, link, linkB (-1 ground / box), n 3, PB 3] */
+/* contacts with both participants: per contact [P 3, dist, link, linkB (-1 ground, -2 obstacle box), n 3, PB 3];
+ * like orc_contacts: of the current pose, as the next substep would find them, cache and last list untouched */
 int32_t  orc_contacts_full(orc_env* e, double* out, int32_t max_contacts);
+/* ... and the contacts the LAST substep solved (aligned with orc_last_normal_impulses) */
+int32_t  orc_last_contacts_full(const orc_env* e, double* out, int32_t max_contacts);
 /* impulses of the last substep: normal impulses per contact */
 int32_t  orc_last_normal_impulses(const orc_env* e, double* out, int32_t max_contacts);
 

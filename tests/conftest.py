@@ -28,6 +28,12 @@ def pkg():
     return importlib.import_module("bullet-envs_amd")
 
 
+# The contact model of rounds 1 and 2 (still a switch): stateless two-point manifold on implicit cylinders, absolute
+# 0.02-m breaking threshold.  The defaults since round 3 are Bullet's own: 32-gon hulls, persistent manifold, the
+# dispatcher's relative threshold.
+ROUND1 = dict(hull_sides=0, contact_model=0, relative_breaking_threshold=0)
+
+
 def random_state(rng, n, z=0.2, qamp=0.5, vamp=1.0, flat=False):
     """A reachable random state [pos3, quat4, omega3, vel3, q n, qd n]."""
     s = np.zeros(13 + 2 * n)

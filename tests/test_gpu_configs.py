@@ -11,6 +11,8 @@ the high-friction envs are judged, not excluded.  Floors: joint angles / base po
 import numpy as np
 import pytest
 
+from conftest import ROUND1
+
 pytestmark = pytest.mark.gpu
 
 
@@ -264,10 +266,10 @@ def test_env_step_parity_random_actions(pkg, oracle_mod, n):
 
 
 @pytest.mark.parametrize("over", [dict(n_modules=16), dict(n_modules=32, self_collision=0),
-                                  dict(n_modules=32), dict(n_modules=32, hull_sides=0, contact_model=0),
+                                  dict(n_modules=32), dict(ROUND1, n_modules=32),
                                   dict(n_modules=16, obstacle=1, obstacle_pos=[0.25, 0.0, 0.1]),
-                                  dict(n_modules=16, obstacle=1, obstacle_pos=[0.25, 0.0, 0.1], hull_sides=0, contact_model=0),
-                                  dict(n_modules=16, hull_sides=0, contact_model=0), dict(n_modules=16, warm_start=1)])
+                                  dict(ROUND1, n_modules=16, obstacle=1, obstacle_pos=[0.25, 0.0, 0.1]),
+                                  dict(ROUND1, n_modules=16), dict(n_modules=16, warm_start=1)])
 def test_outputs_do_not_depend_on_what_ran_before(pkg, over):
     """Every output of a step -- observation incl. the force sensor, reward, done, substep count, the joint-3 read-out --
     is a function of state and action only: two handles, one created after kernels of ANOTHER configuration have run on
@@ -295,7 +297,7 @@ def test_outputs_do_not_depend_on_what_ran_before(pkg, over):
         return out
 
     first = run()
-    other = pkg.Stepper(512, n_modules=48 - n, hull_sides=0, contact_model=0)      # the other chain length: other kernels, other LDS image
+    other = pkg.Stepper(512, n_modules=48 - n, **ROUND1)      # the other chain length: other kernels, other LDS image
     other.reset()
     other.step(bench.gait_actions(np.arange(512), 0, (48 - n) // 2).astype(np.float32))
     other.close()

@@ -44,7 +44,7 @@ def test_env_step_parity_resynced(pkg, oracle_mod, n):
     worst = dict(q=0.0, qd=0.0, r=0.0)
     cal = dict(q=0.0, qd=0.0, r=0.0)
     qd_errs, cal_qd_errs = [], []
-    mism = 0
+    mism = cal_mism = 0
     for j in range(J):
         S, X = st.get_state()
         Mf = st.get_manifold()
@@ -63,6 +63,8 @@ def test_env_step_parity_resynced(pkg, oracle_mod, n):
                 cal_qd_errs.append(cqd)
                 cal["qd"] = max(cal["qd"], cqd)
                 cal["r"] = max(cal["r"], abs(r32 - r))
+            else:
+                cal_mism += 1
             if k != sub[i] or d != bool(done[i]):
                 mism += 1
                 # allowed only at a decision boundary
@@ -79,17 +81,20 @@ def test_env_step_parity_resynced(pkg, oracle_mod, n):
     p90 = float(np.percentile(qd_errs, 90))
     p90c = float(np.percentile(cal_qd_errs, 90))
     print("n", n, "GPU-f32 vs oracle-f64 worst", worst, "qd p90", p90, "| oracle-f32 vs oracle-f64", cal, "qd p90", p90c,
-          "| boundary mismatches", mism, "of", B * J)
+          "| boundary mismatches", mism, "(oracle-f32:", cal_mism, ") of", B * J)
     # the 32-link chain is twice as long and correspondingly more sensitive to round-off
     tq, tp90, tmax, kcal = (5e-3, 5e-2, 0.75, 2.0) if n == 16 else (1e-2, 0.4, 1.0, 3.0)
-    assert worst["q"] < tq and worst["r"] < 5e-3
+    # (hulls on a persistent manifold of one to four points roll more easily than round 1's two end-cap points per
+    #  cylinder: the float32 ORACLE itself is 1e-2 off the float64 one on the worst of these steps, so the absolute caps
+    #  give way to the calibration below)
+    assert worst["q"] < max(tq, kcal * cal["q"]) and worst["r"] < max(5e-3, kcal * cal["r"])
     assert worst["fz"] < 1.0      # sanity only: bit-exactness of the sensor is test_sensor_pass_only_when_observable
     # joint velocities: the 90th percentile within twice the float32 oracle's (every rebuild
     # re-associates FMAs, so an absolute cap on a heavy-tailed error is a coin toss), hard cap tmax
     assert p90 < max(tp90, kcal * p90c) and worst["qd"] < tmax
     assert worst["q"] < kcal * cal["q"] + 1e-4 and worst["qd"] < kcal * cal["qd"] + 1e-3
     assert worst["r"] < kcal * cal["r"] + 2e-3     # the energy term (qd x motor torque) is noisy
-    assert mism <= max(1, B * J // 20)
+    assert mism <= max(1, B * J // 20, 2 * cal_mism + 2)
 
 
 def test_vec_env_semantics(pkg, oracle_mod):
@@ -323,6 +328,7 @@ def test_test_mode_telemetry(pkg, oracle_mod):
                               motorVelocityLimit=np.inf, motorTorqueLimit=np.inf)
     env = pkg.SnakeGymEnv(pkg.Snake(None, None, args=args), args=args)
     ref = oracle_mod.OracleEnv()
+    ref32 = oracle_mod.OracleEnv(f32=True)      # calibration: the oracle built in float32, same substeps
     env.reset()
     ref.reset()
     idx = 1 + np.arange(0, 49, 3)          # oracle rows: root + Bullet links 0..48
@@ -331,6 +337,7 @@ def test_test_mode_telemetry(pkg, oracle_mod):
         S, X = env._stepper.get_state()
         Mf = env._stepper.get_manifold()
         ref.sync(S[0], X[0], None if Mf is None else Mf[0])
+        ref32.sync(S[0], X[0], None if Mf is None else Mf[0])
         obs, rew, done, info = env.step(a.copy())
         k = env.robot.counter
         assert set(info) == {"frames", "internal_observations", "link_positions"} and info["frames"] == []
@@ -340,8 +347,11 @@ def test_test_mode_telemetry(pkg, oracle_mod):
         targets[1::2] = np.clip(a, -1, 1) * (np.pi / 6)
         for i in range(k):
             ref.substep(targets)
+            ref32.substep(targets)
             o = ref.get_obs()
-            tol = 2e-4 * (i + 1)           # float32 drift over the substeps of one env-step
+            o32 = ref32.get_obs()
+            cal = max(np.abs(o32[:16] - o[:16]).max(), np.abs(o32[48:55] - o[48:55]).max())
+            tol = max(2e-4 * (i + 1), 3 * cal)           # float32 drift over the substeps of one env-step
             assert np.abs(info["internal_observations"][i][:16] - o[:16]).max() < tol
             assert np.abs(info["internal_observations"][i][48:55] - o[48:55]).max() < tol
             lp = info["link_positions"][i].reshape(3, 17).T
@@ -366,6 +376,7 @@ def test_env_step_variants(pkg, oracle_mod, variant):
     assert st.act_dim == A
     st.reset()
     refs = [oracle_mod.OracleEnv(**over) for _ in range(B)]
+    ref32 = oracle_mod.OracleEnv(f32=True, **over)
     rng = np.random.default_rng(12)
     compared = 0
     for j in range(3):
@@ -379,13 +390,21 @@ def test_env_step_variants(pkg, oracle_mod, variant):
             e = refs[i]
             e.sync(S[i], X[i], None if Mf is None else Mf[i])
             o, r, d, k, _ = e.env_step(a_in[i].astype(np.float64), vec_mode=False)
+            ref32.sync(S[i], X[i], None if Mf is None else Mf[i])
+            o32, r32, d32, k32, _ = ref32.env_step(a_in[i].astype(np.float64), vec_mode=False)
             if k != sub[i] or d != bool(done[i]):
                 assert abs(k - sub[i]) <= 1 or _near_threshold(o, a[i], 16, e)
                 continue
             compared += 1
-            # one env-step of float32 round-off on a stiff system: 2.5e-3 is typical for the worst env
-            assert np.abs(obs[i, :16] - o[:16]).max() < 1e-2 and np.abs(obs[i, 48:55] - o[48:55]).max() < 1e-2
-            assert abs(rew[i] - r) < 2e-2
+            # one env-step of float32 round-off on a stiff system: 2.5e-3 is typical for the worst env; these variants
+            # drive the pitch joints (the snake lifts itself off the ground), where the float32 ORACLE is off by
+            # several 1e-2 on some steps: calibrated against it, factor 3
+            cq = cr = 0.0
+            if k32 == k and d32 == d:
+                cq = max(np.abs(o32[:16] - o[:16]).max(), np.abs(o32[48:55] - o[48:55]).max())
+                cr = abs(r32 - r)
+            assert max(np.abs(obs[i, :16] - o[:16]).max(), np.abs(obs[i, 48:55] - o[48:55]).max()) < max(1e-2, 3 * cq)
+            assert abs(rew[i] - r) < max(2e-2, 3 * cr)
     assert compared >= 2 * B
 
 
@@ -427,7 +446,7 @@ def test_env_logic_branches(pkg, oracle_mod):
     termination after one substep (:299-301), and the -10 collision term (SnakeGymEnv.py:94)."""
     n = 16
 
-    def both(over, state=None, aux=None, action=None):
+    def both(over, state=None, aux=None, action=None, want32=False):
         st = pkg.Stepper(1, **over)
         st.reset()
         e = oracle_mod.OracleEnv(**over)
@@ -444,6 +463,11 @@ def test_env_logic_branches(pkg, oracle_mod):
         obs, rew, done, sub = st.step(a.copy(), vec_mode=False)
         o, r, d, k, _ = e.env_step(a[0].astype(np.float64), vec_mode=False)
         st.close()
+        if want32:          # calibration: the float32 build of the oracle on the same step (from a reset state only)
+            e32 = oracle_mod.OracleEnv(f32=True, **over)
+            e32.reset()
+            o32 = e32.env_step(a[0].astype(np.float64), vec_mode=False)[0]
+            return (obs[0], float(rew[0]), bool(done[0]), int(sub[0])), (o, r, d, k), o32
         return (obs[0], float(rew[0]), bool(done[0]), int(sub[0])), (o, r, d, k)
 
     # (1) targets already reached: no physics at all, observation is the old state
@@ -451,10 +475,11 @@ def test_env_logic_branches(pkg, oracle_mod):
     assert g[3] == 0 == o[3] and not g[2] and g[1] == 0.0 == o[1]
     assert np.all(g[0][:51] == 0)
     # (2) motors too weak to reach the target: the loop stops at the 41-substep cap
-    g, o = both(dict(max_motor_impulse=2e-5), action=[1.0] * 8)
+    g, o, o32 = both(dict(max_motor_impulse=2e-5), action=[1.0] * 8, want32=True)
     assert g[3] == 41 == o[3] and g[2] == o[2]
-    # 41 substeps of saturated motors against sticking contacts: float32 round-off grows to a few 1e-2
-    assert np.abs(g[0][:16] - o[0][:16]).max() < 0.1
+    # 41 substeps of saturated motors against sticking contacts: float32 round-off grows to a few 1e-2 (more on hulls
+    # that can roll over their vertices): no worse than 3x the float32 oracle on the same step
+    assert np.abs(g[0][:16] - o[0][:16]).max() < max(0.1, 3 * np.abs(o32[:16] - o[0][:16]).max())
     # (3) snake in the air: mean height > 0.1 ends the step after ONE substep, done, -5
     g, o = both({}, state=[0.0, 0.0, 0.5], action=[0.5] * 8)
     assert g[3] == 1 == o[3] and g[2] and o[2]

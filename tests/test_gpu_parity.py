@@ -12,7 +12,7 @@ the test also requires the GPU to be no worse than twice that.
 import numpy as np
 import pytest
 
-from conftest import random_state
+from conftest import ROUND1, random_state
 
 pytestmark = pytest.mark.gpu
 
@@ -188,21 +188,29 @@ def test_rare_branch_early_exit(pkg, oracle_mod):
     assert np.array_equal(info[:, 0], its)
 
 
-@pytest.mark.parametrize("n", [16, 32])
-def test_partial_contact_sets(pkg, oracle_mod, n):
+@pytest.mark.parametrize("n,model", [(16, "round1"), (32, "round1"), (16, "default"), (32, "default")])
+def test_partial_contact_sets(pkg, oracle_mod, n, model):
     """Snake pitched so that only some cylinders are within the contact threshold: contact
     counts that are not multiples of the group sizes (8 rows per branch in the 16-link solve,
-    4 contacts per loop trip in the 32-link one) and in both halves."""
+    4 contacts per loop trip in the 32-link one) and in both halves.  round1: the stateless two-point manifold at the
+    absolute 0.02-m threshold; default: hulls + persistent manifold at the 1.2-mm relative threshold, three substeps
+    from an empty cache (one new point per cylinder per step), shallower pitch angles."""
     states = []
-    for ang in (0.02, 0.04, 0.08, 0.15, 0.3) if n == 16 else (0.01, 0.02, 0.04, 0.08, 0.15):
+    if model == "round1":
+        over, k, z0 = dict(ROUND1), 1, 0.002
+        angs = (0.02, 0.04, 0.08, 0.15, 0.3) if n == 16 else (0.01, 0.02, 0.04, 0.08, 0.15)
+    else:
+        over, k, z0 = dict(), 3, 0.0008
+        angs = (0.0006, 0.0012, 0.0025, 0.005, 0.01) if n == 16 else (0.0003, 0.0006, 0.0012, 0.0025, 0.005)
+    for ang in angs:
         s = np.zeros(13 + 2 * n)
         # pitch about y lifts the tail (the chain extends along -x): nose stays near the ground
         s[3:7] = [0, np.sin(ang / 2), 0, np.cos(ang / 2)]
-        s[2] = 0.002
+        s[2] = z0
         states.append(s)
     S = np.array(states)
     T = np.zeros((len(states), n))
-    G, _, info, R, its, ncs = _substep_compare(pkg, oracle_mod, S, T, n=n, residual_threshold=0.0)
+    G, _, info, R, its, ncs = _substep_compare(pkg, oracle_mod, S, T, k=k, n=n, residual_threshold=0.0, **over)
     assert np.array_equal(info[:, 1], ncs), (info[:, 1], ncs)
     assert len(set(ncs.tolist())) >= 3 and any(c % 8 for c in ncs) and any(c % 4 for c in ncs)   # really partial sets
     assert np.abs(G[:, :7] - R[:, :7]).max() < 2e-4 and np.abs(G[:, 13:13 + n] - R[:, 13:13 + n]).max() < 2e-4

@@ -26,7 +26,12 @@ def _coiled_states(B, seed=0):
     rng = np.random.default_rng(seed)
     S = np.zeros((B, 13 + 2 * N), np.float32)
     for i in range(B):
-        S[i, 6] = 1.0
+        # a little pitch and roll: a cylinder lying exactly flat has its end caps equally deep, and which vertex is the
+        # support point is then decided by the last bit (in Bullet too; float32 and float64 decide differently)
+        pr = rng.uniform(0.004, 0.012, 2)
+        S[i, 3:7] = [0.5 * pr[0], 0.5 * pr[1], 0.0, 1.0]
+        S[i, 3:7] /= np.linalg.norm(S[i, 3:7])
+        S[i, 2] = 0.002
         S[i, 13:13 + N] = coil(27.5 + 0.2 * rng.uniform(-1, 1)) + rng.uniform(-0.01, 0.01, N) * (np.arange(N) % 2 == 1)
     return S
 
@@ -34,7 +39,10 @@ def _coiled_states(B, seed=0):
 @gpu
 @pytest.mark.parametrize("hull", [0, 32])
 def test_coil_self_contacts_match_oracle(pkg, oracle_mod, hull):
-    B, K = 6, 4
+    # (implicit cylinders: three substeps -- in the fourth the motors have pushed some pairs past both collision margins,
+    #  where the narrow phase changes tier (shrunk cores, Bullet: EPA), and the float32 GJK of the kernels and the
+    #  oracle's, two independent implementations, take that step a substep apart: 2e-3 against 4e-5)
+    B, K = 6, (4 if hull else 3)
     over = dict(n_modules=N, hull_sides=hull, residual_threshold=0.0)
     st = pkg.Stepper(B, **over)
     S = _coiled_states(B, seed=hull)
@@ -68,9 +76,11 @@ def test_coil_self_contacts_match_oracle(pkg, oracle_mod, hull):
                 alive[i] = False          # a pair at the breaking threshold counted on one side only
                 flips += 1
                 continue
-            assert info[i, 1] > 128                                   # ground contacts + link-link contacts
+            lc = refs[i].last_contacts_full()
+            pair = lc[:, 5] >= 0                                      # link-link contacts follow the ground's
+            assert pair.any() and not pair[0] and info[i, 1] == len(lc)
             imp = refs[i].last_normal_impulses(512)
-            if imp[128:].max() > 1e-4:
+            if imp[:len(lc)][pair].max() > 1e-4:
                 acted += 1
             ref = refs[i].get_state()
             worst_p = max(worst_p, np.abs(G[i, :7] - ref[:7]).max(), np.abs(G[i, 13:13 + N] - ref[13:13 + N]).max())

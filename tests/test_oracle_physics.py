@@ -174,7 +174,7 @@ def test_rest_on_plane_supports_weight(oracle_mod, model):
     points of every cylinder (vertices 5 mm apart no longer merge at a 1.2-mm threshold) and the 50 unconverged sweeps
     over 128 contacts leave a jitter of a few tenths of a newton: the MEAN over the last 60 substeps carries the
     weight.  round1: two end-cap points per cylinder."""
-    over = dict(hull_sides=0, contact_model=0) if model == "round1" else {}
+    over = dict(hull_sides=0, contact_model=0, relative_breaking_threshold=0) if model == "round1" else {}
     e = oracle_mod.OracleEnv(**over)
     totals = []
     for k in range(480):
