@@ -164,7 +164,9 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=2000,
                     help="env-steps of the CPU baseline (BASELINE.md B3: 2000 after 20 warm-up steps)")
     ap.add_argument("--streamed-rows", action="store_true",
-                    help="diagnostic: 16 links on the streamed-row solve (the obstacle kernels, the box parked 50 m away)")
+                    help="diagnostic: 16 links on the streamed-row solve (SNK_FORCE_STREAMED=1)")
+    ap.add_argument("--obstacle", type=float, default=None, metavar="X",
+                    help="not a BASELINE config: the block of snake_gait_test.py:51 (static) with its centre at x = X")
     ap.add_argument("--no-variants", action="store_true",
                     help="skip the extra measurement of the round-1 contact model (1 GPU, default configuration only)")
     ap.add_argument("--policy", action="store_true",
@@ -207,9 +209,13 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    extra = dict(obstacle=1, obstacle_pos=[50.0, 0.0, 0.1]) if args.streamed_rows else {}
+    extra = {}
+    if args.streamed_rows:
+        os.environ["SNK_FORCE_STREAMED"] = "1"           # read by snk_create
     if args.warm_start:
         extra["warm_start"] = 1
+    if args.obstacle is not None:
+        extra.update(obstacle=1, obstacle_pos=[args.obstacle, 0.0, 0.1])
     local = pkg.DeviceVecEnv(E, device_index=local_rank, n_modules=NL, hull_sides=args.hull_sides,
                              contact_model=args.contact_model, self_collision=args.self_collision, **extra)
     if args.friction_seed is not None:      # configs[4]: this rank's shard of the per-env plane friction
@@ -331,7 +337,8 @@ def main():
         cfg_key = ("c%d" % NL) + ("_fric" if args.friction_seed is not None else "") + ("_policy" if args.policy else "") + (
             "_hull%d_cm%d" % (args.hull_sides, args.contact_model) if (args.hull_sides != 32 or args.contact_model != 1) else "") + (
             "_warm" if args.warm_start else "") + (
-            "_nosc" if (NL == 32 and not args.self_collision) else "") + ("_streamed" if args.streamed_rows else "")
+            "_nosc" if (NL == 32 and not args.self_collision) else "") + ("_streamed" if args.streamed_rows else "") + (
+            "_obstacle" if args.obstacle is not None else "")
         traffic, traffic_src, valu = None, None, None
         try:
             import glob

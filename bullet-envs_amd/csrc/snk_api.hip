@@ -241,7 +241,9 @@ int init_handle(snk_handle* h, const snk_params* p, int32_t n_envs, int32_t devi
     snk::build_host_model(*p, h->H);
     snk::build_dev_model(*p, h->H, h->D);
     h->rec = h->D.rec_floats;
-    h->v2 = h->n == 16 && !p->obstacle;        // the register-resident solve has no slot for obstacle contacts
+    // 16 links: the register-resident solve (the obstacle's contacts take slots out of the ground's 64).
+    // SNK_FORCE_STREAMED=1 (diagnostics, tests): the streamed-row kernels for a 16-link handle too
+    h->v2 = h->n == 16 && getenv("SNK_FORCE_STREAMED") == nullptr;
     h->lds_bytes = h->n == 16 ? (h->v2 ? sizeof(snk::Lds<16, true>) : sizeof(snk::Lds<16, false>)) : sizeof(snk::Lds<32, false>);
     int rc = SNK_DISPATCH(h, set_lds_attr, h->lds_bytes);
     if (rc) return rc;
@@ -289,6 +291,11 @@ int init_handle(snk_handle* h, const snk_params* p, int32_t n_envs, int32_t devi
         sc.cap = 2u;                                  // power of two >= 2 n_envs: slot = ticket & (cap - 1) survives the
         while (sc.cap < 2u * (uint32_t)n_envs) sc.cap <<= 1;      // wrap-around of the 32-bit tickets
         sc.quantum = quantum;
+        {
+            const char* hy = getenv("SNK_HYST");      // experiments: see snk_device.hpp Sched::hyst
+            sc.hyst = hy ? atoi(hy) : 3;
+            if (sc.hyst < 1) sc.hyst = 1;
+        }
         HIP_TRY(hipMalloc(&sc.head, sizeof(uint32_t)));
         HIP_TRY(hipMalloc(&sc.tail, sizeof(uint32_t)));
         HIP_TRY(hipMemset(sc.head, 0, sizeof(uint32_t)));
@@ -613,7 +620,6 @@ int snk_set_ground_friction(snk_handle* h, const float* mu) {
 
 int snk_joint3_reaction_fz(snk_handle* h, float* out) {
     if (!h || !out) return fail("snk_joint3_reaction_fz: null argument");
-    if (h->v2) return fail("snk_joint3_reaction_fz: evaluated by the streamed-row solve only (32 links, or an obstacle)");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipDeviceSynchronize());
     const size_t ne = (size_t)h->n_envs;

@@ -259,7 +259,8 @@ struct Lds<N, true> : LdsCommon<N, N> {
     // link forces of the constraint pass: columns 8..13 of the staging rows, which that pass uses in columns 0..5 only
     __device__ __forceinline__ float* ext(int b) { return &stM[b][8]; }
     float MmS[N][4];             // the motors' rhs, den, 1/den, target velocity change (their M^-1 rows are Mm)
-    float fz_park;               // first-pass part of the joint-0 force, parked across the solve
+    float fz_park, fz3_park;     // first-pass parts of the joint-0 force and of the first motor joint's reaction, parked across the solve
+    int nplane;                  // ground contacts of this substep (the obstacle's follow them in the compact list)
     // contacts of cylinder c: compact indices [cylbase[c], + cyln[c]); cylkeep[c]: which of its cached manifold points
     // they are (bit j = point j has rows; contact_model 1)
     unsigned char cylbase[2 * N], cyln[2 * N], cylkeep[2 * N];
@@ -1602,18 +1603,26 @@ __device__ __forceinline__ void substep(LT& L, const DevModel& M0, int lane_in, 
 // ----------------------------------------------------------------------------------
 // record <-> LDS, observation packing (snake.py:209-217)
 // ----------------------------------------------------------------------------------
+// The lane index as a value the compiler cannot see through: per-lane addresses built from it are computed where they
+// are used.  (Built from the kernel's own threadIdx.x they are loop-invariant, get hoisted in front of the servo loop and
+// stay live across it -- twenty VGPRs in round 3's first build, which the solve's row registers then paid for with
+// reloads from scratch memory inside the Gauss-Seidel loop.)
+__device__ __forceinline__ int launder_lane(int lane) {
+    asm volatile("" : "+v"(lane));
+    return lane;
+}
 template <class LT>
 __device__ __forceinline__ void load_rec(LT& L, const float* __restrict__ rec, int lane) {
     constexpr int N = LT::kN;
-#pragma unroll
+    lane = launder_lane(lane);
     for (int i = lane; i < LT::REC; i += 64) L.rec[i] = rec[i];
     lds_sync();
 }
 template <class LT>
 __device__ __forceinline__ void store_rec(LT& L, float* __restrict__ rec, int lane) {
     constexpr int N = LT::kN;
+    lane = launder_lane(lane);
     lds_sync();
-#pragma unroll
     for (int i = lane; i < LT::REC; i += 64) rec[i] = L.rec[i];
 }
 // The same store, write-through (sc1): the record leaves this XCD's L2 for memory at once, so a wave on another
@@ -1623,6 +1632,7 @@ __device__ __forceinline__ void store_rec(LT& L, float* __restrict__ rec, int la
 template <class LT>
 __device__ __forceinline__ void store_rec_through(LT& L, float* __restrict__ rec, int lane) {
     typedef float v4f __attribute__((ext_vector_type(4)));
+    lane = launder_lane(lane);
     lds_sync();
     if (lane < LT::REC / 4) {
         const v4f v = reinterpret_cast<const v4f*>(L.rec)[lane];
@@ -1636,6 +1646,7 @@ template <class LT>
 __device__ __forceinline__ void load_mf(LT& L, const float* __restrict__ mf, int lane) {
     if constexpr (LT::kV2) {
         if (mf) {
+            lane = launder_lane(lane);
             for (int i = lane; i < 2 * LT::kN * kMfFloats; i += 64) {
                 const int c = i / kMfFloats, f = i - c * kMfFloats;
                 const float v = mf[i];
@@ -1650,6 +1661,7 @@ template <class LT, bool THROUGH>
 __device__ __forceinline__ void store_mf(LT& L, float* __restrict__ mf, int lane) {
     if constexpr (LT::kV2) {
         if (mf) {
+            lane = launder_lane(lane);
             lds_sync();
             for (int i = lane; i < 2 * LT::kN * kMfFloats; i += 64) {
                 const int c = i / kMfFloats, f = i - c * kMfFloats;
@@ -1663,6 +1675,7 @@ __device__ __forceinline__ void store_mf(LT& L, float* __restrict__ mf, int lane
 template <class LT>
 __device__ __forceinline__ void write_obs(LT& L, float* __restrict__ obs, int lane) {
     constexpr int N = LT::kN;
+    lane = launder_lane(lane);
     // obs = [q, qd, tau_motor | pos3 quat4 | fz]; rec = [pos3 quat4 w3 v3 | q qd taum | fz px]
     for (int i = lane; i < 3 * N + 8; i += 64) {
         float x;
@@ -1675,6 +1688,7 @@ __device__ __forceinline__ void write_obs(LT& L, float* __restrict__ obs, int la
 template <class LT>
 __device__ __forceinline__ void soft_reset(LT& L, int lane) {
     constexpr int N = LT::kN;
+    lane = launder_lane(lane);
     // snake.py:96-99,119-127: base pose/twist and joint q, qd; motor-torque and sensor caches persist [U]
     for (int i = lane; i < 13 + 2 * N; i += 64) L.rec[i] = (i == 6) ? 1.0f : 0.0f;
 }
@@ -1955,6 +1969,11 @@ struct Sched {
     uint32_t cap;               // ring size: a power of two >= 2 n_envs (an env is queued at most once), so that the
                                 // slot of a ticket, tk & (cap - 1), stays consistent when the 32-bit tickets wrap
     int32_t quantum;            // substeps per slice
+    int32_t hyst;               // a slice's env-step is handed off when a waiting one has at least this many more substeps
+                                // left.  1 = strict longest-remaining-first: two env-steps of equal length then swap places
+                                // after every substep (each hand-off moves the record and the contact cache through
+                                // memory); 3 levels the finish times as well and hands off a third as often: measured
+                                // 336.6 k -> 342.7 k env-steps/s (1, 3, 4, 6, 8: 336.6 / 342.7 / 341.6 / 341.4 / 322.9)
     long long* wstat;           // SNK_SCHED_DEBUG: [grid][4] ticks waiting, ticks alive, slices, substeps
 };
 
@@ -2192,7 +2211,7 @@ __global__ __launch_bounds__(64, 2) void env_step_sched_kernel(int model_slot, f
 #ifdef SNK_SCHED_DEBUG
                 n_chk++; s_top += top; s_rem += remaining; if (top > remaining) n_req++;
 #endif
-                if (top > remaining) {
+                if (top >= remaining + sc.hyst) {
                     store_rec_through(L, rec, lane);
                     store_mf<LT, true>(L, env_mf, lane);        // the contact cache travels with the record
                     __hip_atomic_store(&sc.counter[env], counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

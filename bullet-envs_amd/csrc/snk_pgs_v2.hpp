@@ -375,10 +375,97 @@ __device__ __forceinline__ int lane_prefix3(int cnt, int lane, int& total) {
     return __popcll(b0 & below) + 2 * __popcll(b1 & below) + 4 * __popcll(b2 & below);
 }
 
+// Contacts with the obstacle box for the register-resident solve (lane = cylinder, the two-tier GJK of
+// snk_selfcol.hpp): at most LT::kObs of them (more are counted: snk_contact_overflow), appended behind the ground
+// contacts by find_contacts_v2.  The narrow phase runs BEFORE the ground contacts are compacted, because the slots the
+// box's contacts take come out of the ground's share (64 in all).
+struct ObsHit {
+    bool hit;
+    f3 P, n, dA, dB;
+    float dist;
+};
+template <class LT>
+__device__ __forceinline__ int find_obstacle_v2(LT& L, const DevModel& M, int lane, ObsHit& h,
+                                                unsigned long long* __restrict__ ovf) {
+    constexpr int N = LT::kN;
+    h.hit = false;
+    h.P = mk3(0, 0, 0); h.n = mk3(0, 0, 1); h.dA = mk3(0, 0, 0); h.dB = mk3(0, 0, 0);
+    h.dist = 0.f;
+    if (!M.obstacle) return 0;
+    const float rb = sqrtf(M.cyl_r * M.cyl_r + M.cyl_hl * M.cyl_hl) + M.margin;
+    Cvx Bx;
+    Bx.c = mk3(M.obs_c[0], M.obs_c[1], M.obs_c[2]);
+#pragma unroll
+    for (int i = 0; i < 9; i++) Bx.R[i] = (i % 4 == 0) ? 1.f : 0.f;
+    Bx.box = 1;
+    Bx.half = mk3(M.obs_h[0], M.obs_h[1], M.obs_h[2]);
+    const float rbox = sqrtf(dot(Bx.half, Bx.half));
+    const int a = lane < 2 * N ? lane : 2 * N - 1;
+    const int ba = (a + 1) >> 1;
+    const f3 ca = ld3(L.o[ba]) + mulRv(L.R[ba], ld3(M.cyl_c[a]));
+    const f3 d = ca - Bx.c;
+    const float reach_ob = rb + rbox + M.break_thr;
+    const bool cand = lane < 2 * N && dot(d, d) <= reach_ob * reach_ob;
+    if (!__any(cand)) return 0;
+    if (cand) {
+        Cvx A;
+        cyl_world_rot(L.R[ba], M.cyl_R[a], A.R);
+        A.c = ca;
+        A.box = 0;
+        A.half = mk3(0.f, 0.f, 0.f);
+        f3 pa, pb;
+        float mg = M.margin;
+        float dd = gjk_distance(M, A, Bx, 0.f, pa, pb);
+        if (dd < 0.f) {
+            dd = gjk_distance(M, A, Bx, kShrink, pa, pb);
+            mg = M.margin + kShrink;
+        }
+        if (dd < 0.f) {
+            const float nn = sqrtf(dot(d, d));
+            h.n = nn > 0.f ? d * (1.0f / nn) : mk3(-1.f, 0.f, 0.f);
+            h.P = A.c;
+            h.dist = -2.0f * mg;
+        } else {
+            h.n = (pa - pb) * (1.0f / dd);
+            h.dist = dd - 2.0f * mg;
+            h.P = pa - h.n * mg;
+        }
+        h.hit = h.dist < M.break_thr;
+        plane_space(h.n, h.dA, h.dB);
+        h.dA = aniso_scale(M, A.R, h.dA);
+        h.dB = aniso_scale(M, A.R, h.dB);
+    }
+    const int n_ob = __popcll(__ballot(h.hit));
+    if (n_ob > LT::kObs && lane == 0) atomicAdd(ovf + 2, (unsigned long long)(n_ob - LT::kObs));
+    return n_ob > LT::kObs ? LT::kObs : n_ob;
+}
+// ... and their records, behind the nplane ground contacts
+template <class LT>
+__device__ __forceinline__ void append_obstacle_v2(LT& L, int lane, const ObsHit& h, int nplane) {
+    constexpr int N = LT::kN;
+    const unsigned long long bal = __ballot(h.hit);
+    if (h.hit) {
+        const int k = __popcll(bal & ((1ull << lane) - 1ull));
+        if (k < LT::kObs) {
+            const int idx = nplane + k;
+            st3(L.ccP[idx], h.P);
+            L.ccdist[idx] = h.dist;
+            L.ccbody[idx] = (unsigned char)((lane + 1) >> 1);
+            L.ccds[idx] = (unsigned char)(2 * N + k);
+            st3(L.cdir[2 * N + k][0], h.dA);
+            st3(L.cdir[2 * N + k][1], h.dB);
+            st3(L.obn[k], h.n);
+            L.app[kAppNormal + idx] = 0.f;       // (no contact cache for the box's contacts: nothing to warm-start from)
+        }
+    }
+}
+
 template <class LT>
 __device__ int find_contacts_v2(LT& L, const DevModel& M, int lane, unsigned long long* __restrict__ ovf) {
     constexpr int N = LT::kN;
     static_assert(4 * N == 64, "one contact slot per lane");
+    ObsHit oh;
+    const int n_ob = find_obstacle_v2(L, M, lane, oh, ovf);      // 0 without an obstacle
     if (M.contact_model == 1) {
         // lane = cylinder; its manifold lives in LDS while this wave holds the environment (Lds<N, true>::mfl)
         int cnt = 0;
@@ -403,7 +490,7 @@ __device__ int find_contacts_v2(LT& L, const DevModel& M, int lane, unsigned lon
         }
         int total;
         (void)lane_prefix3(cnt, lane, total);
-        const int room = 4 * N;                      // the solve's contact slots
+        const int room = 4 * N - n_ob;               // the solve's contact slots, less the box's contacts
         const int mask = manifold_keep_mask(cnt, p, lane, total, room);
         const int kept = __popc(mask);
         int tk;
@@ -441,7 +528,9 @@ __device__ int find_contacts_v2(LT& L, const DevModel& M, int lane, unsigned lon
                 }
             }
         }
-        return tk;
+        if (lane == 0) L.nplane = tk;
+        if (n_ob) append_obstacle_v2(L, lane, oh, tk);
+        return tk + n_ob;
     }
     const int slot = lane;
     const int c = slot >> 1;
@@ -456,8 +545,15 @@ __device__ int find_contacts_v2(LT& L, const DevModel& M, int lane, unsigned lon
     f3 loc = mk3(lx + M.margin * dl.x, ly + M.margin * dl.y, lz + M.margin * dl.z);
     f3 P = ld3(L.o[b]) + mulRv(Rb, ld3(M.cyl_c[c])) + mulRv(Rw, loc);
     const float dist = P.z;
-    const bool active = dist < M.break_thr;
+    bool active = dist < M.break_thr;
     unsigned long long bal = __ballot(active);
+    const int room = 4 * N - n_ob;                   // the solve's contact slots, less the box's contacts
+    if (__popcll(bal) > room) {                      // (only with an obstacle: two points per cylinder are 4 N at most)
+        if (lane == 0) { atomicAdd(ovf, 1ull); atomicAdd(ovf + 1, (unsigned long long)(__popcll(bal) - room)); }
+        active = active && __popcll(bal & ((1ull << lane) - 1ull)) < room;      // the last in slot order go
+        bal = __ballot(active);
+    }
+    const int np_ = __popcll(bal);
     if (active) {
         const int idx = __popcll(bal & ((1ull << lane) - 1ull));
         st3(L.ccP[idx], P);
@@ -478,7 +574,9 @@ __device__ int find_contacts_v2(LT& L, const DevModel& M, int lane, unsigned lon
         L.cylbase[lane] = (unsigned char)__popcll(bal & ((1ull << (2 * lane)) - 1ull));
         L.cyln[lane] = (unsigned char)((int)((bal >> (2 * lane)) & 1ull) + (int)((bal >> (2 * lane + 1)) & 1ull));
     }
-    return __popcll(bal);
+    if (lane == 0) L.nplane = np_;
+    if (n_ob) append_obstacle_v2(L, lane, oh, np_);
+    return np_ + n_ob;
 }
 
 // The same persistent-manifold contacts for the streamed-row solve (chains up to 32 links: one cylinder per lane):
@@ -569,7 +667,8 @@ __device__ void build_batch_v2(LT& L, const DevModel& M, int lane, int nc, int b
         } else {
             k = L.ccbody[ci];
             P = ld3(L.ccP[ci]);
-            d = KIND == 1 ? mk3(0.f, 0.f, 1.f) : ld3(L.cdir[L.ccds[ci]][lane >> 5]);
+            // a ground contact's normal is +z, the obstacle's contacts (behind the nplane ground contacts) carry theirs
+            d = KIND == 1 ? (ci < L.nplane ? mk3(0.f, 0.f, 1.f) : ld3(L.obn[ci - L.nplane])) : ld3(L.cdir[L.ccds[ci]][lane >> 5]);
         }
         f3 pN = mk3(0, 0, 0), pF = mk3(0, 0, 0);
 #pragma unroll 4
@@ -672,7 +771,7 @@ struct SlotRaw {
     bool valid;
 };
 template <class LT, int KIND>
-__device__ __forceinline__ SlotRaw fetch_slot(LT& L, const LaneK& K, int s, int count, int base) {
+__device__ __forceinline__ SlotRaw fetch_slot(LT& L, const LaneK& K, int s, int count, int base, int nplane) {
     SlotRaw r;
     // KIND 1: slot s holds contacts 2s, 2s+1 (staging row = contact);  KIND 4: slot s = contact s,
     // direction A / B in the lower / upper half, staged in rows (s - base) and 32 + (s - base)
@@ -686,7 +785,7 @@ __device__ __forceinline__ SlotRaw fetch_slot(LT& L, const LaneK& K, int s, int 
     r.dinv = st[24];
     r.sp = st[22 + K.spoff];
     r.P = ld3(L.ccP[rs]);
-    r.dir = KIND == 1 ? mk3(0.f, 0.f, 1.f) : ld3(L.cdir[L.ccds[rs]][K.h]);
+    r.dir = KIND == 1 ? (rs < nplane ? mk3(0.f, 0.f, 1.f) : ld3(L.obn[rs - nplane])) : ld3(L.cdir[L.ccds[rs]][K.h]);
     r.k = L.ccbody[rs];
     r.lam = (KIND == 1 && r.valid) ? L.app[kAppNormal + rs] : 0.f;     // where the normal row starts (warm starting)
     return r;
@@ -709,15 +808,23 @@ __device__ __forceinline__ void finish_slot(const SlotRaw& r, const LaneK& K, fl
 }
 // eight consecutive slots BASE .. BASE+7 of one kind, reads issued one slot ahead (two ahead
 // measured the same and spills)
+// friction rows are written in units of their contact's friction coefficient (finish_slot): the ground's for the first
+// nplane contacts, the obstacle's for those behind them
+struct MuScale {
+    float fJ, fM, fJo, fMo;
+    int nplane;
+};
 template <class LT, int KIND, int BASE, int DST>
-__device__ __forceinline__ void load_slots8(LT& L, const LaneK& K, int count, int base, float sJ, float sM,
+__device__ __forceinline__ void load_slots8(LT& L, const LaneK& K, int count, int base, const MuScale& ms,
                                             float (&RJ)[kSlots], float (&RM)[kSlots], float& wsum) {
-    SlotRaw cur = fetch_slot<LT, KIND>(L, K, BASE, count, base);
+    SlotRaw cur = fetch_slot<LT, KIND>(L, K, BASE, count, base, ms.nplane);
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         SlotRaw nxt = cur;
-        if (i < 7) nxt = fetch_slot<LT, KIND>(L, K, BASE + i + 1, count, base);
-        finish_slot<KIND>(cur, K, sJ, sM, RJ[DST + BASE + i], RM[DST + BASE + i], wsum);
+        if (i < 7) nxt = fetch_slot<LT, KIND>(L, K, BASE + i + 1, count, base, ms.nplane);
+        const bool gr = KIND == 1 || BASE + i < ms.nplane;           // (KIND 4: slot = contact)
+        finish_slot<KIND>(cur, K, KIND == 1 ? 1.0f : (gr ? ms.fJ : ms.fJo), KIND == 1 ? 1.0f : (gr ? ms.fM : ms.fMo),
+                          RJ[DST + BASE + i], RM[DST + BASE + i], wsum);
         cur = nxt;
     }
 }
@@ -1201,7 +1308,11 @@ __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane, f
         float nv0 = sqrtf(dot(v_old, v_old));
         f3 a1 = ld3(&L.acc0[3]);
         float fz1 = -dot(zb, (a1 - mk3(0.f, 0.f, M.gz)) * M.m_root + v_old * (M.m_root * (M.lin_damp + M.lin_damp * nv0)));
-        if (lane == 0) L.fz_park = fz1;
+        // ... and of the reaction through the first motor joint (Bullet joint 3, snake_gait_test.py:33-40): what body 0
+        // does not use up of the forces on it, F = -(m_0 (a_0 + alpha_0 x c_0) + own force bias), z of body 1
+        const f3 al0 = ld3(&L.acc0[0]);
+        const f3 F3 = -((a1 + cross(al0, ld3(L.cw[0]))) * M.mass[0] + ld3(&L.p[0][3]));
+        if (lane == 0) { L.fz_park = fz1; L.fz3_park = F3.x * L.R[1][2] + F3.y * L.R[1][5] + F3.z * L.R[1][8]; }
     }
     // (3) v += a dt (clamped)
     if (lane < 6) {
@@ -1234,7 +1345,13 @@ __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane, f
         K.oL = ld3(L.o[K.bL]);
         K.aL = (K.d >= 6 && K.isdof) ? ld3(L.ax[K.bL])
                                      : mk3(K.d == 0 ? 1.f : 0.f, K.d == 1 ? 1.f : 0.f, K.d == 2 ? 1.f : 0.f);
-        const float fJ = mu > 0.f ? 1.0f / mu : 0.f, fM = mu > 0.f ? mu : 0.f;
+        MuScale ms;
+        // (wave-uniform values, pinned to scalar registers: the row builder's vector registers are all spoken for)
+        auto sgpr = [](float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); };
+        ms.fJ = sgpr(mu > 0.f ? 1.0f / mu : 0.f); ms.fM = sgpr(mu > 0.f ? mu : 0.f);
+        const float mu_ob = fminf(M.mu_link * M.mu_obs, 10.0f);
+        ms.fJo = sgpr(mu_ob > 0.f ? 1.0f / mu_ob : 0.f); ms.fMo = sgpr(mu_ob > 0.f ? mu_ob : 0.f);
+        ms.nplane = __builtin_amdgcn_readfirstlane(L.nplane);
         build_batch_v2<LT, 0>(L, M, lane, nc);
         SNK_STAMP(4)
         // friction pairs: two batches of 32 contacts x {A, B}
@@ -1242,18 +1359,18 @@ __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane, f
         for (int s = 0; s < kSlots - kSlotFric; s++) { RJ[kSlotFric + s] = 0.f; RM[kSlotFric + s] = 0.f; }
         build_batch_v2<LT, 4>(L, M, lane, nc, 0);
         SNK_STAMP(5)
-        if (nc > 0) load_slots8<LT, 4, 0, kSlotFric>(L, K, nc, 0, fJ, fM, RJ, RM, wsum);
-        if (nc > 8) load_slots8<LT, 4, 8, kSlotFric>(L, K, nc, 0, fJ, fM, RJ, RM, wsum);
-        if (nc > 16) load_slots8<LT, 4, 16, kSlotFric>(L, K, nc, 0, fJ, fM, RJ, RM, wsum);
-        if (nc > 24) load_slots8<LT, 4, 24, kSlotFric>(L, K, nc, 0, fJ, fM, RJ, RM, wsum);
+        if (nc > 0) load_slots8<LT, 4, 0, kSlotFric>(L, K, nc, 0, ms, RJ, RM, wsum);
+        if (nc > 8) load_slots8<LT, 4, 8, kSlotFric>(L, K, nc, 0, ms, RJ, RM, wsum);
+        if (nc > 16) load_slots8<LT, 4, 16, kSlotFric>(L, K, nc, 0, ms, RJ, RM, wsum);
+        if (nc > 24) load_slots8<LT, 4, 24, kSlotFric>(L, K, nc, 0, ms, RJ, RM, wsum);
         lds_sync();
         SNK_STAMP(6)
         build_batch_v2<LT, 4>(L, M, lane, nc, 32);      // no active lanes when nc <= 32
         SNK_STAMP(7)
-        if (nc > 32) load_slots8<LT, 4, 32, kSlotFric>(L, K, nc, 32, fJ, fM, RJ, RM, wsum);
-        if (nc > 40) load_slots8<LT, 4, 40, kSlotFric>(L, K, nc, 32, fJ, fM, RJ, RM, wsum);
-        if (nc > 48) load_slots8<LT, 4, 48, kSlotFric>(L, K, nc, 32, fJ, fM, RJ, RM, wsum);
-        if (nc > 56) load_slots8<LT, 4, 56, kSlotFric>(L, K, nc, 32, fJ, fM, RJ, RM, wsum);
+        if (nc > 32) load_slots8<LT, 4, 32, kSlotFric>(L, K, nc, 32, ms, RJ, RM, wsum);
+        if (nc > 40) load_slots8<LT, 4, 40, kSlotFric>(L, K, nc, 32, ms, RJ, RM, wsum);
+        if (nc > 48) load_slots8<LT, 4, 48, kSlotFric>(L, K, nc, 32, ms, RJ, RM, wsum);
+        if (nc > 56) load_slots8<LT, 4, 56, kSlotFric>(L, K, nc, 32, ms, RJ, RM, wsum);
         lds_sync();
         SNK_STAMP(8)
         build_batch_v2<LT, 1>(L, M, lane, nc);
@@ -1261,10 +1378,10 @@ __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane, f
 #pragma unroll
         for (int s = 0; s < kSlotFric; s++) { RJ[kSlotNormal + s] = 0.f; RM[kSlotNormal + s] = 0.f; }
         // a normal slot holds contacts 2s, 2s+1: 8 slots per 16 contacts
-        if (nc > 0) load_slots8<LT, 1, 0, kSlotNormal>(L, K, nc, 0, 1.0f, 1.0f, RJ, RM, wsum);
-        if (nc > 16) load_slots8<LT, 1, 8, kSlotNormal>(L, K, nc, 0, 1.0f, 1.0f, RJ, RM, wsum);
-        if (nc > 32) load_slots8<LT, 1, 16, kSlotNormal>(L, K, nc, 0, 1.0f, 1.0f, RJ, RM, wsum);
-        if (nc > 48) load_slots8<LT, 1, 24, kSlotNormal>(L, K, nc, 0, 1.0f, 1.0f, RJ, RM, wsum);
+        if (nc > 0) load_slots8<LT, 1, 0, kSlotNormal>(L, K, nc, 0, ms, RJ, RM, wsum);
+        if (nc > 16) load_slots8<LT, 1, 8, kSlotNormal>(L, K, nc, 0, ms, RJ, RM, wsum);
+        if (nc > 32) load_slots8<LT, 1, 16, kSlotNormal>(L, K, nc, 0, ms, RJ, RM, wsum);
+        if (nc > 48) load_slots8<LT, 1, 24, kSlotNormal>(L, K, nc, 0, ms, RJ, RM, wsum);
         // motors: column 6+j of M^-1 (divided by the row's denominator) in both halves;
         // target velocity change of motor j in lane 6+j
 #pragma unroll
@@ -1376,6 +1493,14 @@ __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane, f
         const int n_iter = M.n_iter;
         const bool cone = M.cone != 0;
         int it = 0;
+        // Every row register gets a NEW live range here (an empty asm that "rewrites" it).  Where the row builder's peak
+        // demand had pushed a row into scratch memory, the allocator otherwise keeps it there for good and reloads it at
+        // every use -- inside this loop, 50 times per substep (round-3 ISA: up to 20 such reloads per iteration) -- although
+        // the loop itself leaves twenty registers unused.  Split here, the row is reloaded once, in front of the loop.
+#pragma unroll
+        for (int s2 = 0; s2 < kSlots; s2++) asm volatile("" : "+v"(RJ[s2]), "+v"(RM[s2]));
+#pragma unroll
+        for (int j2 = 0; j2 < 16; j2++) asm volatile("" : "+v"(RMm[j2]));
         for (; it < n_iter; it++) {
             // Bullet leaves the sweep when max_rows |dI * den| <= threshold.  `exceeded` becomes 1
             // as soon as a group of rows shows a larger residual; from then on the residual-free
@@ -1434,8 +1559,10 @@ __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane, f
             const int h = lane >> 5;
 #pragma unroll
             for (int s = 0; s < kSlotFric; s++) L.app[kAppNormal + 2 * s + h] = RJ[kSlotNormal + s];
+            const int npl = L.nplane;
+            const float mu_ob = fminf(M.mu_link * M.mu_obs, 10.0f);
 #pragma unroll
-            for (int s = 0; s < kSlots - kSlotFric; s++) L.app[kAppFric + 2 * s + h] = RJ[kSlotFric + s] * mu;
+            for (int s = 0; s < kSlots - kSlotFric; s++) L.app[kAppFric + 2 * s + h] = RJ[kSlotFric + s] * (s < npl ? mu : mu_ob);
         }
         if (lane >= 6 && lane < ND) L.app[kAppMotor + lane - 6] = ACCV * L.MmS[lane - 6][2];   // y / den = impulse
     }
@@ -1457,14 +1584,15 @@ __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane, f
     // tolerance); for the third, no sampled point can move further in one substep than
     // dt * (|v| + L_chain * (|omega| + sum |qd|)): rigid rotations about the base and the joints.
     const bool sensor = sensor_pass_needed(L, M, lane, dv, hint);
-    float fz = L.fz();
+    float fz = L.fz(), fz3 = L.fz3();
     if (sensor) {
         // lane = contact: its force and its moment about the body's joint origin (staging rows are
         // free now); then lane = body sums the contacts of its cylinders (2b-1 and 2b; body 0: cylinder 0) in
         // contact order
         if (lane < nc) {
             const int ci = lane, k = L.ccbody[ci];
-            f3 F = (mk3(0.f, 0.f, 1.f) * L.app[kAppNormal + ci] +
+            const f3 nrm = ci < L.nplane ? mk3(0.f, 0.f, 1.f) : ld3(L.obn[ci - L.nplane]);
+            f3 F = (nrm * L.app[kAppNormal + ci] +
                     ld3(L.cdir[L.ccds[ci]][0]) * L.app[kAppFric + 2 * ci] +
                     ld3(L.cdir[L.ccds[ci]][1]) * L.app[kAppFric + 2 * ci + 1]) * M.inv_dt;
             st3(&L.stM[ci][0], cross(ld3(L.ccP[ci]) - ld3(L.o[k]), F));
@@ -1483,6 +1611,11 @@ __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane, f
                     eF = eF + ld3(&L.stM[ci][3]);
                 }
             }
+            for (int ci = L.nplane; ci < nc; ci++)               // the obstacle's contacts, behind the ground's
+                if (L.ccbody[ci] == b) {
+                    eN = eN + ld3(&L.stM[ci][0]);
+                    eF = eF + ld3(&L.stM[ci][3]);
+                }
             st3(L.ext(b), eN);
             st3(L.ext(b) + 3, eF);
         }
@@ -1515,6 +1648,9 @@ __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane, f
             float nv1 = sqrtf(dot(v1, v1));
             f3 a2 = ld3(&L.acc0[3]);
             fz = L.fz_park - dot(zb, a2 * M.m_root + v1 * (M.m_root * (M.lin_damp + M.lin_damp * nv1)));
+            const f3 al2 = ld3(&L.acc0[0]);
+            const f3 F3 = -((a2 + cross(al2, ld3(L.cw[0]))) * M.mass[0] + ld3(&L.p[0][3]));
+            fz3 = L.fz3_park + F3.x * L.R[1][2] + F3.y * L.R[1][5] + F3.z * L.R[1][8];
         }
         SNK_STAMP(15)
     }
@@ -1551,6 +1687,7 @@ __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane, f
             bs[0] += dt * vl.x; bs[1] += dt * vl.y; bs[2] += dt * vl.z;
             bs[3] = nx * inv; bs[4] = ny * inv; bs[5] = nz * inv; bs[6] = nw * inv;
             L.fz() = fz;
+            L.fz3() = fz3;
         }
     }
     lds_sync();

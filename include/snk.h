@@ -42,8 +42,8 @@ typedef struct snk_params {
                                    limits and no rows are built                               */
     int32_t obstacle;           /* 1: a box stands on the ground in front of the snake -- snake/block.urdf loaded by
                                    Snake.add_obstacle (snake.py:83-84, commented out at :94) and by
-                                   snake_gait_test.py:51.  STATIC here (the reference's is a free 200-kg body).
-                                   Its contacts need the streamed-row solve (slower for 16 links). Default 0  */
+                                   snake_gait_test.py:51.  STATIC (the reference's is a free 200-kg body).
+                                   16 links: up to 8 contacts with it, taken out of the solve's 64 slots. Default 0 */
     double  obstacle_pos[3];    /* centre of the box: [2, 0, 0.1] (snake.py:94, snake_gait_test.py:51)         */
     double  obstacle_half[3];   /* half extents: [0.1, 0.4, 0.1] (snake/block.urdf:16)                         */
     double  mu_obstacle;        /* 0.5 [U]: Bullet's default lateral friction for a link without <contact>     */
@@ -133,7 +133,8 @@ int snk_reset(snk_handle* h, const uint8_t* mask_dev, float* obs_dev, void* stre
  * the env-steps through an in-launch queue.  Results do not depend on that schedule.
  * Every wait inside the kernel is bounded; if one ever runs out the kernel drains, and this and
  * every later call on the handle return non-zero ("env-step scheduler: ...").  Environment:
- * SNK_QUANTUM=<substeps per slice> (default 1; 0 = the unscheduled kernel), read by snk_create. */
+ * SNK_QUANTUM=<substeps per slice> (default 1; 0 = the unscheduled kernel), SNK_FORCE_STREAMED=1 (16 links on the
+ * streamed-row kernels of the 32-link chain: diagnostics and cross-checks), both read by snk_create. */
 int snk_step(snk_handle* h, float* actions_dev, float* obs_dev, float* rew_dev,
              uint8_t* done_dev, int32_t* substeps_dev, int32_t vec_mode, void* stream);
 
@@ -173,8 +174,8 @@ int snk_link_positions(snk_handle* h, float* out);
 
 /* Reaction force through the first motor joint (Bullet joint 3: INPUT_IF_1 -> OUTPUT_BODY_1), z component in the
  * child link's frame, of every env's last physics substep: what snake_gait_test.py:33-40,126 reads
- * (getJointState(robot, 3)[2][2], "> 20: the snake has hit the wall").  Host buffer [n_envs].  Evaluated by the
- * streamed-row solve (32 links, or 16 links with an obstacle); fails for a register-resident 16-link handle. */
+ * (getJointState(robot, 3)[2][2], "> 20: the snake has hit the wall").  Host buffer [n_envs].  Like the joint-0 force
+ * of the observation it is evaluated on the last substep of an env-step (and by every snk_substep_host substep). */
 int snk_joint3_reaction_fz(snk_handle* h, float* out);
 
 /* Contacts the solves had no room for, counted on the device since snk_create (Bullet has no such limit; these

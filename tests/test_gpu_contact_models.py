@@ -362,5 +362,7 @@ def test_contact_slot_limit_is_counted_and_fair(pkg, oracle_mod):
           "| worst one-substep difference", worst, "| flips", flips, "of", 150 * B)
     assert seen_over > 0 and sub == seen_over and pts > 0 and other == 0
     assert flips <= 150 * B // 10 and compared > 100 * B
-    assert worst < 2e-4
+    # (over the limit, which of a resting cylinder's near-equally deep points counts as its deepest is a last-bit decision
+    #  too, and one the cache comparison above cannot see: the kept SETS may differ by a point)
+    assert worst < 5e-4
     st.close()

@@ -9,7 +9,7 @@ pkg = importlib.import_module("bullet-envs_amd")
 STEPS = int(sys.argv[1]) if len(sys.argv) > 1 else 600
 rng = np.random.default_rng(0)
 # (links, envs, parameter overrides): round 2 adds Bullet's contact model (a contact cache that moves between waves with
-# the env-step's slices), the obstacle on the 16-link streamed-row kernels and the wrap-around of the queue's tickets
+# the env-step's slices), the obstacle on the 16-link kernels and the wrap-around of the queue's tickets
 CASES = ((16, 4096, {}), (32, 4096, {}), (16, 1537, {}), (16, 4096, dict(hull_sides=0, contact_model=0, relative_breaking_threshold=0)),
          (32, 2500, dict(hull_sides=0, contact_model=0, relative_breaking_threshold=0)), (16, 2048, dict(warm_start=1)), (16, 1200, dict(obstacle=1, obstacle_pos=[0.25, 0.0, 0.1])))
 for case, (n, B, over) in enumerate(CASES):

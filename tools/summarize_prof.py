@@ -22,9 +22,9 @@ RK = 'reset_kernel<%d,' % N
 
 
 def one(pattern, required=True):
-    g = glob.glob(os.path.join(src, pattern))
-    assert g or not required, pattern
-    return g[0] if g else None
+    g = sorted(glob.glob(os.path.join(src, pattern)), key=os.path.getmtime)       # gpurun_out/ keeps earlier runs' files:
+    assert g or not required, pattern                                               # the newest one is this run's
+    return g[-1] if g else None
 
 
 def agg(path, kern):
