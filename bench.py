@@ -208,7 +208,23 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+        # the record must prove what ran: RCCL (or the rehearsal backend) saw exactly --gpus ranks, one per device
+        assert dist.get_world_size() == args.gpus == world, (dist.get_world_size(), args.gpus, world)
+        assert dist.get_rank() == rank, (dist.get_rank(), rank)
 
+    rank_info = {"rank": rank, "local_rank": local_rank, "device": torch.cuda.current_device(),
+                 "name": torch.cuda.get_device_name(dev), "pid": os.getpid()}
+    try:
+        rank_info["pci_bus_id"] = torch.cuda.get_device_properties(dev).pci_bus_id
+    except Exception:  # noqa: BLE001  (older torch: no such field)
+        pass
+    ranks = [rank_info]
+    if dist is not None:
+        ranks = [None] * world
+        dist.all_gather_object(ranks, rank_info)
+        if backend == "nccl":
+            # one GPU per rank: no two ranks on the same device of this node
+            assert len({(r["device"], r.get("pci_bus_id")) for r in ranks}) == world, ranks
     extra = {}
     if args.streamed_rows:
         os.environ["SNK_FORCE_STREAMED"] = "1"           # read by snk_create
@@ -389,6 +405,7 @@ def main():
                 "self_collision": args.self_collision if NL == 32 else "flag on, inert and not evaluated for 16 links",
                 "world_size": (dist.get_world_size() if dist is not None else 1),
                 "backend": (dist.get_backend() if dist is not None else None),
+                "ranks": ranks,
                 "parallelism": "envs sharded over %d GPU(s), no data-path collective; "
                                "RCCL actions scatter + obs/reward/done gather to rank 0" % world
                                if world > 1 else "1 GPU, one wavefront per env",

@@ -35,6 +35,7 @@ def build(force=False, verbose=False, defines=(), out=None):
         hipcc = "hipcc"
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-shared", "-fPIC",
            os.path.join(CSRC, "snk_api.hip"), "-o", out or LIB] + ["-D" + d for d in defines]
+    cmd += os.environ.get("SNK_EXTRA_FLAGS", "").split()        # compiler experiments
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
         print(" ".join(cmd))

@@ -76,8 +76,11 @@ int launch_step(snk_handle* h, float* act, float* obs, float* rew, uint8_t* done
     if (h->use_sched) {
         hipLaunchKernelGGL((snk::plan_sched_kernel<N>), dim3(1), dim3(1024), 0, st, h->d_model, h->d_recs, act, h->sched,
                            h->n_envs);
-        hipLaunchKernelGGL((snk::env_step_sched_kernel<N, V2>), dim3(h->grid_waves), dim3(64), h->lds_bytes, st, h->model_slot,
-                           h->d_recs, h->d_mu, act, obs, rew, done, sub, vec_mode, h->n_envs, h->sched, h->d_rows, h->d_mf, h->d_ovf);
+        snk::StepArgs a;
+        a.recs = h->d_recs; a.mu_plane = h->d_mu; a.actions = act; a.obs = obs; a.rew = rew; a.done = done; a.substeps = sub;
+        a.rows_all = h->d_rows; a.mf_all = h->d_mf; a.ovf = h->d_ovf; a.sc = h->sched;
+        a.model_slot = h->model_slot; a.vec_mode = vec_mode; a.n_envs = h->n_envs; a.pad_ = 0;
+        hipLaunchKernelGGL((snk::env_step_sched_kernel<N, V2>), dim3(h->grid_waves), dim3(64), h->lds_bytes, st, a);
         return 0;
     }
     if (h->plan)
@@ -240,6 +243,10 @@ int init_handle(snk_handle* h, const snk_params* p, int32_t n_envs, int32_t devi
     h->n = p->n_modules;
     snk::build_host_model(*p, h->H);
     snk::build_dev_model(*p, h->H, h->D);
+    // SNK_POISON=1 (tests): the kernels' LDS images and every fresh device allocation start as NaNs instead of as
+    // whatever was there, so that a read of something never written shows in the outputs
+    const bool poison = getenv("SNK_POISON") != nullptr;
+    h->D.poison = poison ? 1 : 0;
     h->rec = h->D.rec_floats;
     // 16 links: the register-resident solve (the obstacle's contacts take slots out of the ground's 64).
     // SNK_FORCE_STREAMED=1 (diagnostics, tests): the streamed-row kernels for a 16-link handle too
@@ -265,10 +272,31 @@ int init_handle(snk_handle* h, const snk_params* p, int32_t n_envs, int32_t devi
     HIP_TRY(hipMalloc(&h->d_info, ne * 2 * sizeof(int32_t)));
     HIP_TRY(hipMalloc(&h->d_h, ne * sizeof(float)));
     HIP_TRY(hipMalloc(&h->d_order, ne * sizeof(int32_t)));
+    if (poison) {
+        const size_t na = ne * h->D.act_dim * sizeof(float), no = ne * h->D.obs_dim * sizeof(float);
+        HIP_TRY(hipMemset(h->d_act, 0xFF, na)); HIP_TRY(hipMemset(h->d_obs, 0xFF, no));
+        HIP_TRY(hipMemset(h->d_rew, 0xFF, ne * sizeof(float))); HIP_TRY(hipMemset(h->d_tgt, 0xFF, ne * h->n * sizeof(float)));
+        HIP_TRY(hipMemset(h->d_h, 0xFF, ne * sizeof(float)));
+    }
     if (!h->v2) {
-        const size_t bytes = ne * (h->n == 32 ? snk::Lds<32, false>::kRowFloats : snk::Lds<16, false>::kRowFloats) * sizeof(float);
+        // one block per environment for the kernels launched one workgroup per environment (snk_substep_host, the
+        // unscheduled step kernel); the scheduled step kernel uses the first `resident waves` of them
+        const size_t rf = h->n == 32 ? snk::Lds<32, false>::kRowFloats : snk::Lds<16, false>::kRowFloats;
+        const size_t bytes = ne * rf * sizeof(float);
         HIP_TRY(hipMalloc(&h->d_rows, bytes));
-        HIP_TRY(hipMemset(h->d_rows, 0, bytes));     // the last three rows of every block stay zero for good
+        HIP_TRY(hipMemset(h->d_rows, poison ? 0xFF : 0, bytes));
+        // what the kernels rely on being zero for good: the last three rows of every block (the refill of a skipped
+        // friction pair) and the pad columns of the M^-1 block behind the rows
+        const size_t z0 = h->n == 32 ? (size_t)(snk::Lds<32, false>::kRows - 3) * snk::Lds<32, false>::kRS
+                                     : (size_t)(snk::Lds<16, false>::kRows - 3) * snk::Lds<16, false>::kRS;
+        const size_t zn = 3 * (size_t)(h->n == 32 ? snk::Lds<32, false>::kRS : snk::Lds<16, false>::kRS);
+        const size_t m0 = h->n == 32 ? snk::Lds<32, false>::kMmOff : snk::Lds<16, false>::kMmOff;
+        const size_t m1 = h->n == 32 ? snk::Lds<32, false>::kYOff : snk::Lds<16, false>::kYOff;
+        if (poison)
+            for (size_t e = 0; e < ne; e++) {
+                HIP_TRY(hipMemsetAsync(h->d_rows + e * rf + z0, 0, zn * sizeof(float), nullptr));
+                HIP_TRY(hipMemsetAsync(h->d_rows + e * rf + m0, 0, (m1 - m0) * sizeof(float), nullptr));
+            }
     }
     HIP_TRY(hipMalloc(&h->d_ovf, 3 * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(h->d_ovf, 0, 3 * sizeof(unsigned long long)));

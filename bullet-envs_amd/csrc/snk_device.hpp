@@ -133,6 +133,8 @@ __device__ __forceinline__ float cols_max(float x) {
     x = step(x, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{});
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), LAST));
 }
+// the lane's index within its wave (= threadIdx.x of the one-wave workgroups here), recomputed instead of kept
+__device__ __forceinline__ int lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 __device__ __forceinline__ float lane_bcast(float x, int src_lane_uniform) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), src_lane_uniform));
 }
@@ -173,6 +175,17 @@ struct LdsCommon {
     int nc_joint[NL];
     float nc_sign[NL], nc_rhs[NL], nc_dinv[NL], nc_den[NL], nc_lo[NL], nc_hi[NL], nc_app[NL];
 
+    // SNK_POISON=1 (snk_create; tests): every float of the image becomes a NaN before an environment is loaded, so that a
+    // read of something this substep did not write shows up in the outputs instead of depending on what the previous
+    // environment -- or another kernel -- left behind.  (The integer tables are left alone: a NaN's bits as an index
+    // would turn such a bug into a wild address.)
+    __device__ __forceinline__ void poison_common(int lane) {
+        float* a = rec;
+        const int nf = (int)(reinterpret_cast<float*>(nc_joint) - a);
+        for (int i = lane; i < nf; i += 64) a[i] = __int_as_float(0x7fc00000);
+        float* b = nc_sign;
+        for (int i = lane; i < 7 * NL; i += 64) b[i] = __int_as_float(0x7fc00000);
+    }
     __device__ __forceinline__ float* base() { return rec; }
     __device__ __forceinline__ float* q() { return rec + 13; }
     __device__ __forceinline__ float* qd() { return rec + 13 + N; }
@@ -192,6 +205,11 @@ struct Lds<N, false> : LdsCommon<N, 2 * N> {
     static constexpr int NC = 4 * N, NR = 12 * N, ND = N + 6;
     float ext_[LdsCommon<N, 2 * N>::NB][6];      // link forces of the constraint pass
     __device__ __forceinline__ float* ext(int b) { return ext_[b]; }
+    __device__ __forceinline__ void poison(int lane) {
+        this->poison_common(lane);
+        for (int i = lane; i < LdsCommon<N, 2 * N>::NB * 6; i += 64) (&ext_[0][0])[i] = __int_as_float(0x7fc00000);
+        for (int i = lane; i < (NC + kRing + 3) * 4; i += 64) (&acc[0][0])[i] = __int_as_float(0x7fc00000);
+    }
     int clist[NC];               // compact contact index -> slot
     int cidx[NC];                // slot -> compact contact index (-1: not in contact)
     // The contact rows themselves (J and M^-1 J^T, 2 x 384 x 38 floats = 117 KB) do not fit LDS next
@@ -272,6 +290,13 @@ struct Lds<N, true> : LdsCommon<N, N> {
     // coordinates (3), point on the ground x, y (its z is the plane's: 0), the normal impulse of the last substep
     float mfl[24][2 * N];
     unsigned char mfn[2 * N];    // cached points of cylinder c
+    __device__ __forceinline__ void poison(int lane) {
+        this->poison_common(lane);
+        auto fill = [&](float* a, int n) { for (int i = lane; i < n; i += 64) a[i] = __int_as_float(0x7fc00000); };
+        fill(&Mm[0][0], N * ND); fill(&ccP[0][0], NC * 3); fill(ccdist, NC); fill(&cdir[0][0][0], (2 * N + kObs) * 6);
+        fill(&obn[0][0], kObs * 3); fill(&stM[0][0], 64 * 25); fill(&MmS[0][0], N * 4);
+        fill(app, 2 * (N / 2 + NC / 2 + NC)); fill(&mfl[0][0], 24 * 2 * N);
+    }
 };
 
 __device__ __forceinline__ void lds_sync() { __syncthreads(); }
@@ -1712,6 +1737,7 @@ __global__ __launch_bounds__(64, 2) void env_step_kernel(const DevModel* __restr
     // longest-first schedule: workgroup b takes the env with the b-th largest predicted work
     const int env = order ? __builtin_amdgcn_readfirstlane(order[blockIdx.x]) : (int)blockIdx.x;
     const int lane = threadIdx.x;
+    if (M.poison) { L.poison(lane); lds_sync(); }
     load_rec(L, recs + (size_t)env * LT::REC, lane);
     const int A = M.act_dim;
     // checkBound (SnakeGymEnv.py:82-88) clips the caller's array in place
@@ -1797,6 +1823,7 @@ __global__ __launch_bounds__(64, 2) void substep_kernel(const DevModel* __restri
     const int env = blockIdx.x;
     const int lane = threadIdx.x;
     if (env >= n_envs) return;
+    if (M.poison) { L.poison(lane); lds_sync(); }
     load_rec(L, recs + (size_t)env * LT::REC, lane);
     if (lane < N) L.targets[lane] = targets[(size_t)env * N + lane];
     lds_sync();
@@ -2126,23 +2153,47 @@ __global__ __launch_bounds__(1024) void plan_sched_kernel(const DevModel* __rest
     for (int e = tid + kKeep * 1024; e < n_envs; e += 1024) enqueue(e, key_of(e));
 }
 
+// Arguments of the scheduled step kernel: ONE struct, passed by value -- i.e. it IS the kernel-argument segment -- and
+// read through step_args(), a pointer to that segment the compiler cannot see through, at the place of use.  Passed
+// as ordinary kernel arguments these twenty pointers are loaded once at kernel entry and then sit in scalar registers
+// for the whole launch; the register-resident solve has none to spare, so ~190 of them were spilled into lanes of FOUR
+// vector registers, which the solve's row registers then paid for with reloads from scratch memory inside the
+// Gauss-Seidel loop (round-3 ISA).  Read where needed, a pointer lives for a few instructions.
+struct StepArgs {
+    float* recs;
+    const float* mu_plane;
+    float* actions;
+    float* obs;
+    float* rew;
+    uint8_t* done;
+    int32_t* substeps;
+    float* rows_all;
+    float* mf_all;
+    unsigned long long* ovf;
+    Sched sc;
+    int32_t model_slot, vec_mode, n_envs, pad_;
+};
+typedef const StepArgs __attribute__((address_space(4))) * StepArgPtr;
+__device__ __forceinline__ StepArgPtr step_args() {
+    StepArgPtr p = (StepArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return p;
+}
+__device__ __forceinline__ Sched load_sched(StepArgPtr p) {
+    Sched sc;
+    sc.head = p->sc.head; sc.tail = p->sc.tail; sc.ent = p->sc.ent; sc.waiting = p->sc.waiting;
+    sc.counter = p->sc.counter; sc.finished = p->sc.finished; sc.alarm = p->sc.alarm;
+    sc.cap = p->sc.cap; sc.quantum = p->sc.quantum; sc.hyst = p->sc.hyst; sc.wstat = p->sc.wstat;
+    return sc;
+}
+
 template <int N, bool V2>
-__global__ __launch_bounds__(64, 2) void env_step_sched_kernel(int model_slot, float* __restrict__ recs,
-                                                            const float* __restrict__ mu_plane,
-                                                            float* __restrict__ actions, float* __restrict__ obs,
-                                                            float* __restrict__ rew, uint8_t* __restrict__ done,
-                                                            int32_t* __restrict__ substeps, int vec_mode, int n_envs,
-                                                            Sched sc, float* __restrict__ rows_all,
-                                                            float* __restrict__ mf_all, unsigned long long* __restrict__ ovf) {
+__global__ __launch_bounds__(64, 2) void env_step_sched_kernel(StepArgs args_by_value) {
+    (void)args_by_value;            // read through step_args() only
     extern __shared__ float4 smem_raw[];
     using LT = Lds<N, V2>;
     LT& L = *reinterpret_cast<LT*>(smem_raw);
-    const DevModel& M = g_models[model_slot];
-    const int lane = threadIdx.x;
-    const int A = M.act_dim;
-    float* env_rows = nullptr;      // constraint rows of chains too long for the register-resident solve:
-    if constexpr (!LT::kV2) env_rows = rows_all + (size_t)blockIdx.x * LT::kRowFloats;   // one block per resident wave
-    const int quantum = sc.quantum;
+    int lane = threadIdx.x;
 #ifdef SNK_SCHED_DEBUG
     long long t_wait = 0, n_slices = 0, n_sub = 0, n_chk = 0, n_req = 0, s_top = 0, s_rem = 0;
     const long long t_birth = wall_clock64();
@@ -2151,32 +2202,41 @@ __global__ __launch_bounds__(64, 2) void env_step_sched_kernel(int model_slot, f
 #ifdef SNK_SCHED_DEBUG
         const long long t_p0 = wall_clock64();
 #endif
-        if (__builtin_amdgcn_readfirstlane((int)__popcll(__ballot(1))) != 64) {   // the 64 lanes stay together (see sched_pop)
-            sched_alarm(sc, lane);
-            break;
-        }
-        const int env = __builtin_amdgcn_readfirstlane(sched_pop(sc, lane, n_envs));
+        const StepArgPtr ap = step_args();
+        const DevModel& M = g_models[ap->model_slot];
+        const int A = M.act_dim;
+        const int n_envs = ap->n_envs;
+        int env;
+        {
+            const Sched sc = load_sched(ap);
+            if (__builtin_amdgcn_readfirstlane((int)__popcll(__ballot(1))) != 64) {   // the 64 lanes stay together (see sched_pop)
+                sched_alarm(sc, lane);
+                break;
+            }
+            env = __builtin_amdgcn_readfirstlane(sched_pop(sc, lane, n_envs));
 #ifdef SNK_SCHED_DEBUG
-        if (env >= 0) { t_wait += wall_clock64() - t_p0; n_slices++; }
-        else if (lane == 0) {
-            long long* w = sc.wstat + 8 * (size_t)blockIdx.x;
-            w[0] = t_wait; w[1] = t_p0 - t_birth; w[2] = n_slices; w[3] = n_sub;
-            w[4] = n_chk; w[5] = n_req; w[6] = s_top; w[7] = s_rem;
-        }
+            if (env >= 0) { t_wait += wall_clock64() - t_p0; n_slices++; }
+            else if (lane == 0) {
+                long long* w = sc.wstat + 8 * (size_t)blockIdx.x;
+                w[0] = t_wait; w[1] = t_p0 - t_birth; w[2] = n_slices; w[3] = n_sub;
+                w[4] = n_chk; w[5] = n_req; w[6] = s_top; w[7] = s_rem;
+            }
 #endif
+        }
         if (env < 0) break;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        float* rec = recs + (size_t)env * LT::REC;
-        load_rec(L, rec, lane);
-        int counter = __builtin_amdgcn_readfirstlane(sc.counter[env]);
+        if (M.poison) { L.poison(lane); lds_sync(); }
+        load_rec(L, ap->recs + (size_t)env * LT::REC, lane);
+        int counter = __builtin_amdgcn_readfirstlane(ap->sc.counter[env]);
         if (counter < 0 || counter > M.max_counter + 1 || env >= n_envs) {     // never, unless a hand-off went wrong
-            sched_alarm(sc, lane);
+            sched_alarm(load_sched(ap), lane);
             break;
         }
         // checkBound (SnakeGymEnv.py:82-88) clips the caller's array in place
         float act = 0.f;
         if (lane < A) {
+            float* actions = ap->actions;
             act = actions[(size_t)env * A + lane];
             float cl = fminf(fmaxf(act, -1.0f), 1.0f);
             if (cl != act) actions[(size_t)env * A + lane] = cl;
@@ -2190,9 +2250,13 @@ __global__ __launch_bounds__(64, 2) void env_step_sched_kernel(int model_slot, f
             L.targets[slot] = act * M.scaling;
         }
         lds_sync();
-        const float mu = fminf(M.mu_link * mu_plane[env], 10.0f);
-        float* env_mf = mf_all ? mf_all + (size_t)env * (2 * N * kMfFloats) : nullptr;   // contact cache (contact_model 1)
-        load_mf(L, env_mf, lane);
+        const float mu = fminf(M.mu_link * ap->mu_plane[env], 10.0f);
+        // contact cache of the environment (contact_model 1): recomputed from the argument segment wherever it is used
+        auto env_mf = [&](StepArgPtr q) -> float* {
+            float* mf_all = q->mf_all;
+            return mf_all ? mf_all + (size_t)env * (2 * N * kMfFloats) : nullptr;
+        };
+        load_mf(L, env_mf(ap), lane);
         fk_vel(L, M, lane);
         // Snake.step servo loop (snake.py:283-304), `quantum` substeps at a time
         bool end_height = false, complete = false;
@@ -2204,16 +2268,18 @@ __global__ __launch_bounds__(64, 2) void env_step_sched_kernel(int model_slot, f
             float e = (lane < N) ? (L.targets[lane] - L.q()[lane]) : 0.f;
             float nrm = sqrtf(wave_sum<64>(e * e));
             if (uni(!(nrm > M.servo_tol))) { complete = true; break; }
-            if (in_slice >= quantum) {
+            const StepArgPtr aq = step_args();
+            if (in_slice >= aq->sc.quantum) {
                 // slice boundary: carry on unless an env with more work left is waiting
+                const Sched sc = load_sched(aq);
                 const int remaining = predict_remaining(M, __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(nrm))), counter);
                 const int top = sched_top(sc, lane);
 #ifdef SNK_SCHED_DEBUG
                 n_chk++; s_top += top; s_rem += remaining; if (top > remaining) n_req++;
 #endif
                 if (top >= remaining + sc.hyst) {
-                    store_rec_through(L, rec, lane);
-                    store_mf<LT, true>(L, env_mf, lane);        // the contact cache travels with the record
+                    store_rec_through(L, aq->recs + (size_t)env * LT::REC, lane);
+                    store_mf<LT, true>(L, env_mf(aq), lane);        // the contact cache travels with the record
                     __hip_atomic_store(&sc.counter[env], counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     sched_push(sc, lane, env, remaining);
                     break;
@@ -2221,7 +2287,12 @@ __global__ __launch_bounds__(64, 2) void env_step_sched_kernel(int model_slot, f
                 in_slice = 0;
             }
             hint.counter_next = counter + 1;
-            substep(L, M, lane, mu, it_dummy, nc_dummy, hint, env_rows, env_mf, ovf);
+            {
+                float* env_rows = nullptr;      // constraint rows of chains too long for the register-resident solve:
+                if constexpr (!LT::kV2) env_rows = aq->rows_all + (size_t)blockIdx.x * LT::kRowFloats;   // one block per resident wave
+                substep(L, M, lane, mu, it_dummy, nc_dummy, hint, env_rows, env_mf(aq), aq->ovf);
+                lane = lane_id();       // (not kept in a register across the solve)
+            }
 #ifdef SNK_SCHED_DEBUG
             n_sub++;
 #endif
@@ -2232,6 +2303,7 @@ __global__ __launch_bounds__(64, 2) void env_step_sched_kernel(int model_slot, f
             if (counter > M.max_counter) { complete = true; break; }
         }
         if (!complete) continue;
+        const StepArgPtr af = step_args();
         // SnakeGymEnv.step (SnakeGymEnv.py:36-42)
         float en = (lane < N) ? L.qd()[lane] * L.taum()[lane] * M.energy_dt : 0.f;   // snake.py:336-341
         float energy = wave_sum<64>(en);
@@ -2242,7 +2314,8 @@ __global__ __launch_bounds__(64, 2) void env_step_sched_kernel(int model_slot, f
         if (!dn) dn = uni(mean_height(L, M, lane) > M.height_thr);
         if (!dn) dn = end_height;
         if (dn) r += M.done_pen;
-        float* ob = obs + (size_t)env * (3 * N + 8);
+        const int vec_mode = af->vec_mode;
+        float* ob = af->obs + (size_t)env * (3 * N + 8);
         if (!(dn && vec_mode)) write_obs(L, ob, lane);
         lds_sync();
         if (dn) {
@@ -2254,13 +2327,14 @@ __global__ __launch_bounds__(64, 2) void env_step_sched_kernel(int model_slot, f
         if (lane == 0) {
             // _observation = terminal obs (SnakeGymEnv.py:42); the worker's reset() refreshes it
             L.prev_x() = (dn && vec_mode) ? 0.0f : x;
-            rew[env] = r;
-            done[env] = dn ? 1 : 0;
+            af->rew[env] = r;
+            af->done[env] = dn ? 1 : 0;
+            int32_t* substeps = af->substeps;
             if (substeps) substeps[env] = counter;
         }
-        store_rec(L, rec, lane);
-        store_mf<LT, false>(L, env_mf, lane);
-        atomicAdd(sc.finished, lane == 0 ? 1 : 0);
+        store_rec(L, af->recs + (size_t)env * LT::REC, lane);
+        store_mf<LT, false>(L, env_mf(af), lane);
+        atomicAdd(af->sc.finished, lane == 0 ? 1 : 0);
     }
 }
 

@@ -878,11 +878,18 @@ __device__ __forceinline__ float wrlane(float old, float v_uniform, int l) {
     SNK_REDUCE_345                                         \
     "v_readlane_b32 %[s0], %[t], 31\n\t"                  \
     "s_nop 1\n\t"
+// The accumulated impulse of a row lives in lane 31 (lower-half row) / 63 (upper-half row) of its RJ.  Adding the
+// step's dI there is ONE DPP add and needs no mask register: T holds dI_lower in lanes 0..31 and dI_upper in lanes
+// 32..63 (it comes out of a v_cndmask on the half mask), row_shr:15 has a valid source only in lane 15 of a row --
+// the other lanes are not written (bound_ctrl off) -- and row_mask 0xa keeps rows 1 and 3: lanes 31 and 63 get
+// T[16] + RJ[31] and T[48] + RJ[63].  (Rounds 1-2 multiplied by a 0/1 mask held in a VGPR for the whole solve; the
+// solve has no register to spare: DESIGN.md 4.)
+#define SNK_ACC3163(RJ_, T_) "v_add_f32_dpp " RJ_ ", " T_ ", " RJ_ " row_shr:15 row_mask:0xa bank_mask:0xf\n\t"
 #define SNK_DUO_TAIL                                     \
     "v_cndmask_b32_e64 %[t], %[dS], %[dF], %[lowmask]\n\t" \
     "v_mul_f32 %[x], %[RM], %[t]\n\t"                     \
     "v_mul_f32 %[c2], %[RM], %[t]\n\t"                    \
-    "v_fmac_f32 %[RJ], %[E], %[t]\n\t"                    \
+    SNK_ACC3163("%[RJ]", "%[t]")                           \
     "s_nop 0\n\t"                                         \
     "v_permlane32_swap_b32 %[x], %[c2]\n\t"               \
     "v_add_f32 %[dv], %[dv], %[x]\n\t"                    \
@@ -908,7 +915,7 @@ __device__ __forceinline__ void duo_step(float& RJ, const float RM, float& dv, f
             SNK_DUO_TAIL
             : [t] "=&v"(t), [x] "=&v"(x), [dF] "=&v"(dF), [dS] "=&v"(dS), [c2] "=&v"(c2), [s0] "=&s"(s0), [s1] "=&s"(s1),
               [s2] "=&s"(s2), [s3] "=&s"(s3), [RJ] "+v"(RJ), [dv] "+v"(dv)
-            : [RM] "v"(RM), [E] "v"(E3163), [lowmask] "s"(lowmask));
+            : [RM] "v"(RM), [lowmask] "s"(lowmask));
     } else
     asm volatile(
         SNK_DUO_HEAD
@@ -924,7 +931,7 @@ __device__ __forceinline__ void duo_step(float& RJ, const float RM, float& dv, f
         SNK_DUO_TAIL
         : [t] "=&v"(t), [x] "=&v"(x), [dF] "=&v"(dF), [dS] "=&v"(dS), [c2] "=&v"(c2), [s0] "=&s"(s0), [s1] "=&s"(s1),
           [s2] "=&s"(s2), [s3] "=&s"(s3), [RJ] "+v"(RJ), [dv] "+v"(dv)
-        : [RM] "v"(RM), [HI] "v"(HI), [E] "v"(E3163), [lowmask] "s"(lowmask));
+        : [RM] "v"(RM), [HI] "v"(HI), [lowmask] "s"(lowmask));
     if (RES) asm volatile("v_max3_f32 %[lsq], %[lsq], |%[x]|, |%[c2]|" : [lsq] "+v"(lsq) : [x] "v"(x), [c2] "v"(c2));
 }
 
@@ -984,12 +991,12 @@ __device__ __forceinline__ void quad_step(float& RJ1, const float RM1, float& RJ
         "v_cndmask_b32_e64 %[d3], %[d4], %[d3], %[lowmask]\n\t"
         "v_mul_f32 %[t1], %[RM1], %[d1]\n\t"
         "v_mul_f32 %[t2], %[RM2], %[d3]\n\t"
-        "v_fmac_f32 %[RJ1], %[E], %[d1]\n\t"
-        "v_fmac_f32 %[RJ2], %[E], %[d3]\n\t"
+        SNK_ACC3163("%[RJ1]", "%[d1]")
+        SNK_ACC3163("%[RJ2]", "%[d3]")
         : [t1] "=&v"(t1), [t2] "=&v"(t2), [d1] "=&v"(d1), [d2] "=&v"(d2), [d3] "=&v"(d3), [d4] "=&v"(d4),
           [a1] "=&s"(a1), [a2] "=&s"(a2), [a3] "=&s"(a3), [a4] "=&s"(a4), [s1] "=&s"(s1), [s2] "=&s"(s2), [s3] "=&s"(s3),
           [s4] "=&s"(s4), [RJ1] "+v"(RJ1), [RJ2] "+v"(RJ2)
-        : [RM1] "v"(RM1), [RM2] "v"(RM2), [dv] "v"(dv), [E] "v"(E3163), [lowmask] "s"(lowmask));
+        : [RM1] "v"(RM1), [RM2] "v"(RM2), [dv] "v"(dv), [lowmask] "s"(lowmask));
     if (RES) asm volatile("v_max3_f32 %[lsq], %[lsq], |%[p1]|, |%[p2]|" : [lsq] "+v"(lsq) : [p1] "v"(t1), [p2] "v"(t2));
     asm volatile(
         "v_add_f32 %[p1], %[p1], %[p2]\n\t"
@@ -1024,7 +1031,7 @@ __device__ __forceinline__ void cone_step(float& RJ, const float RM, const float
         "v_readlane_b32 %[s1], %[t], 31\n\t"
         "v_readlane_b32 %[s3], %[t], 63\n\t"
         "s_nop 0\n\t"
-        "v_fma_f32 %[r2], %[s1], %[s1], %[EPS]\n\t"
+        "v_fma_f32 %[r2], %[s1], %[s1], 1\n\t"
         "v_fma_f32 %[r2], %[s3], %[s3], %[r2]\n\t"
         "v_rsq_f32 %[r2], %[r2]\n\t"
         "s_nop 0\n\t"
@@ -1034,14 +1041,14 @@ __device__ __forceinline__ void cone_step(float& RJ, const float RM, const float
         "v_cndmask_b32_e64 %[t], %[xB], %[xA], %[lowmask]\n\t"
         "v_mul_f32 %[r2], %[RM], %[t]\n\t"
         "v_mul_f32 %[c2], %[RM], %[t]\n\t"
-        "v_fmac_f32 %[RJ], %[E], %[t]\n\t"
+        SNK_ACC3163("%[RJ]", "%[t]")
         "s_nop 0\n\t"
         "v_permlane32_swap_b32 %[r2], %[c2]\n\t"
         "v_add_f32 %[dv], %[dv], %[r2]\n\t"
         "v_add_f32 %[dv], %[dv], %[c2]\n\t"
         : [t] "=&v"(t), [xA] "=&v"(xA), [xB] "=&v"(xB), [r2] "=&v"(r2), [c2] "=&v"(c2),
           [s0] "=&s"(s0), [s1] "=&s"(s1), [s2] "=&s"(s2), [s3] "=&s"(s3), [s4] "=&s"(s4), [RJ] "+v"(RJ), [dv] "+v"(dv)
-        : [RM] "v"(RM), [RJnorm] "v"(RJnorm), [EPS] "v"(EPS), [E] "v"(E3163), [lowmask] "s"(lowmask),
+        : [RM] "v"(RM), [RJnorm] "v"(RJnorm), [lowmask] "s"(lowmask),
           [NLn] "n"(NL));
     if (RES) asm volatile("v_max3_f32 %[lsq], %[lsq], |%[r2]|, |%[c2]|" : [lsq] "+v"(lsq) : [r2] "v"(r2), [c2] "v"(c2));
 }
@@ -1078,7 +1085,7 @@ __device__ __forceinline__ void cone_step(float& RJ, const float RM, const float
     "v_readlane_b32 s88, %[t1], 31\n\t" \
     "v_readlane_b32 s89, %[t1], 63\n\t" \
     "s_nop 0\n\t" \
-    "v_fma_f32 v254, s88, s88, %[EPS]\n\t" \
+    "v_fma_f32 v254, s88, s88, 1\n\t" \
     "v_fma_f32 v254, s89, s89, v254\n\t" \
     "v_rsq_f32 v254, v254\n\t" \
     "s_nop 0\n\t" \
@@ -1090,20 +1097,20 @@ __device__ __forceinline__ void cone_step(float& RJ, const float RM, const float
     "v_readlane_b32 s88, %[t2], 31\n\t" \
     "v_readlane_b32 s89, %[t2], 63\n\t" \
     "v_mul_f32 v251, %[RM1], v250\n\t" \
-    "v_fmac_f32 %[RJ1], %[E], v250\n\t" \
-    "v_fma_f32 v254, s88, s88, %[EPS]\n\t" \
+    SNK_ACC3163("%[RJ1]", "v250") \
+    "v_fma_f32 v254, s88, s88, 1\n\t" \
     "v_fma_f32 v254, s89, s89, v254\n\t" \
     "v_rsq_f32 v254, v254\n\t" \
     "s_nop 0\n\t" \
     "v_mul_f32_e64 v254, %[l2], v254 clamp\n\t" \
     "v_pk_fma_f32 v[252:253], v[254:255], s[88:89], v[252:253] op_sel_hi:[0,1,1] neg_lo:[0,1,1] neg_hi:[0,1,1]\n\t" \
     "v_cndmask_b32_e64 v252, v253, v252, %[lowmask]\n\t" \
-    "v_mul_f32 v253, %[RM2], v252\n\t" \
-    "v_fmac_f32 %[RJ2], %[E], v252\n\t"
+    "v_mul_f32 v253, %[RM2], v252\n\t"
 #define SNK_CONE2_TAIL                           \
     "v_add_f32 v251, v251, v253\n\t"           \
     "v_mov_b32 v253, v251\n\t"                 \
-    "s_nop 1\n\t"                              \
+    SNK_ACC3163("%[RJ2]", "v252")                \
+    "s_nop 0\n\t"                              \
     "v_permlane32_swap_b32 v251, v253\n\t"     \
     "v_add_f32 %[dv], %[dv], v251\n\t"         \
     "v_add_f32 %[dv], %[dv], v253\n\t"
@@ -1122,7 +1129,7 @@ __device__ __forceinline__ void cone2_step(float& RJ1, const float RM1, float& R
                      SNK_CONE2_TAIL
                      : [t1] "=&v"(t1), [t2] "=&v"(t2), [l1] "=&s"(l1), [l2] "=&s"(l2), [RJ1] "+v"(RJ1), [RJ2] "+v"(RJ2),
                        [dv] "+v"(dv), [lsq] "+v"(lsq)
-                     : [RM1] "v"(RM1), [RM2] "v"(RM2), [RJn] "v"(RJnorm), [EPS] "v"(EPS), [E] "v"(E3163),
+                     : [RM1] "v"(RM1), [RM2] "v"(RM2), [RJn] "v"(RJnorm),
                        [lowmask] "s"(lowmask)
                      : "v250", "v251", "v252", "v253", "v254", "v255", "s84", "s85", "s86", "s87", "s88", "s89");
     else
@@ -1130,7 +1137,7 @@ __device__ __forceinline__ void cone2_step(float& RJ1, const float RM1, float& R
                      SNK_CONE2_TAIL
                      : [t1] "=&v"(t1), [t2] "=&v"(t2), [l1] "=&s"(l1), [l2] "=&s"(l2), [RJ1] "+v"(RJ1), [RJ2] "+v"(RJ2),
                        [dv] "+v"(dv)
-                     : [RM1] "v"(RM1), [RM2] "v"(RM2), [RJn] "v"(RJnorm), [EPS] "v"(EPS), [E] "v"(E3163),
+                     : [RM1] "v"(RM1), [RM2] "v"(RM2), [RJn] "v"(RJnorm),
                        [lowmask] "s"(lowmask)
                      : "v250", "v251", "v252", "v253", "v254", "v255", "s84", "s85", "s86", "s87", "s88", "s89");
 }
@@ -1278,8 +1285,9 @@ __device__ __forceinline__ void contact_rows(float (&RJ)[kSlots], float (&RM)[kS
 }
 
 template <class LT>
-__device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane, float mu, int& iters, int& ncontacts,
+__device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane_in, float mu, int& iters, int& ncontacts,
                                            const SensorHint& hint, unsigned long long* __restrict__ ovf) {
+    int lane = lane_in;
     constexpr int N = LT::kN;
     constexpr int ND = N + 6;
     static_assert(N == 16, "v2 is laid out for the 16-link chain");
@@ -1329,7 +1337,7 @@ __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane, f
     // runs while at most the 128 friction-row registers are live: motors go to LDS first,
     // then friction A, friction B, normals through the 64-row staging, motors are loaded last.
     float RJ[kSlots], RM[kSlots];
-    float RMm[16], TARGV, PMIV;   // PMIV: per-lane bound on y = dI * den (clamped motors only)
+    float RMm[16], TARGV;
     bool malive;                  // every motor row has a positive denominator
     float wsum = 0.f;             // sum over the normal rows of M^-1 J^T x (the impulse the row starts from), per half
     {
@@ -1391,7 +1399,6 @@ __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane, f
             const int jm = mot ? K.d - 6 : 0;
             const float dinv_m = mot ? L.MmS[jm][2] : 0.f;
             TARGV = (mot && dinv_m > 0.f) ? L.MmS[jm][3] : 0.f;
-            PMIV = (M.max_motor_imp < 1e30f && dinv_m > 0.f) ? M.max_motor_imp / dinv_m : 1e30f;
             malive = __all(!mot || dinv_m > 0.f) != 0;
         }
         lds_sync();
@@ -1489,7 +1496,8 @@ __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane, f
         const float mi = M.max_motor_imp;
         const bool mclamp = mi < 1e30f;
         float ACCV = 0.f;     // accumulated motor impulses, motor j in lane 6+j
-        const float thr = sqrtf(M.resid_thr);
+        // (a wave-uniform value, pinned to a scalar register: the solve has no vector register to spare)
+        const float thr = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(sqrtf(M.resid_thr))));
         const int n_iter = M.n_iter;
         const bool cone = M.cone != 0;
         int it = 0;
@@ -1528,11 +1536,18 @@ __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane, f
             // iterations and backwards on even ones.  The motors' residual is always tracked
             // (one v_max per row); it decides which body runs for the ~190 contact rows.
             float mres;
+            // the per-lane bound on y = dI * den of a clamped motor (max_motor_impulse finite: not the reference's
+            // forces = inf), rebuilt from LDS in every sweep that needs it rather than held in a register for all
+            auto pmiv = [&]() {
+                const bool mot = d >= 6 && d < ND;
+                const float dinv_m = mot ? L.MmS[mot ? d - 6 : 0][2] : 0.f;
+                return (dinv_m > 0.f) ? mi / dinv_m : 1e30f;
+            };
 #define SNK_MOTORS(FWD)                                                                             \
-    mres = malive ? (mclamp ? motors16<FWD, true, true>(L, RMm, dv, TARGV, ACCV, PMIV)               \
-                            : motors16<FWD, false, true>(L, RMm, dv, TARGV, ACCV, PMIV))             \
-                  : (mclamp ? motors16<FWD, true, false>(L, RMm, dv, TARGV, ACCV, PMIV)              \
-                            : motors16<FWD, false, false>(L, RMm, dv, TARGV, ACCV, PMIV));
+    mres = malive ? (mclamp ? motors16<FWD, true, true>(L, RMm, dv, TARGV, ACCV, pmiv())             \
+                            : motors16<FWD, false, true>(L, RMm, dv, TARGV, ACCV, 0.f))              \
+                  : (mclamp ? motors16<FWD, true, false>(L, RMm, dv, TARGV, ACCV, pmiv())            \
+                            : motors16<FWD, false, false>(L, RMm, dv, TARGV, ACCV, 0.f));
             if (it & 1) {
                 limit_rows(true);
                 SNK_MOTORS(true)
@@ -1554,8 +1569,11 @@ __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane, f
             if (!exceeded || it >= n_iter - 1) { it++; break; }
         }
         iters = it;
+        // The lane index is re-derived here (v_mbcnt) instead of being kept in a register across the solve: the row
+        // registers leave none to spare (the callers do the same after the substep returns).
+        lane = lane_id();
         // accumulated impulses -> LDS (friction back from units of mu)
-        if (d == 31) {
+        if ((lane & 31) == 31) {
             const int h = lane >> 5;
 #pragma unroll
             for (int s = 0; s < kSlotFric; s++) L.app[kAppNormal + 2 * s + h] = RJ[kSlotNormal + s];

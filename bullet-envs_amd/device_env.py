@@ -124,9 +124,9 @@ class ShardedVecEnv(object):
         return None if allp is None else allp[:, :self.O]
 
     def step(self, actions=None):
-        """The root's `actions` (tensor or ndarray [world * E, A] or [.., A, 1]) are clipped to [-1, 1] IN PLACE, as
-        checkBound does to the caller's array (SnakeGymEnv.py:82-88): the step kernels clip the scattered copies,
-        and the root applies the same clamp to the caller's own buffer."""
+        """The root's `actions` (tensor or ndarray [world * E, A] or [.., A, 1]) are NOT modified: SubprocVecEnv pickles
+        them to its workers (ppo/multiprocessing_env.py:119-122), so checkBound (SnakeGymEnv.py:82-88) only ever clips
+        the workers' copies -- here the scattered copies, which the step kernels clip."""
         t = self.torch
         if self.rank == self.root:
             a = t.as_tensor(actions, dtype=t.float32)       # shares memory with a float32 ndarray / tensor
@@ -139,10 +139,6 @@ class ShardedVecEnv(object):
             chunks = None
         self.dist.scatter(self._act, chunks, src=self.root, group=self.group)
         obs, rew, done = self.env.step(self._act.to(self.device))
-        if a2 is not None:
-            a2.clamp_(-1.0, 1.0)
-            if isinstance(actions, np.ndarray) and actions.dtype != np.float32:
-                np.clip(actions, -1.0, 1.0, out=actions)
         allp = self._gather_pack(obs, rew, done)
         if allp is None:
             return None, None, None, ()

@@ -270,8 +270,10 @@ class VecEnv(object):
 
 
 def _as_action_matrix(actions, n_envs, act_dim):
-    """(N,8) from PPO (ppo/train.py:122), (N,8,1) from ARS (ars/train.py:95-99), lists of either."""
-    a = np.asarray(actions, dtype=np.float32)
+    """(N,8) from PPO (ppo/train.py:122), (N,8,1) from ARS (ars/train.py:95-99), lists of either.  Always a COPY: the
+    reference's SubprocVecEnv pickles the actions to its workers (ppo/multiprocessing_env.py:119-122), so checkBound's
+    in-place clip (SnakeGymEnv.py:82-88) never reaches the trainer's array -- only the single-env seam mutates it."""
+    a = np.array(actions, dtype=np.float32)
     if a.shape == (n_envs, act_dim, 1):
         a = a[:, :, 0]
     if a.shape != (n_envs, act_dim):

@@ -1,7 +1,7 @@
-"""World-size-2 test of the sharded vector env on CPU (gloo).  The per-rank stepper is a
-test double backed by the CPU oracle, so this exercises exactly the product's sharding /
-scatter / gather plumbing (bullet-envs_amd/device_env.py:ShardedVecEnv), which on the GPU box
-runs over RCCL."""
+"""World-size 2, 4 and 8 tests of the sharded vector env on CPU (gloo), trainer rank 0 and not 0.  The per-rank
+stepper is a test double backed by the CPU oracle, so this exercises exactly the product's sharding / scatter / gather
+plumbing (bullet-envs_amd/device_env.py:ShardedVecEnv: slice arithmetic, root != 0, one packed gather), which on the
+GPU node runs over RCCL."""
 import importlib
 import os
 import socket
@@ -45,29 +45,32 @@ def _actions(j, n):
     return a * np.float32(1.5) if j == 1 else a       # step 1 leaves the [-1, 1] box: checkBound must clip it
 
 
-def _worker(rank, world, port, out_path):
+def _worker(rank, world, port, out_path, root):
     sys.path.insert(0, ROOT)
+    import torch
     import torch.distributed as dist
+    torch.set_num_threads(1)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     pkg = importlib.import_module("bullet-envs_amd")
     local = OracleLocalEnv(list(range(rank * E, (rank + 1) * E)))
-    env = pkg.ShardedVecEnv(local, root=0)
+    env = pkg.ShardedVecEnv(local, root=root)
     assert env.num_envs == world * E and len(env) == world * E
     assert env.shard_slice() == slice(rank * E, (rank + 1) * E)
     res = {}
     obs0 = env.reset()
-    if rank == 0:
+    if rank == root:
         res["reset"] = obs0.numpy().copy()
     else:
         assert obs0 is None
     for j in range(STEPS):
-        acts = _actions(j, world * E) if rank == 0 else None
+        acts = _actions(j, world * E) if rank == root else None
         out = env.step(acts)
-        if rank == 0:
-            # the caller's array is clipped in place (SnakeGymEnv.py:82-88), on every shard's rows
-            assert np.array_equal(acts, np.clip(_actions(j, world * E), -1, 1))
+        if rank == root:
+            # the caller's array is NOT touched: SubprocVecEnv pickles the actions to its workers
+            # (ppo/multiprocessing_env.py:119-122), so checkBound (SnakeGymEnv.py:82-88) clips the workers' copies
+            assert np.array_equal(acts, _actions(j, world * E))
             obs, rew, done, infos = out
             assert len(infos) == world * E and obs.shape == (world * E, 56)
             res["obs%d" % j] = obs.numpy().copy()
@@ -75,26 +78,27 @@ def _worker(rank, world, port, out_path):
             res["done%d" % j] = done.numpy().copy()
         else:
             assert out[0] is None
-    if rank == 0:
+    if rank == root:
         np.savez(out_path, **res)
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_sharded_env_world2_gloo(tmp_path, oracle_mod):
+@pytest.mark.parametrize("world,root", [(2, 0), (4, 3), (8, 5)])
+def test_sharded_env_gloo(tmp_path, oracle_mod, world, root):
     import torch.multiprocessing as mp
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     out_path = str(tmp_path / "sharded.npz")
-    mp.spawn(_worker, args=(2, port, out_path), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, port, out_path, root), nprocs=world, join=True)
     got = np.load(out_path)
-    # the same 4 envs stepped directly, unsharded
-    ref = [oracle_mod.OracleEnv() for _ in range(2 * E)]
+    # the same world * E envs stepped directly, unsharded: global env g lives on rank g // E whoever the trainer rank is
+    ref = [oracle_mod.OracleEnv() for _ in range(world * E)]
     assert np.allclose(got["reset"], np.stack([e.reset() for e in ref]))
     for j in range(STEPS):
-        a = _actions(j, 2 * E)
+        a = _actions(j, world * E)
         for i, e in enumerate(ref):
             o, r, d, _, _ = e.env_step(a[i].astype(np.float64), vec_mode=True)
             assert np.allclose(got["obs%d" % j][i], o.astype(np.float32))

@@ -270,12 +270,13 @@ def test_env_step_parity_random_actions(pkg, oracle_mod, n):
                                   dict(n_modules=16, obstacle=1, obstacle_pos=[0.25, 0.0, 0.1]),
                                   dict(ROUND1, n_modules=16, obstacle=1, obstacle_pos=[0.25, 0.0, 0.1]),
                                   dict(ROUND1, n_modules=16), dict(n_modules=16, warm_start=1)])
-def test_outputs_do_not_depend_on_what_ran_before(pkg, over):
+def test_outputs_do_not_depend_on_what_ran_before(pkg, monkeypatch, over):
     """Every output of a step -- observation incl. the force sensor, reward, done, substep count, the joint-3 read-out --
     is a function of state and action only: two handles, one created after kernels of ANOTHER configuration have run on
     the chip (their leftovers sit in LDS and in the recycled device allocations), give bit-identical results.  (Round 2:
     the streamed-row constraint pass read an unwritten LDS table under contact_model 1; states matched, sensor and reward
-    differed from run to run.)"""
+    differed from run to run.)  A third run does not leave it to luck what those leftovers are: SNK_POISON=1 fills the LDS
+    image of every environment and every fresh device allocation with NaNs before use."""
     import bench
     n = over["n_modules"]
     B, A = 96, n // 2
@@ -302,5 +303,9 @@ def test_outputs_do_not_depend_on_what_ran_before(pkg, over):
     other.step(bench.gait_actions(np.arange(512), 0, (48 - n) // 2).astype(np.float32))
     other.close()
     second = run()
-    for x, y in zip(first, second):
+    monkeypatch.setenv("SNK_POISON", "1")
+    third = run()
+    monkeypatch.delenv("SNK_POISON")
+    for x, y, z in zip(first, second, third):
         assert np.array_equal(x, y, equal_nan=True)
+        assert np.all(np.isfinite(z)) and np.array_equal(x, z)

@@ -108,8 +108,12 @@ def test_vec_env_semantics(pkg, oracle_mod):
     assert np.all(obs[:, :51] == 0) and np.all(obs[:, 51:55] == [0, 0, 0, 1])
     seen_done = False
     for j in range(8):
-        a = gait(range(B), j)
+        a = gait(range(B), j) * (np.float32(1.5) if j == 3 else np.float32(1.0))
+        a_before = a.copy()
         obs, rews, dones, infos = env.step(a[:, :, None] if j % 2 else a)   # ARS shape (N,8,1) / PPO (N,8)
+        # SubprocVecEnv pickles the actions to its workers (ppo/multiprocessing_env.py:119-122): checkBound clips THEIR
+        # copies, the trainer's array stays as it was (only the single-env seam mutates the caller's array)
+        assert np.array_equal(a, a_before)
         assert isinstance(obs, np.ndarray) and rews.shape == (B,) and dones.dtype == bool
         assert isinstance(infos, tuple) and len(infos) == B and infos[0] == {}
         assert (1 - dones).sum() + dones.sum() == B                        # ppo/train.py:134
