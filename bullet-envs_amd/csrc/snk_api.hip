@@ -86,13 +86,13 @@ int launch_step(snk_handle* h, float* act, float* obs, float* rew, uint8_t* done
     if (h->plan)
         hipLaunchKernelGGL((snk::plan_kernel<N>), dim3(1), dim3(1024), 0, st, h->d_model, h->d_recs, act, h->d_order,
                            h->n_envs);
-    hipLaunchKernelGGL((snk::env_step_kernel<N, V2>), dim3(h->n_envs), dim3(64), h->lds_bytes, st, h->d_model, h->d_recs,
+    hipLaunchKernelGGL((snk::env_step_kernel<N, V2>), dim3(h->grid_waves), dim3(64), h->lds_bytes, st, h->d_model, h->d_recs,
                        h->d_mu, act, obs, rew, done, sub, vec_mode, h->n_envs, h->plan ? h->d_order : nullptr, h->d_rows, h->d_mf, h->d_ovf);
     return 0;
 }
 template <int N, bool V2>
 int launch_substep(snk_handle* h, const float* tgt, int k, int32_t* info, hipStream_t st) {
-    hipLaunchKernelGGL((snk::substep_kernel<N, V2>), dim3(h->n_envs), dim3(64), h->lds_bytes, st, h->d_model, h->d_recs,
+    hipLaunchKernelGGL((snk::substep_kernel<N, V2>), dim3(h->grid_waves), dim3(64), h->lds_bytes, st, h->d_model, h->d_recs,
                        h->d_mu, tgt, k, info, h->n_envs, h->d_rows, h->d_mf, h->d_ovf);
     return 0;
 }
@@ -278,11 +278,18 @@ int init_handle(snk_handle* h, const snk_params* p, int32_t n_envs, int32_t devi
         HIP_TRY(hipMemset(h->d_rew, 0xFF, ne * sizeof(float))); HIP_TRY(hipMemset(h->d_tgt, 0xFF, ne * h->n * sizeof(float)));
         HIP_TRY(hipMemset(h->d_h, 0xFF, ne * sizeof(float)));
     }
+    {
+        int waves = 0;
+        rc = resident_waves(h->lds_bytes, device, &waves);
+        if (rc) return rc;
+        h->grid_waves = waves > 0 && waves < n_envs ? waves : n_envs;
+    }
     if (!h->v2) {
-        // one block per environment for the kernels launched one workgroup per environment (snk_substep_host, the
-        // unscheduled step kernel); the scheduled step kernel uses the first `resident waves` of them
+        // one block of streamed constraint rows per RESIDENT WAVE (every step / substep kernel is launched with that many
+        // workgroups and strides over the environments): 2048 x 112 KB = 230 MB for 32 links, whatever n_envs is
         const size_t rf = h->n == 32 ? snk::Lds<32, false>::kRowFloats : snk::Lds<16, false>::kRowFloats;
-        const size_t bytes = ne * rf * sizeof(float);
+        const size_t nb = (size_t)h->grid_waves;
+        const size_t bytes = nb * rf * sizeof(float);
         HIP_TRY(hipMalloc(&h->d_rows, bytes));
         HIP_TRY(hipMemset(h->d_rows, poison ? 0xFF : 0, bytes));
         // what the kernels rely on being zero for good: the last three rows of every block (the refill of a skipped
@@ -293,7 +300,7 @@ int init_handle(snk_handle* h, const snk_params* p, int32_t n_envs, int32_t devi
         const size_t m0 = h->n == 32 ? snk::Lds<32, false>::kMmOff : snk::Lds<16, false>::kMmOff;
         const size_t m1 = h->n == 32 ? snk::Lds<32, false>::kYOff : snk::Lds<16, false>::kYOff;
         if (poison)
-            for (size_t e = 0; e < ne; e++) {
+            for (size_t e = 0; e < nb; e++) {
                 HIP_TRY(hipMemsetAsync(h->d_rows + e * rf + z0, 0, zn * sizeof(float), nullptr));
                 HIP_TRY(hipMemsetAsync(h->d_rows + e * rf + m0, 0, (m1 - m0) * sizeof(float), nullptr));
             }
@@ -338,10 +345,6 @@ int init_handle(snk_handle* h, const snk_params* p, int32_t n_envs, int32_t devi
         HIP_TRY(hipHostMalloc(&h->h_alarm, 64 * sizeof(int32_t), hipHostMallocMapped));
         memset(h->h_alarm, 0, 64 * sizeof(int32_t));
         HIP_TRY(hipHostGetDevicePointer((void**)&sc.alarm, h->h_alarm, 0));
-        int waves = 0;
-        rc = resident_waves(h->lds_bytes, device, &waves);
-        if (rc) return rc;
-        h->grid_waves = waves > 0 && waves < n_envs ? waves : n_envs;
 #ifdef SNK_SCHED_DEBUG
         HIP_TRY(hipMalloc(&sc.wstat, (size_t)h->grid_waves * 8 * sizeof(long long)));
 #endif

@@ -1672,11 +1672,16 @@ __device__ __forceinline__ void load_mf(LT& L, const float* __restrict__ mf, int
     if constexpr (LT::kV2) {
         if (mf) {
             lane = launder_lane(lane);
-            for (int i = lane; i < 2 * LT::kN * kMfFloats; i += 64) {
-                const int c = i / kMfFloats, f = i - c * kMfFloats;
-                const float v = mf[i];
-                if (f == 0) L.mfn[c] = (unsigned char)(v < 0.f ? 0.f : (v > 4.f ? 4.f : v));
-                else if (f >= 4) L.mfl[f - 4][c] = v;
+            // the counts first (lane = cylinder), then only the points that exist: most cylinders hold one or two of
+            // their four slots, and the rest of a cylinder's 112 bytes need not travel
+            if (lane < 2 * LT::kN) {
+                const float v = mf[(size_t)lane * kMfFloats];
+                L.mfn[lane] = (unsigned char)(v < 0.f ? 0.f : (v > 4.f ? 4.f : v));
+            }
+            lds_sync();
+            for (int i = lane; i < 2 * LT::kN * 24; i += 64) {
+                const int c = i / 24, f = i - c * 24;
+                if (f < 6 * (int)L.mfn[c]) L.mfl[f][c] = mf[(size_t)c * kMfFloats + 4 + f];
             }
             lds_sync();
         }
@@ -1688,11 +1693,14 @@ __device__ __forceinline__ void store_mf(LT& L, float* __restrict__ mf, int lane
         if (mf) {
             lane = launder_lane(lane);
             lds_sync();
-            for (int i = lane; i < 2 * LT::kN * kMfFloats; i += 64) {
-                const int c = i / kMfFloats, f = i - c * kMfFloats;
-                const float v = f == 0 ? (float)L.mfn[c] : (f >= 4 ? L.mfl[f - 4][c] : 0.f);
-                if (THROUGH) asm volatile("global_store_dword %0, %1, off sc1" : : "v"(mf + i), "v"(v) : "memory");
-                else mf[i] = v;
+            auto put = [&](float* p, float v) {
+                if (THROUGH) asm volatile("global_store_dword %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+                else *p = v;
+            };
+            if (lane < 2 * LT::kN) put(mf + (size_t)lane * kMfFloats, (float)L.mfn[lane]);
+            for (int i = lane; i < 2 * LT::kN * 24; i += 64) {
+                const int c = i / 24, f = i - c * 24;
+                if (f < 6 * (int)L.mfn[c]) put(mf + (size_t)c * kMfFloats + 4 + f, L.mfl[f][c]);
             }
         }
     }
@@ -1733,9 +1741,10 @@ __global__ __launch_bounds__(64, 2) void env_step_kernel(const DevModel* __restr
     using LT = Lds<N, V2>;
     LT& L = *reinterpret_cast<LT*>(smem_raw);
     const DevModel& M = *Mp;
-    if ((int)blockIdx.x >= n_envs) return;
-    // longest-first schedule: workgroup b takes the env with the b-th largest predicted work
-    const int env = order ? __builtin_amdgcn_readfirstlane(order[blockIdx.x]) : (int)blockIdx.x;
+    // longest-first schedule: workgroup b takes the envs with the b-th, (b + G)-th, ... largest predicted work (G
+    // workgroups: as many as the chip holds at once; the block of streamed constraint rows belongs to the WORKGROUP)
+    for (int slot_ = blockIdx.x; slot_ < n_envs; slot_ += gridDim.x) {
+    const int env = order ? __builtin_amdgcn_readfirstlane(order[slot_]) : slot_;
     const int lane = threadIdx.x;
     if (M.poison) { L.poison(lane); lds_sync(); }
     load_rec(L, recs + (size_t)env * LT::REC, lane);
@@ -1758,7 +1767,7 @@ __global__ __launch_bounds__(64, 2) void env_step_kernel(const DevModel* __restr
     lds_sync();
     float mu = fminf(M.mu_link * mu_plane[env], 10.0f);
     float* env_rows = nullptr;      // constraint rows of chains too long for the register-resident solve
-    if constexpr (!LT::kV2) env_rows = rows_all + (size_t)env * LT::kRowFloats;
+    if constexpr (!LT::kV2) env_rows = rows_all + (size_t)blockIdx.x * LT::kRowFloats;
     float* env_mf = mf_all ? mf_all + (size_t)env * (2 * N * kMfFloats) : nullptr;   // contact cache (contact_model 1)
     load_mf(L, env_mf, lane);
     fk_vel(L, M, lane);
@@ -1808,6 +1817,8 @@ __global__ __launch_bounds__(64, 2) void env_step_kernel(const DevModel* __restr
     }
     store_rec(L, recs + (size_t)env * LT::REC, lane);
     store_mf<LT, false>(L, env_mf, lane);
+    lds_sync();
+    }
 }
 
 template <int N, bool V2>
@@ -1820,9 +1831,8 @@ __global__ __launch_bounds__(64, 2) void substep_kernel(const DevModel* __restri
     using LT = Lds<N, V2>;
     LT& L = *reinterpret_cast<LT*>(smem_raw);
     const DevModel& M = *Mp;
-    const int env = blockIdx.x;
     const int lane = threadIdx.x;
-    if (env >= n_envs) return;
+    for (int env = blockIdx.x; env < n_envs; env += gridDim.x) {      // (the block of streamed rows belongs to the workgroup)
     if (M.poison) { L.poison(lane); lds_sync(); }
     load_rec(L, recs + (size_t)env * LT::REC, lane);
     if (lane < N) L.targets[lane] = targets[(size_t)env * N + lane];
@@ -1833,13 +1843,15 @@ __global__ __launch_bounds__(64, 2) void substep_kernel(const DevModel* __restri
     SensorHint hint;
     hint.always = true; hint.counter_next = 0; hint.h_prev = 0.f;
     float* env_rows = nullptr;
-    if constexpr (!LT::kV2) env_rows = rows_all + (size_t)env * LT::kRowFloats;
+    if constexpr (!LT::kV2) env_rows = rows_all + (size_t)blockIdx.x * LT::kRowFloats;
     float* env_mf = mf_all ? mf_all + (size_t)env * (2 * N * kMfFloats) : nullptr;
     load_mf(L, env_mf, lane);
     for (int s = 0; s < k; s++) substep(L, M, lane, mu, iters, nc, hint, env_rows, env_mf, ovf);
     if (info && lane == 0) { info[2 * env] = iters; info[2 * env + 1] = nc; }
     store_rec(L, recs + (size_t)env * LT::REC, lane);
     store_mf<LT, false>(L, env_mf, lane);
+    lds_sync();
+    }
 }
 
 template <int N, bool V2>

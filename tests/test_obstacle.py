@@ -149,6 +149,33 @@ def test_add_obstacle_mirror(pkg):
 
 
 @gpu
+def test_test_mode_survives_world_rebuilds(pkg):
+    """mode='test' replays every env-step substep by substep on a scratch handle (SnakeGymEnv._record_telemetry) and
+    insists on ending on the step kernel's bits.  The scratch handle must follow the world: add_obstacle AFTER a first
+    step rebuilds it with the box, a hard reset empties its contact cache like the main handle's."""
+    import argparse
+    import bench
+    args = argparse.Namespace(alpha=1.0, beta=0.01, gamma=0.1, mode="test", gaitSelection=1, scaling_factor=6,
+                              motorVelocityLimit=np.inf, motorTorqueLimit=np.inf)
+    robot = pkg.Snake(None, None, args=args)
+    env = pkg.SnakeGymEnv(robot, args=args)
+    env.reset()
+    o, r, d, info = env.step(bench.gait_actions([5], 0)[0].astype(np.float64))
+    assert len(info["internal_observations"]) == robot.counter > 0
+    robot.add_obstacle("block.urdf", [0.100, 0.0, 0.1])              # a hard reset of the world, now with the box
+    mx = 0.0
+    for j in range(6):
+        o, r, d, info = env.step(bench.gait_actions([5], j)[0].astype(np.float64))     # raises if the replay diverges
+        assert len(info["link_positions"]) == robot.counter
+        mx = max(mx, abs(float(env._stepper.joint3_reaction_fz()[0])))
+    assert o[48] < 0.004 and mx > 10.0                                # the box is there, in both handles
+    env.reset(hardReset=True)                                          # a populated contact cache must not survive
+    for j in range(3):
+        o, r, d, info = env.step(bench.gait_actions([5], j)[0].astype(np.float64))
+    env.close()
+
+
+@gpu
 @pytest.mark.parametrize("box", [False, True])
 def test_two_solves_one_physics(pkg, monkeypatch, box):
     """The 16-link chain through both solves: rows resident in registers (lane = row builder, two rows per register) and
