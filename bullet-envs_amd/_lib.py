@@ -21,6 +21,7 @@ class SnkParams(C.Structure):
         ("hull_sides", C.c_int32), ("contact_model", C.c_int32),
         ("self_collision", C.c_int32), ("obstacle", C.c_int32),
         ("obstacle_pos", C.c_double * 3), ("obstacle_half", C.c_double * 3), ("mu_obstacle", C.c_double),
+        ("obstacle_mass", C.c_double),
         ("dt", C.c_double), ("gravity_z", C.c_double),
         ("lin_damping", C.c_double), ("ang_damping", C.c_double),
         ("joint_damping", C.c_double), ("max_coord_vel", C.c_double),
@@ -68,6 +69,8 @@ SYMBOLS = {
     "snk_get_manifold": (C.c_int, [_vp, _F]),
     "snk_set_manifold": (C.c_int, [_vp, _F]),
     "snk_contact_overflow": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
+    "snk_get_box": (C.c_int, [_vp, _F, _F]),
+    "snk_set_box": (C.c_int, [_vp, _F, _F]),
     "snk_get_obs": (C.c_int, [_vp, _F]),
     "snk_mean_height": (C.c_int, [_vp, _F]),
     "snk_link_positions": (C.c_int, [_vp, _F]),
@@ -227,6 +230,24 @@ class Stepper:
         m = np.ascontiguousarray(m, dtype=np.float32)
         assert m.shape == (self.n_envs, 2 * self.n, 29)
         check(self.lib.snk_set_manifold(self.h, fptr(m)), "snk_set_manifold")
+
+    def get_box(self):
+        """obstacle 2: (state [n_envs, 13], manifold with the plane [n_envs, 29]) of the free box."""
+        s = np.zeros((self.n_envs, 13), dtype=np.float32)
+        m = np.zeros((self.n_envs, 29), dtype=np.float32)
+        check(self.lib.snk_get_box(self.h, fptr(s), fptr(m)), "snk_get_box")
+        return s, m
+
+    def set_box(self, state=None, manifold=None):
+        s = m = None
+        if state is not None:
+            s = np.ascontiguousarray(state, dtype=np.float32)
+            assert s.shape == (self.n_envs, 13)
+        if manifold is not None:
+            m = np.ascontiguousarray(manifold, dtype=np.float32)
+            assert m.shape == (self.n_envs, 29)
+        check(self.lib.snk_set_box(self.h, fptr(s) if s is not None else None, fptr(m) if m is not None else None),
+              "snk_set_box")
 
     def contact_overflow(self):
         """(substeps with more ground-contact points than slots, points left without rows, link-link / obstacle contacts

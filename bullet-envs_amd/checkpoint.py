@@ -23,10 +23,13 @@ def save_state(env, path):
     state, aux = st.get_state()
     # the EFFECTIVE friction, read back from the device (also covers values set through the C ABI directly)
     mf = st.get_manifold()           # the contact cache is simulator state too (contact_model 1)
+    box = st.get_box() if st.params.obstacle == 2 else None      # ... and so is a free obstacle box
     np.savez_compressed(path, state=state, aux=aux, n_envs=np.int64(st.n_envs),
                         params=np.frombuffer(bytes(st.params), dtype=np.uint8),
                         ground_friction=st.get_ground_friction(),
-                        manifold=np.zeros(0, np.float32) if mf is None else mf)
+                        manifold=np.zeros(0, np.float32) if mf is None else mf,
+                        box_state=np.zeros(0, np.float32) if box is None else box[0],
+                        box_manifold=np.zeros(0, np.float32) if box is None else box[1])
 
 
 def load_state(env, path):
@@ -43,3 +46,5 @@ def load_state(env, path):
         st.set_state(z["state"], z["aux"])
         if "manifold" in z.files and z["manifold"].size:
             st.set_manifold(z["manifold"])
+        if "box_state" in z.files and z["box_state"].size:
+            st.set_box(z["box_state"], z["box_manifold"])

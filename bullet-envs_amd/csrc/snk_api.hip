@@ -54,6 +54,7 @@ struct snk_handle {
     float* d_mf = nullptr;        // contact_model 1: the persistent contact manifolds, [n_envs][2n][kMfFloats]
     float* d_rows = nullptr;      // 32-link chains: constraint rows streamed from global memory (snk_device.hpp: pgs_v1)
     unsigned long long* d_ovf = nullptr;   // contacts the solves had no room for (snk_contact_overflow): 3 counters
+    float* d_box = nullptr;       // obstacle 2: the free box of every env, [n_envs][kBoxFloats] (state 13, count, manifold 24)
     int32_t* d_order = nullptr;
     bool plan = true;
     // in-launch scheduler of env_step_sched_kernel (snk_device.hpp): rings, counters, the host-mapped alarm word
@@ -78,7 +79,7 @@ int launch_step(snk_handle* h, float* act, float* obs, float* rew, uint8_t* done
                            h->n_envs);
         snk::StepArgs a;
         a.recs = h->d_recs; a.mu_plane = h->d_mu; a.actions = act; a.obs = obs; a.rew = rew; a.done = done; a.substeps = sub;
-        a.rows_all = h->d_rows; a.mf_all = h->d_mf; a.ovf = h->d_ovf; a.sc = h->sched;
+        a.rows_all = h->d_rows; a.mf_all = h->d_mf; a.ovf = h->d_ovf; a.box_all = h->d_box; a.sc = h->sched;
         a.model_slot = h->model_slot; a.vec_mode = vec_mode; a.n_envs = h->n_envs; a.pad_ = 0;
         hipLaunchKernelGGL((snk::env_step_sched_kernel<N, V2>), dim3(h->grid_waves), dim3(64), h->lds_bytes, st, a);
         return 0;
@@ -87,13 +88,13 @@ int launch_step(snk_handle* h, float* act, float* obs, float* rew, uint8_t* done
         hipLaunchKernelGGL((snk::plan_kernel<N>), dim3(1), dim3(1024), 0, st, h->d_model, h->d_recs, act, h->d_order,
                            h->n_envs);
     hipLaunchKernelGGL((snk::env_step_kernel<N, V2>), dim3(h->grid_waves), dim3(64), h->lds_bytes, st, h->d_model, h->d_recs,
-                       h->d_mu, act, obs, rew, done, sub, vec_mode, h->n_envs, h->plan ? h->d_order : nullptr, h->d_rows, h->d_mf, h->d_ovf);
+                       h->d_mu, act, obs, rew, done, sub, vec_mode, h->n_envs, h->plan ? h->d_order : nullptr, h->d_rows, h->d_mf, h->d_ovf, h->d_box);
     return 0;
 }
 template <int N, bool V2>
 int launch_substep(snk_handle* h, const float* tgt, int k, int32_t* info, hipStream_t st) {
     hipLaunchKernelGGL((snk::substep_kernel<N, V2>), dim3(h->grid_waves), dim3(64), h->lds_bytes, st, h->d_model, h->d_recs,
-                       h->d_mu, tgt, k, info, h->n_envs, h->d_rows, h->d_mf, h->d_ovf);
+                       h->d_mu, tgt, k, info, h->n_envs, h->d_rows, h->d_mf, h->d_ovf, h->d_box);
     return 0;
 }
 template <int N, bool V2>
@@ -195,6 +196,7 @@ void snk_default_params(snk_params* p) {
     p->obstacle_pos[0] = 2.0; p->obstacle_pos[1] = 0.0; p->obstacle_pos[2] = 0.1;
     p->obstacle_half[0] = 0.1; p->obstacle_half[1] = 0.4; p->obstacle_half[2] = 0.1;      // snake/block.urdf:16
     p->mu_obstacle = 0.5;       // [U]
+    p->obstacle_mass = 200.0;   // snake/block.urdf:6
     p->dt = 1.0 / 240.0;
     p->gravity_z = -9.8;
     p->lin_damping = 0.04;
@@ -250,7 +252,8 @@ int init_handle(snk_handle* h, const snk_params* p, int32_t n_envs, int32_t devi
     h->rec = h->D.rec_floats;
     // 16 links: the register-resident solve (the obstacle's contacts take slots out of the ground's 64).
     // SNK_FORCE_STREAMED=1 (diagnostics, tests): the streamed-row kernels for a 16-link handle too
-    h->v2 = h->n == 16 && getenv("SNK_FORCE_STREAMED") == nullptr;
+    h->v2 = h->n == 16 && getenv("SNK_FORCE_STREAMED") == nullptr && p->obstacle != 2;      // (a free box: six more
+                                                                                            //  components, streamed rows)
     h->lds_bytes = h->n == 16 ? (h->v2 ? sizeof(snk::Lds<16, true>) : sizeof(snk::Lds<16, false>)) : sizeof(snk::Lds<32, false>);
     int rc = SNK_DISPATCH(h, set_lds_attr, h->lds_bytes);
     if (rc) return rc;
@@ -304,6 +307,18 @@ int init_handle(snk_handle* h, const snk_params* p, int32_t n_envs, int32_t devi
                 HIP_TRY(hipMemsetAsync(h->d_rows + e * rf + z0, 0, zn * sizeof(float), nullptr));
                 HIP_TRY(hipMemsetAsync(h->d_rows + e * rf + m0, 0, (m1 - m0) * sizeof(float), nullptr));
             }
+    }
+    if (p->obstacle == 2) {
+        // the free box where loadURDF puts it (snake.py:84, snake_gait_test.py:51): at rest, identity orientation,
+        // empty manifold
+        std::vector<float> b(ne * snk::kBoxFloats, 0.f);
+        for (size_t e = 0; e < ne; e++) {
+            float* x = &b[e * snk::kBoxFloats];
+            for (int i = 0; i < 3; i++) x[i] = (float)p->obstacle_pos[i];
+            x[6] = 1.0f;
+        }
+        HIP_TRY(hipMalloc(&h->d_box, b.size() * sizeof(float)));
+        HIP_TRY(hipMemcpy(h->d_box, b.data(), b.size() * sizeof(float), hipMemcpyHostToDevice));
     }
     HIP_TRY(hipMalloc(&h->d_ovf, 3 * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(h->d_ovf, 0, 3 * sizeof(unsigned long long)));
@@ -365,6 +380,11 @@ int snk_create(const snk_params* p, int32_t n_envs, int32_t device, snk_handle**
     if (p->hull_sides != 0 && (p->hull_sides < 3 || p->hull_sides > 32))
         return fail("snk_create: hull_sides must be 0 (implicit cylinder) or 3 .. 32");
     if (p->contact_model != 0 && p->contact_model != 1) return fail("snk_create: contact_model must be 0 or 1");
+    if (p->obstacle < 0 || p->obstacle > 2) return fail("snk_create: obstacle must be 0, 1 (static box) or 2 (free box)");
+    if (p->obstacle == 2 && p->n_modules != 16)
+        return fail("snk_create: obstacle 2 (the free box) is built for n_modules 16 (its six velocity components sit behind "
+                    "the snake's 22 in the 40-lane solve)");
+    if (p->obstacle == 2 && !(p->obstacle_mass > 0.0)) return fail("snk_create: obstacle_mass must be positive");
     if (p->warm_start != 0 && p->warm_start != 1) return fail("snk_create: warm_start must be 0 or 1");
     if (p->warm_start && p->contact_model != 1)
         return fail("snk_create: warm_start needs contact_model 1 (the impulses live in the persistent contact cache)");
@@ -390,7 +410,7 @@ int snk_destroy(snk_handle* h) {
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
     void* bufs[] = {h->d_model, h->d_recs, h->d_mu, h->d_act, h->d_obs, h->d_rew, h->d_done,
-                    h->d_sub, h->d_mask, h->d_tgt, h->d_info, h->d_h, h->d_order, h->d_rows, h->d_linkpos, h->d_mf, h->d_ovf,
+                    h->d_sub, h->d_mask, h->d_tgt, h->d_info, h->d_h, h->d_order, h->d_rows, h->d_linkpos, h->d_mf, h->d_ovf, h->d_box,
                     h->sched.head, h->sched.tail, h->sched.ent, h->sched.waiting, h->sched.counter, h->sched.finished};
     for (void* b : bufs) (void)hipFree(b);
     if (h->h_alarm) (void)hipHostFree(h->h_alarm);
@@ -593,6 +613,57 @@ int snk_set_manifold(snk_handle* h, const float* in) {
         }
     }
     HIP_TRY(hipMemcpy(h->d_mf, dev.data(), dev.size() * sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int snk_get_box(snk_handle* h, float* state, float* manifold) {
+    if (!h) return fail("snk_get_box: null handle");
+    if (!h->d_box) return fail("snk_get_box: this handle has no free box (obstacle != 2)");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipDeviceSynchronize());
+    std::vector<float> b((size_t)h->n_envs * snk::kBoxFloats);
+    HIP_TRY(hipMemcpy(b.data(), h->d_box, b.size() * sizeof(float), hipMemcpyDeviceToHost));
+    for (size_t e = 0; e < (size_t)h->n_envs; e++) {
+        const float* x = &b[e * snk::kBoxFloats];
+        if (state) memcpy(state + 13 * e, x, 13 * sizeof(float));
+        if (manifold) {
+            float* o = manifold + 29 * e;
+            const int n = x[13] < 0.f ? 0 : (x[13] > 4.f ? 4 : (int)x[13]);
+            o[0] = (float)n;
+            for (int j = 0; j < 4; j++) {
+                const bool on = j < n;
+                for (int r = 0; r < 3; r++) o[1 + 7 * j + r] = on ? x[14 + 6 * j + r] : 0.f;
+                o[4 + 7 * j] = on ? x[17 + 6 * j] : 0.f;
+                o[5 + 7 * j] = on ? x[18 + 6 * j] : 0.f;
+                o[6 + 7 * j] = 0.f;
+                o[7 + 7 * j] = on ? x[19 + 6 * j] : 0.f;
+            }
+        }
+    }
+    return 0;
+}
+int snk_set_box(snk_handle* h, const float* state, const float* manifold) {
+    if (!h) return fail("snk_set_box: null handle");
+    if (!h->d_box) return fail("snk_set_box: this handle has no free box (obstacle != 2)");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipDeviceSynchronize());
+    std::vector<float> b((size_t)h->n_envs * snk::kBoxFloats);
+    HIP_TRY(hipMemcpy(b.data(), h->d_box, b.size() * sizeof(float), hipMemcpyDeviceToHost));
+    for (size_t e = 0; e < (size_t)h->n_envs; e++) {
+        float* x = &b[e * snk::kBoxFloats];
+        if (state) memcpy(x, state + 13 * e, 13 * sizeof(float));
+        if (manifold) {
+            const float* o = manifold + 29 * e;
+            x[13] = o[0];
+            for (int j = 0; j < 4; j++) {
+                for (int r = 0; r < 3; r++) x[14 + 6 * j + r] = o[1 + 7 * j + r];
+                x[17 + 6 * j] = o[4 + 7 * j];
+                x[18 + 6 * j] = o[5 + 7 * j];
+                x[19 + 6 * j] = o[7 + 7 * j];
+            }
+        }
+    }
+    HIP_TRY(hipMemcpy(h->d_box, b.data(), b.size() * sizeof(float), hipMemcpyHostToDevice));
     return 0;
 }
 

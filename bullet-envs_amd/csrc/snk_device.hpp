@@ -252,12 +252,21 @@ struct Lds<N, false> : LdsCommon<N, 2 * N> {
     // behind the geometry: M^-1 e_j of the n motor / limit rows, kMO floats each (columns >= ND zero).  The solve keeps
     // them in registers; they left LDS (4.9 KB for 32 links) so that eight waves fit a CU
     static constexpr size_t kMmOff = kGeoOff + (size_t)NCT * kGeo;     // M^-1: ND rows (6 base, then the joints) of kMO floats
-    static constexpr size_t kYOff = kMmOff + (size_t)(N + 6) * kMO;     // Y_k of every body (build_rows_v1), 6 x kMO floats each
-    static constexpr size_t kRowFloats = kYOff + (size_t)(N + 1) * 6 * kMO;
+    // (+ 6 rows and one more Y for the free box of obstacle 2, a second "tree" with six velocity components of its own
+    //  behind the snake's: lanes ND .. ND + 5 of the solve, body index N + 1 in the contact records)
+    static constexpr int kBoxBody = N + 1;
+    static constexpr size_t kYOff = kMmOff + (size_t)(N + 6 + 6) * kMO;     // Y_k of every body (build_rows_v1), 6 x kMO floats each
+    static constexpr size_t kRowFloats = kYOff + (size_t)(N + 2) * 6 * kMO;
+    static_assert(N + 6 + 6 <= kSpec || N > 16, "the free box's lanes must fit in front of the scalar columns (16 links)");
     // accumulated impulses of contact ci: {normal, friction A, friction B, -}
     alignas(16) float acc[NC + kRing + 3][4];        // (+ the entries the solve reads ahead of the last pair)
     static_assert(NCT <= NC + kRing, "the impulses of the link-link contacts live in the ring's padding entries");
     int nplane;                  // ground contacts of this substep (the link-link contacts follow them)
+    // obstacle 2: the free box while this wave holds the environment -- state [pos3, quat4, omega3, vel3], its world
+    // rotation and world inverse inertia (sym6) for this substep, its manifold with the plane (4 x (a3, b.x, b.y,
+    // lambda)) and the point count; travels with the state record (d_box)
+    float box[13], bR[9], bIw[6], bman[24];
+    int bmn;
 };
 
 // v2: rows live in VGPRs during the solve; LDS only stages one 64-row batch while they are built
@@ -482,6 +491,12 @@ __device__ __forceinline__ void cyl_world_rot(const float* Rb, const float* Rc, 
 template <class LT>
 __device__ int find_contacts_manifold_v1(LT& L, const DevModel& M, int lane, float* __restrict__ rows, float* __restrict__ mf,
                                          unsigned long long* __restrict__ ovf);
+// obstacle 2, the free box (snk_freebox.hpp)
+template <class LT>
+__device__ __forceinline__ void box_frame_v1(LT& L, const DevModel& M, int lane);
+template <class LT>
+__device__ __forceinline__ int find_box_ground_v1(LT& L, const DevModel& M, int lane, float mu_ground, int first,
+                                                  float* __restrict__ rows, unsigned long long* __restrict__ ovf);
 
 template <class LT>
 __device__ int find_contacts_v1(LT& L, const DevModel& M, int lane, float* __restrict__ rows, float* __restrict__ mf,
@@ -787,6 +802,18 @@ __device__ void build_rows_v1(LT& L, const DevModel& M, int lane, int nc, int& n
             if (b == k) mden = qdd;
         }
     }
+    // the free box (obstacle 2): a second multibody, block-diagonal in M^-1 -- rows ND .. ND + 5: the world inverse
+    // inertia for its angular components, 1 / m for its linear ones
+    const bool fbox = M.obstacle == 2;
+    const bool boxlane = fbox && lane >= ND && lane < ND + 6;
+    if (boxlane) {
+        const int i = lane - ND;
+        float* Mrow = Mmx + (size_t)lane * kMO;
+        const float* W = L.bIw;
+        const f3 r0 = i == 0 ? mk3(W[0], W[1], W[2]) : (i == 1 ? mk3(W[1], W[3], W[4]) : mk3(W[2], W[4], W[5]));
+        Mrow[ND + 0] = i < 3 ? r0.x : 0.f; Mrow[ND + 1] = i < 3 ? r0.y : 0.f; Mrow[ND + 2] = i < 3 ? r0.z : 0.f;
+        Mrow[ND + 3] = i == 3 ? M.obs_minv : 0.f; Mrow[ND + 4] = i == 4 ? M.obs_minv : 0.f; Mrow[ND + 5] = i == 5 ? M.obs_minv : 0.f;
+    }
     __threadfence();          // M^-1 was written lane = row, it is read lane = column
     lds_sync();
     // ---- (b) lane = velocity component d: what J[d] is made of, and the current velocity
@@ -797,6 +824,14 @@ __device__ void build_rows_v1(LT& L, const DevModel& M, int lane, int nc, int& n
     if (d < 3) { Aj = mk3(d == 0 ? 1.f : 0.f, d == 1 ? 1.f : 0.f, d == 2 ? 1.f : 0.f); Oj = ld3(L.o[0]); vd = L.base()[7 + d]; }
     else if (d < 6) { Bj = mk3(d == 3 ? 1.f : 0.f, d == 4 ? 1.f : 0.f, d == 5 ? 1.f : 0.f); vd = L.base()[7 + d]; }
     else if (d < ND) { Aj = ld3(L.ax[jb]); Oj = ld3(L.o[jb]); vd = L.qd()[d - 6]; }
+    else if (boxlane) {
+        const int i = d - ND;
+        if (i < 3) { Aj = mk3(i == 0 ? 1.f : 0.f, i == 1 ? 1.f : 0.f, i == 2 ? 1.f : 0.f); Oj = ld3(L.box); }
+        else Bj = mk3(i == 3 ? 1.f : 0.f, i == 4 ? 1.f : 0.f, i == 5 ? 1.f : 0.f);
+        vd = L.box[7 + i];
+    }
+    // does this lane's component move a point of body k?  (the snake's: the joints up to k; the box's six: the box)
+    auto moves = [&](int k) { return boxlane ? k == LT::kBoxBody : (k <= N && jb <= k); };
     const bool colv = d < kMO;                      // lanes that own a column of the records
     auto mm = [&](int row) { return colv ? Mmx[(size_t)row * kMO + d] : 0.f; };
     f3 Yt = mk3(mm(0), mm(1), mm(2)), Yf = mk3(mm(3), mm(4), mm(5));    // Y_0
@@ -846,14 +881,16 @@ __device__ void build_rows_v1(LT& L, const DevModel& M, int lane, int nc, int& n
         // J[d] = A_d . ((P - O_d) x dir) + B_d . dir = dir . (A_d x (P - O_d) + B_d), and likewise
         // M^-1 J^T [d] = Yt . ((P - o_k) x dir) + Yf . dir = dir . (Yt x (P - o_k) + Yf): one vector per contact and
         // lane for each, a dot product per row
+        // (a body's reference point: its joint origin; the free box's: its centre)
+        auto org = [&](int k) { return (TWO && k == LT::kBoxBody) ? ld3(L.box) : ld3(L.o[k <= N ? k : 0]); };
         f3 Cj = cross(Aj, P - Oj) + Bj;
-        if (!(jb <= kA)) Cj = mk3(0, 0, 0);
-        f3 Dj = cross(YtA, P - ld3(L.o[kA])) + YfA;
+        if (!moves(kA)) Cj = mk3(0, 0, 0);
+        f3 Dj = cross(YtA, P - org(kA)) + YfA;
         if (TWO && kB >= 0) {                                           // wave-uniform: minus the same for the other body
             f3 Cb = cross(Aj, PB - Oj) + Bj;
-            if (!(jb <= kB)) Cb = mk3(0, 0, 0);
+            if (!moves(kB)) Cb = mk3(0, 0, 0);
             Cj = Cj - Cb;
-            Dj = Dj - (cross(YtB, PB - ld3(L.o[kB])) + YfB);
+            Dj = Dj - (cross(YtB, PB - org(kB)) + YfB);
         }
         float Jr[3], Mr[3], red[7];
 #pragma unroll
@@ -927,6 +964,17 @@ __device__ void build_rows_v1(LT& L, const DevModel& M, int lane, int nc, int& n
     // ---- (d) link-link and obstacle contacts: any two bodies, their Y from the block the recursion left behind
     if (two_body) {
         while (kcur < N) advance();
+        if (fbox && colv) {
+            // Y of the box: a unit wrench (tau, f) about its centre moves its own six components only --
+            // angular component i: row i of the world inverse inertia . tau, linear component i: f_i / m
+            float* y = Yb + (size_t)LT::kBoxBody * 6 * kMO + d;
+            const int i = d - ND;
+            const float* W = L.bIw;
+            f3 yt = mk3(0, 0, 0), yf = mk3(0, 0, 0);
+            if (boxlane && i < 3) yt = i == 0 ? mk3(W[0], W[1], W[2]) : (i == 1 ? mk3(W[1], W[3], W[4]) : mk3(W[2], W[4], W[5]));
+            if (boxlane && i >= 3) yf = mk3(i == 3 ? M.obs_minv : 0.f, i == 4 ? M.obs_minv : 0.f, i == 5 ? M.obs_minv : 0.f);
+            y[0] = yt.x; y[kMO] = yt.y; y[2 * kMO] = yt.z; y[3 * kMO] = yf.x; y[4 * kMO] = yf.y; y[5 * kMO] = yf.z;
+        }
         __threadfence();
         lds_sync();
         for (int ci = nplane; ci < nc; ci++) {
@@ -1135,7 +1183,7 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
     constexpr int ND = N + 6;
     static_assert(ND <= 64, "this solve is laid out for one row per 64-lane register");
     constexpr int kSpec = LT::kSpec;
-    const bool act = lane < ND;
+    const bool act = lane < ND + (M.obstacle == 2 ? 6 : 0);      // (the free box's six components sit behind the snake's)
     const int nlim = nn - N;                       // violated joint limits come first in the non-contact list
     // model fields used inside the loops, read once (the model lives in global memory)
     // (v_readfirstlane: the loads go through vector memory, the values must be scalar for the
@@ -1219,7 +1267,7 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
             if (__builtin_amdgcn_readfirstlane(a != 0.f ? 1 : 0)) {
                 float jj, mm;
                 ldN((unsigned)ci * kRecB, jj, mm);
-                dv += (lane < ND) ? a * mm : 0.f;
+                dv += act ? a * mm : 0.f;
             }
         }
     }
@@ -1405,6 +1453,8 @@ __device__ void substep_v1(LT& L, const DevModel& M, int lane, float mu, int& it
     unsigned long long prof_t[10];
 #endif
     SNK_STAMP(0)
+    const bool fbox = M.obstacle == 2;         // the obstacle as a free body: six more velocity components (lanes ND ..)
+    if (fbox) box_frame_v1(L, M, lane);
     // (1) contacts of the current pose, (2) bias forces with gravity, joint damping torque
     int nc = find_contacts_v1(L, M, lane, rows, mf, ovf);
     SNK_STAMP(1)
@@ -1412,6 +1462,7 @@ __device__ void substep_v1(LT& L, const DevModel& M, int lane, float mu, int& it
     const int nplane = nc;
     if (M.self_collision || M.obstacle)
         nc += find_self_contacts_v1(L, M, lane, mu, rows, ovf);   // link-link and obstacle contacts follow the ground's
+    if (fbox) nc += find_box_ground_v1(L, M, lane, mu, nc - nplane, rows, ovf);     // ... and the box's own with the ground
     ncontacts = nc;
     __threadfence();      // contact geometry: written lane = slot, read lane = row
     lds_sync();
@@ -1446,6 +1497,22 @@ __device__ void substep_v1(LT& L, const DevModel& M, int lane, float mu, int& it
     } else if (lane < ND) {
         float x = L.qd()[lane - 6] + L.qdd[lane - 6] * dt;
         L.qd()[lane - 6] = fminf(fmaxf(x, -M.max_vel), M.max_vel);
+    } else if (fbox && lane < ND + 6) {
+        // the free box, a btMultiBody without links [U]: gravity, the base's damping m v (k + k|v|), I w (k + k|w|),
+        // the gyroscopic term; lanes ND .. ND + 2 its angular, ND + 3 .. ND + 5 its linear components
+        const f3 om = ld3(L.box + 7), vl = ld3(L.box + 10);
+        const float nw = sqrtf(dot(om, om)), nv = sqrtf(dot(vl, vl));
+        // world inertia times omega: R diag(1 / iinv) R^T omega
+        const f3 wl = mulRtv(L.bR, om);
+        const f3 Iw = mulRv(L.bR, mk3(M.obs_iinv[0] > 0.f ? wl.x / M.obs_iinv[0] : 0.f, M.obs_iinv[1] > 0.f ? wl.y / M.obs_iinv[1] : 0.f,
+                                      M.obs_iinv[2] > 0.f ? wl.z / M.obs_iinv[2] : 0.f));
+        const f3 tq = -cross(om, Iw) - Iw * (M.ang_damp + M.ang_damp * nw);
+        const f3 al = mulSv(L.bIw, tq);
+        const f3 a = mk3(0.f, 0.f, M.gz) - vl * (M.lin_damp + M.lin_damp * nv);
+        const int i = lane - ND;
+        const float acc = i == 0 ? al.x : (i == 1 ? al.y : (i == 2 ? al.z : (i == 3 ? a.x : (i == 4 ? a.y : a.z))));
+        const float x = L.box[7 + i] + acc * dt;
+        L.box[7 + i] = fminf(fmaxf(x, -M.max_vel), M.max_vel);
     }
     lds_sync();
     // (4) rows, (5) PGS
@@ -1553,6 +1620,15 @@ __device__ void substep_v1(LT& L, const DevModel& M, int lane, float mu, int& it
         }
     }
     SNK_STAMP(7)
+    if (fbox && lane == 0) {
+        // the box's contacts with the ground are the last L.bmn-or-fewer of the list: their normal impulses go back
+        // into its manifold (btManifoldPoint::m_appliedImpulse [U])
+        int nb = 0;
+        for (int ci = nplane; ci < nc; ci++) {
+            const float* geo = rows + LT::kGeoOff + (size_t)(LT::NC + ci - nplane) * LT::kGeo;
+            if ((int)geo[16] == LT::kBoxBody) { if (nb < 4) L.bman[6 * nb + 5] = L.acc[ci][0]; nb++; }
+        }
+    }
     // (7) apply the solver's delta-v (clamped), motor torques, integrate positions
     if (lane < 6) {
         float x = L.base()[7 + lane] + dv;
@@ -1562,6 +1638,9 @@ __device__ void substep_v1(LT& L, const DevModel& M, int lane, float mu, int& it
         x = fminf(fmaxf(x, -M.max_vel), M.max_vel);
         L.qd()[lane - 6] = x;
         L.q()[lane - 6] += dt * x;
+    } else if (fbox && lane < ND + 6) {
+        const float x = L.box[7 + lane - ND] + dv;
+        L.box[7 + lane - ND] = fminf(fmaxf(x, -M.max_vel), M.max_vel);
     }
     if (lane < N) {
         // motor rows sit after the limit rows in the non-contact list
@@ -1593,6 +1672,28 @@ __device__ void substep_v1(LT& L, const DevModel& M, int lane, float mu, int& it
         }
     }
     lds_sync();
+    if (fbox) {
+        // the box's pose: btMultiBody::stepPositionsMultiDof, the same exponential-map update as the snake's base [U]
+        float* bx = L.box;
+        const f3 om = ld3(bx + 7), vl = ld3(bx + 10);
+        float fA = sqrtf(dot(om, om));
+        const float kThr = 0.78539816339744831f;
+        if (fA * dt > kThr) fA = kThr / dt;
+        const float sc = fA < 0.001f ? 0.5f * dt - (dt * dt * dt) * 0.020833333333f * fA * fA : sinf(0.5f * fA * dt) / fA;
+        const float dx = om.x * sc, dy = om.y * sc, dz = om.z * sc, dw = cosf(fA * dt * 0.5f);
+        const float qx = bx[3], qy = bx[4], qz = bx[5], qw = bx[6];
+        const float nw = dw * qw - dx * qx - dy * qy - dz * qz;
+        const float nx = dw * qx + dx * qw + dy * qz - dz * qy;
+        const float ny = dw * qy - dx * qz + dy * qw + dz * qx;
+        const float nz = dw * qz + dx * qy - dy * qx + dz * qw;
+        const float inv = 1.0f / sqrtf(nx * nx + ny * ny + nz * nz + nw * nw);
+        lds_sync();
+        if (lane == 0) {
+            bx[0] += dt * vl.x; bx[1] += dt * vl.y; bx[2] += dt * vl.z;
+            bx[3] = nx * inv; bx[4] = ny * inv; bx[5] = nz * inv; bx[6] = nw * inv;
+        }
+        lds_sync();
+    }
     SNK_STAMP(8)
     // pose of the new state: feeds checkSnakeHeight and the next substep
     fk_vel(L, M, lane);
@@ -1606,6 +1707,7 @@ __device__ void substep_v1(LT& L, const DevModel& M, int lane, float mu, int& it
 
 }  // namespace snk
 #include "snk_pgs_v2.hpp"
+#include "snk_freebox.hpp"
 namespace snk {
 
 template <class LT>
@@ -1705,6 +1807,35 @@ __device__ __forceinline__ void store_mf(LT& L, float* __restrict__ mf, int lane
         }
     }
 }
+// obstacle 2: the free box of the environment (state 13, point count, manifold 24: kBoxFloats per env in d_box) travels
+// with the state record, like the contact cache
+constexpr int kBoxFloats = 40;
+template <class LT>
+__device__ __forceinline__ void load_box(LT& L, const float* __restrict__ bx, int lane) {
+    if constexpr (!LT::kV2) {
+        if (bx) {
+            lane = launder_lane(lane);
+            if (lane < 13) L.box[lane] = bx[lane];
+            else if (lane == 13) L.bmn = (int)bx[13];
+            else if (lane < 38) L.bman[lane - 14] = bx[lane];
+            lds_sync();
+        }
+    }
+}
+template <class LT, bool THROUGH>
+__device__ __forceinline__ void store_box(LT& L, float* __restrict__ bx, int lane) {
+    if constexpr (!LT::kV2) {
+        if (bx) {
+            lane = launder_lane(lane);
+            lds_sync();
+            if (lane < 38) {
+                const float v = lane < 13 ? L.box[lane] : (lane == 13 ? (float)L.bmn : L.bman[lane - 14]);
+                if (THROUGH) asm volatile("global_store_dword %0, %1, off sc1" : : "v"(bx + lane), "v"(v) : "memory");
+                else bx[lane] = v;
+            }
+        }
+    }
+}
 template <class LT>
 __device__ __forceinline__ void write_obs(LT& L, float* __restrict__ obs, int lane) {
     constexpr int N = LT::kN;
@@ -1736,7 +1867,8 @@ __global__ __launch_bounds__(64, 2) void env_step_kernel(const DevModel* __restr
                                                       float* __restrict__ rew, uint8_t* __restrict__ done,
                                                       int32_t* __restrict__ substeps, int vec_mode, int n_envs,
                                                       const int32_t* __restrict__ order, float* __restrict__ rows_all,
-                                                      float* __restrict__ mf_all, unsigned long long* __restrict__ ovf) {
+                                                      float* __restrict__ mf_all, unsigned long long* __restrict__ ovf,
+                                                      float* __restrict__ box_all) {
     extern __shared__ float4 smem_raw[];
     using LT = Lds<N, V2>;
     LT& L = *reinterpret_cast<LT*>(smem_raw);
@@ -1770,6 +1902,8 @@ __global__ __launch_bounds__(64, 2) void env_step_kernel(const DevModel* __restr
     if constexpr (!LT::kV2) env_rows = rows_all + (size_t)blockIdx.x * LT::kRowFloats;
     float* env_mf = mf_all ? mf_all + (size_t)env * (2 * N * kMfFloats) : nullptr;   // contact cache (contact_model 1)
     load_mf(L, env_mf, lane);
+    float* env_box = box_all ? box_all + (size_t)env * kBoxFloats : nullptr;
+    load_box(L, env_box, lane);
     fk_vel(L, M, lane);
     // Snake.step servo loop (snake.py:283-304)
     int counter = 0;
@@ -1817,6 +1951,7 @@ __global__ __launch_bounds__(64, 2) void env_step_kernel(const DevModel* __restr
     }
     store_rec(L, recs + (size_t)env * LT::REC, lane);
     store_mf<LT, false>(L, env_mf, lane);
+    store_box<LT, false>(L, env_box, lane);
     lds_sync();
     }
 }
@@ -1826,7 +1961,8 @@ __global__ __launch_bounds__(64, 2) void substep_kernel(const DevModel* __restri
                                                      const float* __restrict__ mu_plane,
                                                      const float* __restrict__ targets, int k,
                                                      int32_t* __restrict__ info, int n_envs, float* __restrict__ rows_all,
-                                                     float* __restrict__ mf_all, unsigned long long* __restrict__ ovf) {
+                                                     float* __restrict__ mf_all, unsigned long long* __restrict__ ovf,
+                                                     float* __restrict__ box_all) {
     extern __shared__ float4 smem_raw[];
     using LT = Lds<N, V2>;
     LT& L = *reinterpret_cast<LT*>(smem_raw);
@@ -1846,10 +1982,13 @@ __global__ __launch_bounds__(64, 2) void substep_kernel(const DevModel* __restri
     if constexpr (!LT::kV2) env_rows = rows_all + (size_t)blockIdx.x * LT::kRowFloats;
     float* env_mf = mf_all ? mf_all + (size_t)env * (2 * N * kMfFloats) : nullptr;
     load_mf(L, env_mf, lane);
+    float* env_box = box_all ? box_all + (size_t)env * kBoxFloats : nullptr;
+    load_box(L, env_box, lane);
     for (int s = 0; s < k; s++) substep(L, M, lane, mu, iters, nc, hint, env_rows, env_mf, ovf);
     if (info && lane == 0) { info[2 * env] = iters; info[2 * env + 1] = nc; }
     store_rec(L, recs + (size_t)env * LT::REC, lane);
     store_mf<LT, false>(L, env_mf, lane);
+    store_box<LT, false>(L, env_box, lane);
     lds_sync();
     }
 }
@@ -2182,6 +2321,7 @@ struct StepArgs {
     float* rows_all;
     float* mf_all;
     unsigned long long* ovf;
+    float* box_all;
     Sched sc;
     int32_t model_slot, vec_mode, n_envs, pad_;
 };
@@ -2269,6 +2409,11 @@ __global__ __launch_bounds__(64, 2) void env_step_sched_kernel(StepArgs args_by_
             return mf_all ? mf_all + (size_t)env * (2 * N * kMfFloats) : nullptr;
         };
         load_mf(L, env_mf(ap), lane);
+        auto env_box = [&](StepArgPtr q) -> float* {           // the free box of obstacle 2 (null otherwise)
+            float* box_all = q->box_all;
+            return box_all ? box_all + (size_t)env * kBoxFloats : nullptr;
+        };
+        load_box(L, env_box(ap), lane);
         fk_vel(L, M, lane);
         // Snake.step servo loop (snake.py:283-304), `quantum` substeps at a time
         bool end_height = false, complete = false;
@@ -2292,6 +2437,7 @@ __global__ __launch_bounds__(64, 2) void env_step_sched_kernel(StepArgs args_by_
                 if (top >= remaining + sc.hyst) {
                     store_rec_through(L, aq->recs + (size_t)env * LT::REC, lane);
                     store_mf<LT, true>(L, env_mf(aq), lane);        // the contact cache travels with the record
+                    store_box<LT, true>(L, env_box(aq), lane);
                     __hip_atomic_store(&sc.counter[env], counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     sched_push(sc, lane, env, remaining);
                     break;
@@ -2346,6 +2492,7 @@ __global__ __launch_bounds__(64, 2) void env_step_sched_kernel(StepArgs args_by_
         }
         store_rec(L, af->recs + (size_t)env * LT::REC, lane);
         store_mf<LT, false>(L, env_mf(af), lane);
+        store_box<LT, false>(L, env_box(af), lane);
         atomicAdd(af->sc.finished, lane == 0 ? 1 : 0);
     }
 }

@@ -61,6 +61,8 @@ struct DevModel {
     float warm_factor;
     int obstacle;                        // a static box on the ground (snake/block.urdf), contacts through the streamed-row solve
     float obs_c[3], obs_h[3], mu_obs;    // its centre, half extents, lateral friction
+    // obstacle 2 (a free body): mass, inverse inertia diagonal in box axes, breaking threshold of its manifold with the plane
+    float obs_minv, obs_iinv[3], obs_thr;
     float cyl_zoff;
     float hull_xy[32][2];
     // sensors
@@ -239,6 +241,18 @@ inline void build_dev_model(const snk_params& P, const HostModel& H, DevModel& D
     D.obstacle = P.obstacle;
     for (int i = 0; i < 3; i++) { D.obs_c[i] = (float)P.obstacle_pos[i]; D.obs_h[i] = (float)P.obstacle_half[i]; }
     D.mu_obs = (float)P.mu_obstacle;
+    {
+        // [U] no URDF_USE_INERTIA_FROM_FILE: btBoxShape::calculateLocalInertia on the nominal box (block.urdf:7 otherwise)
+        const double lx = 2 * P.obstacle_half[0], ly = 2 * P.obstacle_half[1], lz = 2 * P.obstacle_half[2], m = P.obstacle_mass;
+        double I[3] = {m / 12 * (ly * ly + lz * lz), m / 12 * (lx * lx + lz * lz), m / 12 * (lx * lx + ly * ly)};
+        if (P.inertia_from_file) { I[0] = 1.0; I[1] = 100.0; I[2] = 1.0; }
+        D.obs_minv = (float)(m > 0 ? 1.0 / m : 0.0);
+        for (int i = 0; i < 3; i++) D.obs_iinv[i] = (float)(I[i] > 0 ? 1.0 / I[i] : 0.0);
+        const double hn = std::sqrt(P.obstacle_half[0] * P.obstacle_half[0] + P.obstacle_half[1] * P.obstacle_half[1] +
+                                    P.obstacle_half[2] * P.obstacle_half[2]);
+        // its manifold with the plane: the box's own angular-motion disc (|half extents|), smaller than the plane's [U]
+        D.obs_thr = (float)(P.relative_breaking_threshold ? P.breaking_threshold * hn : P.breaking_threshold);
+    }
     D.cyl_zoff = 0.0183f;                                               // snake.urdf:807,863
     for (int s = 0; s < P.hull_sides && s < 32; s++) {
         const double th = 2.0 * 3.14159265358979323846 * s / P.hull_sides;

@@ -267,11 +267,17 @@ __device__ int find_self_contacts_v1(LT& L, const DevModel& M, int lane, float m
 #pragma unroll
     for (int i = 0; i < 9; i++) ob_R[i] = 0.f;
     int n_ob = 0;
+    f3 ob_PB = mk3(0, 0, 0);           // the contact's point on the box (a free box, obstacle 2, needs it for its rows)
     if (M.obstacle) {
         Cvx Bx;
         Bx.c = mk3(M.obs_c[0], M.obs_c[1], M.obs_c[2]);
 #pragma unroll
         for (int i = 0; i < 9; i++) Bx.R[i] = (i % 4 == 0) ? 1.f : 0.f;
+        if (M.obstacle == 2) {         // the free box: where it is now (LDS: Lds<N, false>::box, bR)
+            Bx.c = ld3(L.box);
+#pragma unroll
+            for (int i = 0; i < 9; i++) Bx.R[i] = L.bR[i];
+        }
         Bx.box = 1;
         Bx.half = mk3(M.obs_h[0], M.obs_h[1], M.obs_h[2]);
         const float rbox = sqrtf(dot(Bx.half, Bx.half));
@@ -295,11 +301,13 @@ __device__ int find_self_contacts_v1(LT& L, const DevModel& M, int lane, float m
                     const float nn = sqrtf(dot(d, d));
                     ob_n = nn > 0.f ? d * (1.0f / nn) : mk3(-1.f, 0.f, 0.f);
                     ob_P = A.c;
+                    ob_PB = ob_P;
                     ob_dist = -2.0f * mg;
                 } else {
                     ob_n = (pa - pb) * (1.0f / dd);
                     ob_dist = dd - 2.0f * mg;
                     ob_P = pa - ob_n * mg;
+                    ob_PB = pb + ob_n * mg;
                 }
                 ob_hit = ob_dist < M.break_thr;
             }
@@ -393,9 +401,9 @@ __device__ int find_self_contacts_v1(LT& L, const DevModel& M, int lane, float m
             st3(geo + 4, dA);
             st3(geo + 7, dB);
             st3(geo + 10, ob_n);
-            st3(geo + 13, mk3(0.f, 0.f, 0.f));
+            st3(geo + 13, ob_PB);
             geo[16] = (float)((a + 1) >> 1);
-            geo[17] = -1.0f;
+            geo[17] = M.obstacle == 2 ? (float)LT::kBoxBody : -1.0f;      // a free box is the contact's second body
             geo[18] = rho_ob;
             geo[19] = 0.f;
         }
@@ -405,3 +413,4 @@ __device__ int find_self_contacts_v1(LT& L, const DevModel& M, int lane, float m
 }
 
 }  // namespace snk
+

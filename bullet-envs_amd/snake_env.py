@@ -118,12 +118,15 @@ class Snake(object):
         self._need_env()._reset_robot(hardReset)
         return True
 
-    def add_obstacle(self, urdf_file, position):
+    def add_obstacle(self, urdf_file, position, static=False):
         """snake.py:83-84: loads snake/block.urdf at `position` ([2, 0, 0.1] at snake.py:94 and
-        snake_gait_test.py:51).  The box is the one of block.urdf (0.2 x 0.8 x 0.2 m) whatever `urdf_file` says, and it
-        is static here.  Takes effect with a hard reset of the world, like loadURDF."""
+        snake_gait_test.py:51) -- with loadURDF's default useFixedBase=0, i.e. as a FREE 200-kg body (snk_params
+        obstacle = 2; 16-link snakes: DESIGN.md 8).  static=True (or a 32-link snake) gives the immovable box of
+        obstacle = 1, which keeps a 16-link env on the faster register-resident kernels.  The box is the one of
+        block.urdf (0.2 x 0.8 x 0.2 m) whatever `urdf_file` says.  Takes effect with a hard reset of the world, like
+        loadURDF."""
         env = self._need_env()
-        env.params.obstacle = 1
+        env.params.obstacle = 1 if (static or env.params.n_modules != 16) else 2
         for i in range(3):
             env.params.obstacle_pos[i] = float(position[i])
         env._reset_robot(True)
@@ -183,7 +186,8 @@ class SnakeGymEnv(object):
         if a32.shape[1] != self._stepper.act_dim:
             raise SystemError("Action not executed!")
         if self.mode == 'test':
-            before = self._stepper.get_state() + (self._stepper.get_manifold(),)
+            before = self._stepper.get_state() + (self._stepper.get_manifold(),
+                                                  self._stepper.get_box() if self.params.obstacle == 2 else None)
         obs, rew, done, sub = self._stepper.step(a32, vec_mode=False)
         if self.mode == 'test':
             self._record_telemetry(before, a32[0], int(sub[0]), obs[0])
@@ -217,6 +221,8 @@ class SnakeGymEnv(object):
         sc.set_state(before[0], before[1])
         if before[2] is not None:             # contact_model 1: the contact cache is part of the state the step started in
             sc.set_manifold(before[2])
+        if before[3] is not None:             # ... and so is a free obstacle box
+            sc.set_box(*before[3])
         n = self.params.n_modules
         # createAction + convertActionToJointCommand with the gait and scale the DEVICE uses (self.params: they
         # may have been overridden through **over, which the robot facade does not see)

@@ -40,13 +40,18 @@ typedef struct snk_params {
                                    URDF_USE_SELF_COLLISION (snake.py:93) switches on [U].  Evaluated for
                                    n_modules 32; for the 16-link snake they can never act inside the joint
                                    limits and no rows are built                               */
-    int32_t obstacle;           /* 1: a box stands on the ground in front of the snake -- snake/block.urdf loaded by
-                                   Snake.add_obstacle (snake.py:83-84, commented out at :94) and by
-                                   snake_gait_test.py:51.  STATIC (the reference's is a free 200-kg body).
-                                   16 links: up to 8 contacts with it, taken out of the solve's 64 slots. Default 0 */
+    int32_t obstacle;           /* the box of snake/block.urdf that Snake.add_obstacle (snake.py:83-84, commented out
+                                   at :94) and snake_gait_test.py:51 put in front of the snake.  0 (default): none.
+                                   1: STATIC (16 links: up to 8 contacts with it, out of the solve's 64 slots).
+                                   2: as the reference loads it (useFixedBase=0): a FREE body of obstacle_mass resting
+                                   on the ground -- its own six velocity components, gravity, damping, a persistent
+                                   manifold with the plane, two-body rows with the snake's links; 16 links only, on
+                                   the streamed-row kernels                                       */
     double  obstacle_pos[3];    /* centre of the box: [2, 0, 0.1] (snake.py:94, snake_gait_test.py:51)         */
     double  obstacle_half[3];   /* half extents: [0.1, 0.4, 0.1] (snake/block.urdf:16)                         */
     double  mu_obstacle;        /* 0.5 [U]: Bullet's default lateral friction for a link without <contact>     */
+    double  obstacle_mass;      /* 200 (snake/block.urdf:6); inertia from the box shape [U] (inertia_from_file 1:
+                                   block.urdf:7's 1, 100, 1)                                                   */
     /* pybullet world */
     double  dt;                 /* 1/240 [U]: setTimeSteps is never called (snake.py:271-272) */
     double  gravity_z;          /* snake.py:8,91   -9.8                                       */
@@ -177,6 +182,13 @@ int snk_link_positions(snk_handle* h, float* out);
  * (getJointState(robot, 3)[2][2], "> 20: the snake has hit the wall").  Host buffer [n_envs].  Like the joint-0 force
  * of the observation it is evaluated on the last substep of an env-step (and by every snk_substep_host substep). */
 int snk_joint3_reaction_fz(snk_handle* h, float* out);
+
+/* obstacle 2 only: the free box of every env (part of the simulator state; a soft reset leaves it where it is, like
+ * resetBasePositionAndOrientation of the SNAKE, snake.py:126-127).  Host buffers: state [n_envs x 13] = pos3,
+ * quat xyzw 4, omega_world 3, vel_world 3; manifold [n_envs x 29] = its contact cache with the plane, [count, 4 x
+ * (point on the box in box coordinates 3, point on the ground 3, applied normal impulse)].  Either may be NULL. */
+int snk_get_box(snk_handle* h, float* state, float* manifold);
+int snk_set_box(snk_handle* h, const float* state, const float* manifold);
 
 /* Contacts the solves had no room for, counted on the device since snk_create (Bullet has no such limit; these
  * counters say when this build's structural limits were hit -- DESIGN.md 3):

@@ -20,6 +20,7 @@ class OrcParams(C.Structure):
         ("hull_sides", C.c_int32), ("contact_model", C.c_int32), ("max_contacts", C.c_int32),
         ("self_collision", C.c_int32), ("max_self_contacts", C.c_int32), ("obstacle", C.c_int32),
         ("obstacle_pos", C.c_double * 3), ("obstacle_half", C.c_double * 3), ("mu_obstacle", C.c_double),
+        ("obstacle_mass", C.c_double),
         ("dt", C.c_double), ("gravity_z", C.c_double),
         ("lin_damping", C.c_double), ("ang_damping", C.c_double),
         ("joint_damping", C.c_double), ("max_coord_vel", C.c_double),
@@ -81,6 +82,8 @@ def _load(f32=False):
         "orc_substep": (None, [vp, D]),
         "orc_manifold_floats": (C.c_int32, [vp]),
         "orc_get_manifold": (None, [vp, D]), "orc_set_manifold": (None, [vp, D]),
+        "orc_get_box_state": (None, [vp, D]), "orc_set_box_state": (None, [vp, D]),
+        "orc_get_box_manifold": (None, [vp, D]), "orc_set_box_manifold": (None, [vp, D]),
         "orc_last_iterations": (C.c_int32, [vp]), "orc_last_num_contacts": (C.c_int32, [vp]),
         "orc_env_step": (None, [vp, D, C.c_int32, D, D, I, I]),
         "orc_link_com_world": (None, [vp, D]), "orc_joint_axes_world": (None, [vp, D, D]),
@@ -208,6 +211,22 @@ class OracleEnv:
         m = np.ascontiguousarray(m, dtype=np.float64)
         assert m.shape == (2 * self.n, 29)
         self.lib.orc_set_manifold(self.h, _dp(m))
+
+    def get_box(self):
+        """obstacle 2: (state [pos3, quat xyzw 4, omega 3, vel 3], manifold with the plane [29])."""
+        s, m = np.zeros(13), np.zeros(29)
+        self.lib.orc_get_box_state(self.h, _dp(s))
+        self.lib.orc_get_box_manifold(self.h, _dp(m))
+        return s, m
+
+    def set_box(self, state, manifold=None):
+        s = np.ascontiguousarray(state, dtype=np.float64)
+        assert s.shape == (13,)
+        self.lib.orc_set_box_state(self.h, _dp(s))
+        if manifold is not None:
+            m = np.ascontiguousarray(manifold, dtype=np.float64)
+            assert m.shape == (29,)
+            self.lib.orc_set_box_manifold(self.h, _dp(m))
 
     def reset(self):
         o = np.zeros(self.obs_dim)

@@ -190,7 +190,7 @@ struct Contact {
     int linkB;
     Real PB[3], n[3];
     Real mu;     /* combined friction coefficient of the pair */
-    int kind;    /* 0 ground, 1 link-link, 2 obstacle box */
+    int kind;    /* 0 ground, 1 link-link, 2 link against the obstacle box, 3 the free box against the ground (link -1) */
     int mpoint;  /* contact_model 1, ground contacts: index of its cached point in the link's manifold (else -1) */
 };
 
@@ -231,6 +231,11 @@ struct orc_env {
     std::vector<Contact> contacts;
     std::vector<Real> last_normal_impulse;
     std::vector<Manifold> manifolds;   /* contact_model 1: one per link (used by the links that carry a cylinder) */
+    /* obstacle 2: the free box (a btMultiBody without links [U]) */
+    Real bpos[3], bquat[4], bomega[3], bvel[3];
+    Real bR[9];               /* its world rotation (from bquat, refreshed by find_contacts / substep) */
+    Real bI[3];               /* inertia diagonal in box axes */
+    Manifold bman;            /* its persistent manifold with the plane */
 };
 
 namespace {
@@ -1047,13 +1052,16 @@ void find_self_contacts(orc_env* e) {
 /* Contacts with the obstacle box (snake/block.urdf placed by Snake.add_obstacle / snake_gait_test.py:51), kept STATIC
  * here: one point per (cylinder link, box) pair per step from the same two-tier GJK, the normal pointing from the box
  * to the link, friction mu_link x mu_obstacle [U], friction directions scaled by the link's anisotropy only. */
+/* world rotation of the box from its quaternion */
+void box_frame(orc_env* e) { quat_to_mat(e->bquat, e->bR); }
+
 void find_obstacle_contacts(orc_env* e) {
     const orc_params& P = e->P;
-    static const Real Rid[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
     const Real mg = (Real)P.collision_margin, thr = e->break_thr;
+    box_frame(e);
     Convex box;
-    box.e = e; box.link = -1; box.R = Rid; box.shrink = 0; box.box = 1;
-    for (int r = 0; r < 3; r++) { box.c[r] = (Real)P.obstacle_pos[r]; box.half[r] = (Real)P.obstacle_half[r]; }
+    box.e = e; box.link = -1; box.R = e->bR; box.shrink = 0; box.box = 1;
+    for (int r = 0; r < 3; r++) { box.c[r] = e->bpos[r]; box.half[r] = (Real)P.obstacle_half[r]; }
     const Real rb = std::sqrt(e->cyl_r * e->cyl_r + e->cyl_len * e->cyl_len / 4) + mg;
     const Real rbox = std::sqrt(dot3(box.half, box.half));
     Real mu = (Real)(P.mu_link * P.mu_obstacle);
@@ -1087,9 +1095,76 @@ void find_obstacle_contacts(orc_env* e) {
         } else {
             for (int r = 0; r < 3; r++) c.n[r] = (pa[r] - pb[r]) / dist;
             c.dist = dist - 2 * mgx;
-            for (int r = 0; r < 3; r++) c.P[r] = pa[r] - mgx * c.n[r];
+            for (int r = 0; r < 3; r++) { c.P[r] = pa[r] - mgx * c.n[r]; c.PB[r] = pb[r] + mgx * c.n[r]; }
         }
+        if (dist < 0)
+            for (int r = 0; r < 3; r++) c.PB[r] = c.P[r];
         if (c.dist < thr) e->contacts.push_back(c);
+    }
+}
+
+/* obstacle 2: the free box against the ground [U] -- btBoxShape is polyhedral, so the same convex-plane algorithm and
+ * persistent manifold as a link's hull: refresh, then one new support corner per step (localGetSupportingVertex: the
+ * nominal corner, the box keeps its margin inside), <= 4 cached points.  Threshold: the box's own angular-motion disc
+ * (|half extents|: 0.424 m -> 8.5 mm with the relative flag), smaller than the plane's. */
+void find_box_ground_contacts(orc_env* e) {
+    const orc_params& P = e->P;
+    const Real hx[3] = {(Real)P.obstacle_half[0], (Real)P.obstacle_half[1], (Real)P.obstacle_half[2]};
+    const Real thr = (Real)(P.relative_breaking_threshold ? P.breaking_threshold * std::sqrt(dot3(hx, hx)) : P.breaking_threshold);
+    box_frame(e);
+    const Real* R = e->bR;
+    Manifold& m = e->bman;
+    Real wa[4][3];
+    for (int j = 0; j < m.n; j++) {
+        mat3_vec(R, m.p[j].localA, wa[j]);
+        for (int r = 0; r < 3; r++) wa[j][r] += e->bpos[r];
+        m.p[j].dist = wa[j][2] - m.p[j].worldB[2];
+    }
+    for (int j = m.n - 1; j >= 0; j--) {
+        bool drop = !(m.p[j].dist <= thr);
+        if (!drop) {
+            Real dx = m.p[j].worldB[0] - wa[j][0], dy = m.p[j].worldB[1] - wa[j][1];
+            Real dz = m.p[j].worldB[2] - (wa[j][2] - m.p[j].dist);
+            drop = dx * dx + dy * dy + dz * dz > thr * thr;
+        }
+        if (drop) {
+            int last = m.n - 1;
+            if (j != last) { m.p[j] = m.p[last]; for (int r = 0; r < 3; r++) wa[j][r] = wa[last][r]; }
+            m.n--;
+        }
+    }
+    Real dl[3] = {-R[6], -R[7], -R[8]};      /* world -z in box coordinates */
+    ManifoldPoint np;
+    for (int r = 0; r < 3; r++) np.localA[r] = dl[r] >= 0 ? hx[r] : -hx[r];      /* btBoxShape: btFsels(v, h, -h) */
+    Real w[3];
+    mat3_vec(R, np.localA, w);
+    np.dist = e->bpos[2] + w[2];
+    np.lambda = 0;
+    if (np.dist < thr) {
+        np.worldB[0] = e->bpos[0] + w[0]; np.worldB[1] = e->bpos[1] + w[1]; np.worldB[2] = 0;
+        int nearest = -1;
+        Real shortest = thr * thr;
+        for (int j = 0; j < m.n; j++) {
+            Real d[3] = {m.p[j].localA[0] - np.localA[0], m.p[j].localA[1] - np.localA[1], m.p[j].localA[2] - np.localA[2]};
+            Real dd = dot3(d, d);
+            if (dd < shortest) { shortest = dd; nearest = j; }
+        }
+        int where;
+        if (nearest >= 0) { np.lambda = m.p[nearest].lambda; where = nearest; }
+        else if (m.n < 4) where = m.n++;
+        else where = manifold_sort_cached(m, np);
+        m.p[where] = np;
+        for (int r = 0; r < 3; r++) wa[where][r] = e->bpos[r] + w[r];
+    }
+    Real mu = (Real)(P.mu_obstacle * e->mu_plane);
+    if (mu > 10) mu = 10;
+    for (int j = 0; j < m.n; j++) {
+        Contact c;
+        c.link = -1; c.linkB = -1; c.mu = mu; c.kind = 3; c.mpoint = j;
+        c.n[0] = 0; c.n[1] = 0; c.n[2] = 1; c.PB[0] = c.PB[1] = c.PB[2] = 0;
+        for (int r = 0; r < 3; r++) c.P[r] = wa[j][r];
+        c.dist = m.p[j].dist;
+        e->contacts.push_back(c);
     }
 }
 
@@ -1161,6 +1236,7 @@ void find_contacts(orc_env* e) {
         e->contacts.erase(e->contacts.begin() + before + n_self + keep_ob, e->contacts.end());
         e->contacts.erase(e->contacts.begin() + before + keep_self, e->contacts.begin() + before + n_self);
     }
+    if (e->P.obstacle == 2) find_box_ground_contacts(e);      /* row order: ground, link-link, link-box, box-ground */
 }
 
 void apply_dv(orc_env* e, const Real* dvec, Real mult) {
@@ -1214,9 +1290,20 @@ inline Real resolve_row(Row& c, std::vector<Real>& dv, int nd) {
     return c.dinv != 0 ? dI / c.dinv : 0;
 }
 
+/* obstacle 2: world inverse inertia of the box times a vector */
+inline void box_iinv(const orc_env* e, const Real* t, Real* out) {
+    Real l[3];
+    mat3T_vec(e->bR, t, l);
+    for (int r = 0; r < 3; r++) l[r] /= e->bI[r];
+    mat3_vec(e->bR, l, out);
+}
+
 void substep(orc_env* e, const Real* targets) {
     const orc_params& P = e->P;
-    int n = e->n, nd = e->nd;
+    int n = e->n;
+    const int nds = e->nd;                               /* the snake's velocity components */
+    const bool fbox = P.obstacle == 2;                   /* the free box: six more, behind the snake's */
+    const int nd = nds + (fbox ? 6 : 0);
     Real dt = (Real)P.dt;
     if (!e->fk_valid) fk(e);
 
@@ -1225,7 +1312,7 @@ void substep(orc_env* e, const Real* targets) {
 
     /* (2) forward dynamics: gravity, joint damping torque -c*qd (PyBullet adds the URDF
      * joint damping as a joint torque before every step [U]), link damping, gyroscopic */
-    std::vector<Real> tau(n), qdd(n), acc(nd);
+    std::vector<Real> tau(n), qdd(n), acc(nds);
     for (int j = 0; j < n; j++) tau[j] = -(Real)P.joint_damping * e->qd[j];
     velocities(e, e->omega, e->vel, e->qd.data());
     aba_factor(e);
@@ -1239,11 +1326,34 @@ void substep(orc_env* e, const Real* targets) {
 
     /* (3) v += a dt  (applyDeltaVeeMultiDof, clamped) */
     apply_dv(e, acc.data(), dt);
+    if (fbox) {
+        /* the box: a btMultiBody without links [U] -- gravity, the same base damping m v (k + k|v|), I w (k + k|w|),
+         * the gyroscopic term; v += a dt, clamped */
+        box_frame(e);
+        const Real m = (Real)P.obstacle_mass, kl = (Real)P.lin_damping, ka = (Real)P.ang_damping;
+        Real nv = std::sqrt(dot3(e->bvel, e->bvel)), nw = std::sqrt(dot3(e->bomega, e->bomega));
+        Real wl[3], Iw[3], Iww[3], gy[3], tq[3], al[3];
+        mat3T_vec(e->bR, e->bomega, wl);
+        for (int r = 0; r < 3; r++) Iw[r] = e->bI[r] * wl[r];
+        mat3_vec(e->bR, Iw, Iww);                        /* I w in world axes */
+        cross3(e->bomega, Iww, gy);
+        for (int r = 0; r < 3; r++) tq[r] = -gy[r] - Iww[r] * (ka + ka * nw);
+        box_iinv(e, tq, al);
+        Real mx = (Real)P.max_coord_vel;
+        auto clampv = [&](Real& x) { if (x > mx) x = mx; if (x < -mx) x = -mx; };
+        for (int r = 0; r < 3; r++) {
+            Real a = (r == 2 ? (Real)P.gravity_z : 0) - e->bvel[r] * (kl + kl * nv);
+            e->bomega[r] += al[r] * dt; clampv(e->bomega[r]);
+            e->bvel[r] += a * dt; clampv(e->bvel[r]);
+        }
+    }
 
     /* (4) constraint rows */
     std::vector<Real> g(nd);
     for (int r = 0; r < 3; r++) { g[r] = e->omega[r]; g[3 + r] = e->vel[r]; }
     for (int j = 0; j < n; j++) g[6 + j] = e->qd[j];
+    if (fbox)
+        for (int r = 0; r < 3; r++) { g[nds + r] = e->bomega[r]; g[nds + 3 + r] = e->bvel[r]; }
 
     std::vector<Row> noncontact, normals, frictions;
     auto finish_row = [&](Row& row, Real vel_target_minus_relvel_plus_pos) {
@@ -1294,12 +1404,31 @@ void substep(orc_env* e, const Real* targets) {
     if (mu > 10) mu = 10;   /* MAX_FRICTION */
     std::vector<Real> Jtmp(nd);
     /* J of a contact row: link A's point along d, minus the other link's point along d (link-link contacts) */
+    /* ... and, with a free box, minus / plus the box's point along d: J_box = [(P - c) x d ; d] over its six
+     * components; M^-1 J^T there is [I_w^-1 ((P - c) x d) ; d / m] (block diagonal: two separate multibodies) */
+    auto box_part = [&](const Real* Pb, const Real* d, Real sign, Real* J, Real* Mv) {
+        Real rel[3], t[3], it[3];
+        for (int r = 0; r < 3; r++) rel[r] = Pb[r] - e->bpos[r];
+        cross3(rel, d, t);
+        box_iinv(e, t, it);
+        for (int r = 0; r < 3; r++) {
+            J[nds + r] = sign * t[r]; J[nds + 3 + r] = sign * d[r];
+            Mv[nds + r] = sign * it[r]; Mv[nds + 3 + r] = sign * d[r] / (Real)P.obstacle_mass;
+        }
+    };
     auto contact_jac = [&](const Contact& c, const Real* d, Real* J) {
+        for (int i = 0; i < nd; i++) J[i] = 0;
+        if (c.link < 0) return;                    /* the box against the ground: its part comes from box_part */
         jac_row(e, c.link, c.P, d, J);
         if (c.linkB >= 0) {
             jac_row(e, c.linkB, c.PB, d, Jtmp.data());
-            for (int i = 0; i < nd; i++) J[i] -= Jtmp[i];
+            for (int i = 0; i < nds; i++) J[i] -= Jtmp[i];
         }
+    };
+    auto contact_minv = [&](const Contact& c, const Real* d, Row& row) {
+        if (c.link >= 0) minv_apply(e, c.link, c.P, d, nullptr, row.M.data(), c.linkB, c.PB);
+        if (fbox && c.kind == 2) box_part(c.PB, d, Real(-1), row.J.data(), row.M.data());
+        if (fbox && c.kind == 3) box_part(c.P, d, Real(1), row.J.data(), row.M.data());
     };
     for (int ci = 0; ci < nc; ci++) {
         Contact& c = e->contacts[ci];
@@ -1310,7 +1439,7 @@ void substep(orc_env* e, const Real* targets) {
         row.J.assign(nd, 0); row.M.assign(nd, 0);
         memcpy(row.dir, nrm, sizeof(nrm));
         contact_jac(c, nrm, row.J.data());
-        minv_apply(e, c.link, c.P, nrm, nullptr, row.M.data(), c.linkB, c.PB);
+        contact_minv(c, nrm, row);
         Real rel_vel = 0;
         for (int i = 0; i < nd; i++) rel_vel += row.J[i] * g[i];
         Real pen = c.dist + (Real)P.linear_slop;
@@ -1322,7 +1451,8 @@ void substep(orc_env* e, const Real* targets) {
         /* warm starting (SOLVER_USE_WARMSTARTING as btSequentialImpulseConstraintSolver does it; disabled in Bullet's
          * multibody solver [U], hence a switch): the row starts at factor x the impulse its cached point carried */
         if (P.warm_start && c.mpoint >= 0)
-            row.applied = e->manifolds[c.link].p[c.mpoint].lambda * (Real)P.warmstarting_factor;
+            row.applied = (c.kind == 3 ? e->bman.p[c.mpoint].lambda : e->manifolds[c.link].p[c.mpoint].lambda) *
+                          (Real)P.warmstarting_factor;
         normals.push_back(row);
         /* two friction directions from btPlaneSpace1(n) ((0,-1,0), (1,0,0) for the ground's n = (0,0,1)),
          * each scaled by the link's anisotropic friction in link axes:
@@ -1340,9 +1470,13 @@ void substep(orc_env* e, const Real* targets) {
         }
         for (int f = 0; f < 2; f++) {
             Real loc[3], dsc[3];
-            mat3T_vec(&e->Rw[9 * c.link], fd[f], loc);
-            for (int r = 0; r < 3; r++) loc[r] *= (Real)P.aniso[r];
-            mat3_vec(&e->Rw[9 * c.link], loc, dsc);
+            if (c.link >= 0) {
+                mat3T_vec(&e->Rw[9 * c.link], fd[f], loc);
+                for (int r = 0; r < 3; r++) loc[r] *= (Real)P.aniso[r];
+                mat3_vec(&e->Rw[9 * c.link], loc, dsc);
+            } else {
+                for (int r = 0; r < 3; r++) dsc[r] = fd[f][r];      /* the box has no anisotropic friction */
+            }
             if (c.linkB >= 0) {
                 mat3T_vec(&e->Rw[9 * c.linkB], dsc, loc);
                 for (int r = 0; r < 3; r++) loc[r] *= (Real)P.aniso[r];
@@ -1353,7 +1487,7 @@ void substep(orc_env* e, const Real* targets) {
             fr.J.assign(nd, 0); fr.M.assign(nd, 0);
             memcpy(fr.dir, dsc, sizeof(dsc));
             contact_jac(c, dsc, fr.J.data());
-            minv_apply(e, c.link, c.P, dsc, nullptr, fr.M.data(), c.linkB, c.PB);
+            contact_minv(c, dsc, fr);
             Real rv = 0;
             for (int i = 0; i < nd; i++) rv += fr.J[i] * g[i];
             finish_row(fr, -rv);
@@ -1430,6 +1564,11 @@ void substep(orc_env* e, const Real* targets) {
     e->last_normal_impulse.assign(nc, 0);
     for (int ci = 0; ci < nc; ci++) {
         const Contact& c = e->contacts[ci];
+        e->last_normal_impulse[ci] = normals[ci].applied;
+        if (c.link < 0) {      /* the box against the ground: no force on the snake */
+            if (c.mpoint >= 0) e->bman.p[c.mpoint].lambda = normals[ci].applied;
+            continue;
+        }
         ExtForce f;
         f.link = c.link;
         for (int r = 0; r < 3; r++) {
@@ -1445,7 +1584,10 @@ void substep(orc_env* e, const Real* targets) {
             ext.push_back(fb);
         }
         e->last_normal_impulse[ci] = normals[ci].applied;
-        if (c.mpoint >= 0) e->manifolds[c.link].p[c.mpoint].lambda = normals[ci].applied;   /* m_appliedImpulse */
+        if (c.mpoint >= 0) {   /* m_appliedImpulse */
+            if (c.kind == 3) e->bman.p[c.mpoint].lambda = normals[ci].applied;
+            else e->manifolds[c.link].p[c.mpoint].lambda = normals[ci].applied;
+        }
     }
     velocities(e, e->omega, e->vel, e->qd.data());
     bias_forces(e, true, true, false, &ext);
@@ -1460,6 +1602,30 @@ void substep(orc_env* e, const Real* targets) {
 
     /* (7) apply solver delta-v (processDeltaVeeMultiDof2), motor torques, integrate */
     apply_dv(e, dv.data(), 1);
+    if (fbox) {
+        Real mx = (Real)P.max_coord_vel;
+        auto clampv = [&](Real& x) { if (x > mx) x = mx; if (x < -mx) x = -mx; };
+        for (int r = 0; r < 3; r++) {
+            e->bomega[r] += dv[nds + r]; clampv(e->bomega[r]);
+            e->bvel[r] += dv[nds + 3 + r]; clampv(e->bvel[r]);
+        }
+        /* stepPositionsMultiDof: the same exponential-map update as the snake's base */
+        for (int r = 0; r < 3; r++) e->bpos[r] += dt * e->bvel[r];
+        Real fAngle = std::sqrt(dot3(e->bomega, e->bomega));
+        const Real kThresh = (Real)(0.5 * (kPi / 2));
+        if (fAngle * dt > kThresh) fAngle = kThresh / dt;
+        Real sc = fAngle < Real(0.001) ? Real(0.5) * dt - (dt * dt * dt) * Real(0.020833333333) * fAngle * fAngle
+                                       : std::sin(Real(0.5) * fAngle * dt) / fAngle;
+        Real dq[4] = {e->bomega[0] * sc, e->bomega[1] * sc, e->bomega[2] * sc, std::cos(fAngle * dt * Real(0.5))};
+        Real* q = e->bquat;
+        Real nq[4];
+        nq[3] = dq[3] * q[3] - dq[0] * q[0] - dq[1] * q[1] - dq[2] * q[2];
+        nq[0] = dq[3] * q[0] + dq[0] * q[3] + dq[1] * q[2] - dq[2] * q[1];
+        nq[1] = dq[3] * q[1] - dq[0] * q[2] + dq[1] * q[3] + dq[2] * q[0];
+        nq[2] = dq[3] * q[2] + dq[0] * q[1] - dq[1] * q[0] + dq[2] * q[3];
+        Real nn = std::sqrt(nq[0] * nq[0] + nq[1] * nq[1] + nq[2] * nq[2] + nq[3] * nq[3]);
+        for (int r = 0; r < 4; r++) q[r] = nq[r] / nn;
+    }
     for (size_t k2 = 0; k2 < noncontact.size(); k2++)
         if (noncontact[k2].kind == 1) e->tau_motor[noncontact[k2].joint] = noncontact[k2].applied / dt;
     integrate_positions(e);
@@ -1493,6 +1659,22 @@ void get_obs(const orc_env* e, double* obs) {
     obs[3 * n + 7] = e->fz;
 }
 
+/* the obstacle box where loadURDF puts it (snake.py:84, snake_gait_test.py:51), at rest, empty manifold */
+void box_reset(orc_env* e) {
+    const orc_params& P = e->P;
+    for (int r = 0; r < 3; r++) { e->bpos[r] = (Real)P.obstacle_pos[r]; e->bomega[r] = 0; e->bvel[r] = 0; }
+    e->bquat[0] = e->bquat[1] = e->bquat[2] = 0; e->bquat[3] = 1;
+    box_frame(e);
+    memset(&e->bman, 0, sizeof(e->bman));
+    /* [U] no URDF_USE_INERTIA_FROM_FILE: btBoxShape::calculateLocalInertia on the nominal box (the collider is the
+     * box itself: a compound with one child at the identity is replaced by the child) */
+    const double lx = 2 * P.obstacle_half[0], ly = 2 * P.obstacle_half[1], lz = 2 * P.obstacle_half[2], m = P.obstacle_mass;
+    e->bI[0] = (Real)(m / 12 * (ly * ly + lz * lz));
+    e->bI[1] = (Real)(m / 12 * (lx * lx + lz * lz));
+    e->bI[2] = (Real)(m / 12 * (lx * lx + ly * ly));
+    if (P.inertia_from_file) { e->bI[0] = 1; e->bI[1] = 100; e->bI[2] = 1; }      /* block.urdf:7 */
+}
+
 void soft_reset(orc_env* e) {
     /* snake.py:96-99: resetBasePositionAndOrientation([0,0,0],[0,0,0,1]) zeroes the base
      * twist [U]; resetJointState(i, 0) zeroes q and qd; motor/sensor caches persist [U] */
@@ -1520,6 +1702,7 @@ void orc_default_params(orc_params* p) {
     p->obstacle_pos[0] = 2.0; p->obstacle_pos[1] = 0.0; p->obstacle_pos[2] = 0.1;      /* snake.py:94 */
     p->obstacle_half[0] = 0.1; p->obstacle_half[1] = 0.4; p->obstacle_half[2] = 0.1;   /* snake/block.urdf:16 */
     p->mu_obstacle = 0.5;
+    p->obstacle_mass = 200.0;                                                          /* snake/block.urdf:6 */
     p->contact_model = 1;/* Bullet's persistent manifold [U]; 0 = the stateless two-point manifold of round 1 */
     p->dt = 1.0 / 240.0;
     p->gravity_z = -9.8;
@@ -1610,6 +1793,33 @@ void orc_hard_reset(orc_env* e) {
     e->contacts.clear();
     e->last_normal_impulse.clear();
     e->manifolds.clear();    /* resetSimulation + loadURDF: a new world (a soft reset keeps the contact cache [U]) */
+    box_reset(e);
+}
+
+void orc_get_box_state(const orc_env* e, double* s) {
+    for (int r = 0; r < 3; r++) { s[r] = e->bpos[r]; s[7 + r] = e->bomega[r]; s[10 + r] = e->bvel[r]; }
+    for (int r = 0; r < 4; r++) s[3 + r] = e->bquat[r];
+}
+void orc_set_box_state(orc_env* e, const double* s) {
+    for (int r = 0; r < 3; r++) { e->bpos[r] = (Real)s[r]; e->bomega[r] = (Real)s[7 + r]; e->bvel[r] = (Real)s[10 + r]; }
+    for (int r = 0; r < 4; r++) e->bquat[r] = (Real)s[3 + r];
+    box_frame(e);
+}
+void orc_get_box_manifold(const orc_env* e, double* o) {
+    for (int r = 0; r < 29; r++) o[r] = 0;
+    o[0] = e->bman.n;
+    for (int j = 0; j < e->bman.n; j++) {
+        for (int r = 0; r < 3; r++) { o[1 + 7 * j + r] = e->bman.p[j].localA[r]; o[4 + 7 * j + r] = e->bman.p[j].worldB[r]; }
+        o[7 + 7 * j] = e->bman.p[j].lambda;
+    }
+}
+void orc_set_box_manifold(orc_env* e, const double* o) {
+    memset(&e->bman, 0, sizeof(e->bman));
+    e->bman.n = (int)o[0];
+    for (int j = 0; j < e->bman.n; j++) {
+        for (int r = 0; r < 3; r++) { e->bman.p[j].localA[r] = (Real)o[1 + 7 * j + r]; e->bman.p[j].worldB[r] = (Real)o[4 + 7 * j + r]; }
+        e->bman.p[j].lambda = (Real)o[7 + 7 * j];
+    }
 }
 
 /* contact cache, per cylinder in link order: [count, 4 x (point on the link in link coords 3, point on the ground 3,

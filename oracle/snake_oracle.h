@@ -53,11 +53,15 @@ typedef struct orc_params {
                                * inside the joint limits (tools/self_collision_clearance.py, and a test);
                                * the 32-link tests switch it on (the product evaluates it for 32 links)        */
     int32_t max_self_contacts;/* 0 = no limit; > 0 mirrors the product's cap on link-link + obstacle contacts  */
-    int32_t obstacle;         /* 1: a STATIC box on the ground (snake/block.urdf; snake.py:83-84,94,
-                               * snake_gait_test.py:51 -- a free 200-kg body there: documented deviation)      */
+    int32_t obstacle;         /* the box of snake/block.urdf (snake.py:83-84,94; snake_gait_test.py:51).  1: STATIC;
+                               * 2: as the reference loads it (useFixedBase=0): a FREE body of obstacle_mass resting on
+                               * the ground -- a btMultiBody without links [U]: gravity, link damping, its own
+                               * persistent manifold with the plane (one support corner per step, <= 4 cached),
+                               * two-body rows with the snake's links                                            */
     double  obstacle_pos[3];  /* centre [2, 0, 0.1]                                                            */
     double  obstacle_half[3]; /* half extents [0.1, 0.4, 0.1] (block.urdf:16)                                  */
     double  mu_obstacle;      /* 0.5 [U]                                                                       */
+    double  obstacle_mass;    /* 200 (block.urdf:6); inertia from the box shape [U] (inertia_from_file: 1, 100, 1) */
     /* world / integrator */
     double  dt;               /* PyBullet default fixedTimeStep 1/240 [U] (F2)           */
     double  gravity_z;        /* snake.py:8  -9.8                                        */
@@ -132,6 +136,13 @@ void     orc_get_obs(const orc_env* e, double* obs);  /* snake.py:209-217 */
 double   orc_mean_height(orc_env* e);                 /* snake.py:237-245 (value) */
 /* getJointState(robot, 3)[2][2] of the last substep (snake_gait_test.py:33-40,126: "> 20: hit the wall") */
 double   orc_joint3_reaction_fz(const orc_env* e);
+
+/* obstacle 2: the box's state [pos3, quat xyzw 4, omega_world 3, vel_world 3] and its manifold with the plane
+ * [count, 4 x (point on the box in box coordinates 3, point on the ground 3, applied normal impulse)] = 29 */
+void     orc_get_box_state(const orc_env* e, double* s13);
+void     orc_set_box_state(orc_env* e, const double* s13);
+void     orc_get_box_manifold(const orc_env* e, double* m29);
+void     orc_set_box_manifold(orc_env* e, const double* m29);
 
 /* contact cache of contact_model 1, per cylinder in link order:
  * [count, 4 x (point on the link in link coordinates 3, point on the ground in world coordinates 3, the normal impulse

@@ -3,10 +3,12 @@ that `Snake.add_obstacle` (/root/reference/snake.py:83-84; commented out on the 
 `snake_gait_test.py:51` put in front of the snake, and the script's "hit the wall" read-out: the z component of the
 first motor joint's reaction force (`getJointState(robot, 3)[2][2] > 20`, snake_gait_test.py:33-40,126).
 
-Here the box is STATIC (the reference's is a free 200-kg body resting on the ground: a documented deviation; the snake's
-4-N-m motors cannot move it).  Contacts: GJK between each cylinder and the box, one point per pair per step.  Since
-round 3 a 16-link handle with `obstacle=1` stays on the register-resident solve (up to 8 box contacts, taken out of its
-64 slots); SNK_FORCE_STREAMED=1 puts it on the streamed-row kernels of the 32-link chain, and the two must agree.
+Two forms (snk_params / orc_params `obstacle`): 1 = STATIC (an immovable box; a 16-link handle stays on the
+register-resident solve, up to 8 box contacts out of its 64 slots) and 2 = as the reference loads it (useFixedBase=0): a
+FREE 200-kg body with its own six velocity components, gravity, damping and persistent manifold with the plane, rows
+with the snake's links over both bodies (16 links, streamed-row kernels).  Contacts: GJK between each cylinder and the
+box, one point per pair per step.  SNK_FORCE_STREAMED=1 puts a 16-link handle on the streamed-row kernels of the 32-link
+chain, and the two solves must agree.
 
 Tolerances: one env-step from a synchronised state, float32 GPU vs float64 oracle, judged against the float32 build of
 the oracle on the same step (factor 3, floors 1e-3 on angles / pose, 5e-2 relative on joint velocities, 2 N on the
@@ -138,13 +140,15 @@ def test_add_obstacle_mirror(pkg):
     robot = pkg.Snake(None, "snake/snake.urdf", None)
     env = pkg.SnakeGymEnv(robot, None)
     robot.add_obstacle("block.urdf", [0.100, 0.0, 0.1])
-    assert env.params.obstacle == 1
+    assert env.params.obstacle == 2                       # loadURDF's default: useFixedBase = 0, a free body
     import bench
     mx = 0.0
     for j in range(12):
         o, r, d, info = env.step(bench.gait_actions([5], j)[0].astype(np.float64))
         mx = max(mx, abs(float(env._stepper.joint3_reaction_fz()[0])))
     assert o[48] < 0.004 and mx > 20.0
+    robot.add_obstacle("block.urdf", [0.100, 0.0, 0.1], static=True)
+    assert env.params.obstacle == 1
     env.close()
 
 
@@ -230,3 +234,143 @@ def test_two_solves_one_physics(pkg, monkeypatch, box):
     assert st["qd"][0] < 1e-2 and st["qd"][1] < 0.15
     assert st["r"][0] < 2e-4 and st["r"][1] < 2e-3
     a_.close(); b_.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# obstacle = 2: the box as the reference loads it (useFixedBase=0): a free 200-kg body (snake/block.urdf:6)
+# ---------------------------------------------------------------------------------------------------------------------
+GAIT_TEST_WORLD = dict(dt=0.01, gravity_z=-9.81, max_motor_impulse=4.0 * 0.01)      # snake_gait_test.py:52-53,76: setTimeStep(0.01),
+                                                                                    # g = -9.81, forces = 4 N m -> impulse 4 dt
+
+
+def test_oracle_free_box_rests_on_its_four_corners(oracle_mod):
+    """The box is a btMultiBody without links: gravity, damping, ONE new support corner per step into a persistent
+    manifold.  Dropped where loadURDF puts it, it rocks onto its four bottom corners within a quarter of a second and
+    the ground then carries exactly its weight."""
+    e = oracle_mod.OracleEnv(obstacle=2, obstacle_pos=[2.0, 0.0, 0.1])
+    e.reset()
+    counts = []
+    for k in range(240):
+        e.substep(np.zeros(16))
+        counts.append(int(e.get_box()[1][0]))
+    s, m = e.get_box()
+    assert counts[0] == 1 and counts[-1] == 4
+    assert abs(s[2] - 0.1) < 2e-4 and np.abs(s[7:]).max() < 1e-4 and np.abs(s[3:6]).max() < 1e-4
+    lc = e.last_contacts_full()
+    imp = e.last_normal_impulses(512)[:len(lc)]
+    assert abs(imp[lc[:, 4] < 0].sum() * 240.0 - 200.0 * 9.8) < 0.5
+    # and the snake does not feel it from two metres away: same state as without the box
+    p = oracle_mod.OracleEnv()
+    p.reset()
+    for k in range(240):
+        p.substep(np.zeros(16))
+    assert np.abs(p.get_state() - e.get_state()).max() < 1e-12
+
+
+@gpu
+@pytest.mark.parametrize("world", ["default", "gait_test"])
+def test_free_box_env_step_parity(pkg, oracle_mod, world):
+    """obstacle = 2 on the device (16 links, streamed-row kernels with six more velocity components) against the
+    oracle, one env-step at a time from synchronised states -- snake, contact cache, box and the box's own manifold --
+    in the reference's training world and in the gait-test script's (dt 0.01, 4-N-m motors, g -9.81,
+    snake_gait_test.py:51-53,71-76), whose read-out (joint-3 reaction > 20: "the snake has hit the wall", :126) is
+    compared as well.  Tolerances: calibrated against the float32 build of the oracle on the same steps, factor 4."""
+    import bench
+    B, J, n = 6, 8, 16
+    over = dict(obstacle=2, obstacle_pos=[0.100, 0.0, 0.1])
+    if world == "gait_test":
+        over.update(GAIT_TEST_WORLD)
+    st = pkg.Stepper(B, **over)
+    st.reset()
+    refs = [oracle_mod.OracleEnv(max_self_contacts=32, max_contacts=4 * n, **over) for _ in range(B)]
+    refs32 = [oracle_mod.OracleEnv(max_self_contacts=32, max_contacts=4 * n, f32=True, **over) for _ in range(B)]
+    ids = np.arange(B)
+    w = dict(q=0.0, qd=0.0, r=0.0, f3=0.0, box=0.0)
+    c = dict(q=0.0, qd=0.0, r=0.0, f3=0.0, box=0.0)
+    mism = touched = compared = 0
+    peak = 0.0
+    for j in range(J):
+        S, X = st.get_state()
+        Mf = st.get_manifold()
+        BS, BM = st.get_box()
+        a = bench.gait_actions(ids + 5, j).astype(np.float32)
+        obs, rew, done, sub = st.step(a.copy(), vec_mode=False)
+        f3 = st.joint3_reaction_fz()
+        BS2, _ = st.get_box()
+        peak = max(peak, float(np.abs(f3).max()))
+        for i in range(B):
+            out = []
+            for e in (refs[i], refs32[i]):
+                e.sync(S[i], X[i], Mf[i])
+                e.set_box(BS[i], BM[i])
+                out.append(e.env_step(a[i].astype(np.float64), vec_mode=False) + (e.joint3_reaction_fz(), e.get_box()[0]))
+            (o, r, d, k, _, g3, b64), (o32, r32, d32, k32, _, g32, b32) = out
+            lc = refs[i].last_contacts_full()
+            if len(lc) and (lc[:, 5] == -2).any():
+                touched += 1
+
+            def smooth(rr, oo):
+                return rr + (10.0 if abs(oo[3 * n + 7]) > 10.0 else 0.0)
+
+            def errs(oo, rr, ff, bb):
+                q = max(np.abs(oo[:n] - o[:n]).max(), np.abs(oo[3 * n:3 * n + 7] - o[3 * n:3 * n + 7]).max())
+                qd = (np.abs(oo[n:2 * n] - o[n:2 * n]) / (1 + np.abs(o[n:2 * n]))).max()
+                return dict(q=q, qd=qd, r=abs(smooth(rr, oo) - smooth(r, o)), f3=abs(ff - g3),
+                            box=max(np.abs(bb[:7] - b64[:7]).max(), 0.1 * np.abs(bb[7:] - b64[7:]).max()))
+            if k32 == k and d32 == d:
+                for key, v in errs(o32, r32, g32, b32).items():
+                    c[key] = max(c[key], v)
+            if k != sub[i] or d != bool(done[i]):
+                mism += 1
+                assert abs(k - sub[i]) <= 1
+                continue
+            if k == 0:
+                continue
+            compared += 1
+            for key, v in errs(obs[i].astype(np.float64), float(rew[i]), float(f3[i]), BS2[i].astype(np.float64)).items():
+                w[key] = max(w[key], v)
+    print("free box parity,", world, "GPU-f32", w, "| oracle-f32", c, "| boundary mismatches", mism, "| steps touching the box",
+          touched, "| peak joint-3 reaction", peak, "| overflow", st.contact_overflow())
+    assert touched >= B and compared >= B * J // 2
+    assert mism <= max(2, B * J // 8)
+    assert w["q"] < max(1e-3, 4 * c["q"]) and w["qd"] < max(5e-2, 4 * c["qd"])
+    assert w["r"] < max(5e-3, 4 * c["r"]) and w["f3"] < max(2.0, 4 * c["f3"])
+    assert w["box"] < max(1e-5, 4 * c["box"])
+    assert peak > 20.0                                   # snake_gait_test.py:126: "The snake has hit the wall"
+    st.close()
+
+
+@gpu
+def test_free_box_settles_moves_and_survives_a_checkpoint(pkg, tmp_path):
+    """Free-running on the device: far from the snake the box settles on four corners where it was put; in the
+    snake's way it is pushed (a little: 200 kg on friction 0.5 against 4-N-m motors) while a static one is not; results
+    do not depend on the schedule, and a checkpoint carries the box."""
+    import bench
+    B = 64
+    ids = np.arange(B) + 5
+    far = pkg.Stepper(B, obstacle=2, obstacle_pos=[2.0, 0.0, 0.1])
+    far.reset()
+    for j in range(3):
+        far.step(bench.gait_actions(ids, j).astype(np.float32))
+    s, m = far.get_box()
+    assert np.all(m[:, 0] >= 3) and np.abs(s[:, 2] - 0.1).max() < 3e-4 and np.abs(s[:, :2] - [2.0, 0.0]).max() < 1e-3
+    far.close()
+    near = pkg.Stepper(B, obstacle=2, obstacle_pos=[0.100, 0.0, 0.1])
+    near.reset()
+    outs = []
+    for j in range(6):
+        if j == 3:
+            pkg.save_state(near, str(tmp_path / "box.npz"))
+        outs.append(near.step(bench.gait_actions(ids, j).astype(np.float32)))
+    s, m = near.get_box()
+    assert np.median(s[:, 0]) > 0.1 + 1e-5 and np.abs(s[:, 0] - 0.1).max() < 5e-3       # pushed forward, a little
+    again = pkg.Stepper(B, obstacle=2, obstacle_pos=[0.100, 0.0, 0.1])
+    pkg.load_state(again, str(tmp_path / "box.npz"))
+    for j in range(3, 6):
+        o, r, d, k = again.step(bench.gait_actions(ids, j).astype(np.float32))
+        assert np.array_equal(o, outs[j][0]) and np.array_equal(r, outs[j][1]) and np.array_equal(k, outs[j][3])
+    s2, m2 = again.get_box()
+    assert np.array_equal(s, s2) and np.array_equal(m, m2)
+    near.close(); again.close()
+    with pytest.raises(RuntimeError):
+        pkg.Stepper(2, n_modules=32, obstacle=2)
