@@ -167,6 +167,8 @@ def main():
                     help="diagnostic: 16 links on the streamed-row solve (SNK_FORCE_STREAMED=1)")
     ap.add_argument("--obstacle", type=float, default=None, metavar="X",
                     help="not a BASELINE config: the block of snake_gait_test.py:51 (static) with its centre at x = X")
+    ap.add_argument("--obstacle-free", action="store_true",
+                    help="with --obstacle: the block as the reference loads it, a free 200-kg body (obstacle = 2)")
     ap.add_argument("--no-variants", action="store_true",
                     help="skip the extra measurement of the round-1 contact model (1 GPU, default configuration only)")
     ap.add_argument("--policy", action="store_true",
@@ -231,7 +233,7 @@ def main():
     if args.warm_start:
         extra["warm_start"] = 1
     if args.obstacle is not None:
-        extra.update(obstacle=1, obstacle_pos=[args.obstacle, 0.0, 0.1])
+        extra.update(obstacle=2 if args.obstacle_free else 1, obstacle_pos=[args.obstacle, 0.0, 0.1])
     local = pkg.DeviceVecEnv(E, device_index=local_rank, n_modules=NL, hull_sides=args.hull_sides,
                              contact_model=args.contact_model, self_collision=args.self_collision, **extra)
     if args.friction_seed is not None:      # configs[4]: this rank's shard of the per-env plane friction
@@ -354,7 +356,7 @@ def main():
             "_hull%d_cm%d" % (args.hull_sides, args.contact_model) if (args.hull_sides != 32 or args.contact_model != 1) else "") + (
             "_warm" if args.warm_start else "") + (
             "_nosc" if (NL == 32 and not args.self_collision) else "") + ("_streamed" if args.streamed_rows else "") + (
-            "_obstacle" if args.obstacle is not None else "")
+            ("_obstacle2" if args.obstacle_free else "_obstacle") if args.obstacle is not None else "")
         traffic, traffic_src, valu = None, None, None
         try:
             import glob

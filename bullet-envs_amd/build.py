@@ -33,7 +33,12 @@ def build(force=False, verbose=False, defines=(), out=None):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-shared", "-fPIC",
+    # -greedy-regclass-priority-trumps-globalness: the register-resident solve keeps 192 row registers + 16 motor columns
+    # alive across its loop; with the allocator's default priorities 4-12 of them ended up in scratch memory, reloaded
+    # in EVERY Gauss-Seidel iteration, and which ones changed with every edit of unrelated code (round 3: 314 k ...
+    # 341 k env-steps/s for the same arithmetic).  With this priority rule: two reloads per iteration, 342.8 k.
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-mllvm",
+           "-greedy-regclass-priority-trumps-globalness=1", "-shared", "-fPIC",
            os.path.join(CSRC, "snk_api.hip"), "-o", out or LIB] + ["-D" + d for d in defines]
     cmd += os.environ.get("SNK_EXTRA_FLAGS", "").split()        # compiler experiments
     if verbose:

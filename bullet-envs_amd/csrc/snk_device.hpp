@@ -202,7 +202,11 @@ struct Lds;
 template <int N>
 struct Lds<N, false> : LdsCommon<N, 2 * N> {
     static constexpr bool kV2 = false;
-    static constexpr int NC = 4 * N, NR = 12 * N, ND = N + 6;
+    // ground-contact slots: 128 for BOTH chain lengths.  The 32-link chain's two end-cap points per cylinder; for the
+    // 16-link chain every point its 32 cylinders' manifolds can hold (4 each) -- this solve is where an environment
+    // goes whose contacts do not fit the register-resident solve's 64 slots (snk_api.hip: overflow list), so that no
+    // 16-link contact is ever left without rows
+    static constexpr int NC = (N <= 16) ? 128 : 4 * N, NR = 3 * NC, ND = N + 6;
     float ext_[LdsCommon<N, 2 * N>::NB][6];      // link forces of the constraint pass
     __device__ __forceinline__ float* ext(int b) { return ext_[b]; }
     __device__ __forceinline__ void poison(int lane) {
@@ -1857,6 +1861,23 @@ __device__ __forceinline__ void soft_reset(LT& L, int lane) {
     for (int i = lane; i < 13 + 2 * N; i += 64) L.rec[i] = (i == 6) ? 1.0f : 0.0f;
 }
 
+// Environments whose contacts do not fit the register-resident solve's 64 slots in some substep (find_contacts_v2) are
+// taken over, from that substep on, by the streamed-row kernels of the same chain (128 + 32 slots: every point a
+// 16-link snake's manifolds can hold): the register-resident kernel stores the untouched state, the substeps done so
+// far (counters) and appends the env to this list; the host launches the streamed-row kernel over the list right
+// behind it (snk_api.hip).  list == nullptr: no hand-over (the streamed-row kernels themselves).
+struct Over {
+    int32_t* list;
+    int32_t* count;
+    int32_t* counters;      // [n_envs]: substeps of the current env-step (or of the current snk_substep_host call) done so far
+};
+__device__ __forceinline__ void over_push(const Over& ov, int lane, int env, int counter) {
+    if (lane == 0) {
+        ov.counters[env] = counter;
+        ov.list[atomicAdd(ov.count, 1)] = env;
+    }
+}
+
 // ----------------------------------------------------------------------------------
 // kernels
 // ----------------------------------------------------------------------------------
@@ -1868,15 +1889,18 @@ __global__ __launch_bounds__(64, 2) void env_step_kernel(const DevModel* __restr
                                                       int32_t* __restrict__ substeps, int vec_mode, int n_envs,
                                                       const int32_t* __restrict__ order, float* __restrict__ rows_all,
                                                       float* __restrict__ mf_all, unsigned long long* __restrict__ ovf,
-                                                      float* __restrict__ box_all) {
+                                                      float* __restrict__ box_all, Over resume, Over over) {
     extern __shared__ float4 smem_raw[];
     using LT = Lds<N, V2>;
     LT& L = *reinterpret_cast<LT*>(smem_raw);
     const DevModel& M = *Mp;
     // longest-first schedule: workgroup b takes the envs with the b-th, (b + G)-th, ... largest predicted work (G
-    // workgroups: as many as the chip holds at once; the block of streamed constraint rows belongs to the WORKGROUP)
-    for (int slot_ = blockIdx.x; slot_ < n_envs; slot_ += gridDim.x) {
-    const int env = order ? __builtin_amdgcn_readfirstlane(order[slot_]) : slot_;
+    // workgroups: as many as the chip holds at once; the block of streamed constraint rows belongs to the WORKGROUP).
+    // resume.list: only the env-steps another kernel handed over (struct Over), continued from resume.counters
+    const int n_items = resume.list ? __builtin_amdgcn_readfirstlane(*resume.count) : n_envs;
+    for (int slot_ = blockIdx.x; slot_ < n_items; slot_ += gridDim.x) {
+    const int env = resume.list ? __builtin_amdgcn_readfirstlane(resume.list[slot_])
+                                : (order ? __builtin_amdgcn_readfirstlane(order[slot_]) : slot_);
     const int lane = threadIdx.x;
     if (M.poison) { L.poison(lane); lds_sync(); }
     load_rec(L, recs + (size_t)env * LT::REC, lane);
@@ -1906,8 +1930,8 @@ __global__ __launch_bounds__(64, 2) void env_step_kernel(const DevModel* __restr
     load_box(L, env_box, lane);
     fk_vel(L, M, lane);
     // Snake.step servo loop (snake.py:283-304)
-    int counter = 0;
-    bool end_height = false;
+    int counter = resume.list ? __builtin_amdgcn_readfirstlane(resume.counters[env]) : 0;
+    bool end_height = false, handed_over = false;
     int it_dummy = 0, nc_dummy = 0;
     SensorHint hint;
     hint.always = false;
@@ -1918,10 +1942,19 @@ __global__ __launch_bounds__(64, 2) void env_step_kernel(const DevModel* __restr
         if (!(nrm > M.servo_tol)) break;
         hint.counter_next = counter + 1;
         substep(L, M, lane, mu, it_dummy, nc_dummy, hint, env_rows, env_mf, ovf);
+        if (nc_dummy < 0) { handed_over = true; break; }      // (register-resident solve only: struct Over)
         counter++;
         hint.h_prev = mean_height(L, M, lane);
         if (hint.h_prev > M.height_thr) { end_height = true; break; }
         if (counter > M.max_counter) break;
+    }
+    if (handed_over) {
+        // the state as the refused substep found it goes back to memory; the streamed-row kernel carries on from there
+        store_rec(L, recs + (size_t)env * LT::REC, lane);
+        store_mf<LT, false>(L, env_mf, lane);
+        over_push(over, lane, env, counter);
+        lds_sync();
+        continue;
     }
     // SnakeGymEnv.step (SnakeGymEnv.py:36-42)
     float en = (lane < N) ? L.qd()[lane] * L.taum()[lane] * M.energy_dt : 0.f;   // snake.py:336-341
@@ -1962,13 +1995,15 @@ __global__ __launch_bounds__(64, 2) void substep_kernel(const DevModel* __restri
                                                      const float* __restrict__ targets, int k,
                                                      int32_t* __restrict__ info, int n_envs, float* __restrict__ rows_all,
                                                      float* __restrict__ mf_all, unsigned long long* __restrict__ ovf,
-                                                     float* __restrict__ box_all) {
+                                                     float* __restrict__ box_all, Over resume, Over over) {
     extern __shared__ float4 smem_raw[];
     using LT = Lds<N, V2>;
     LT& L = *reinterpret_cast<LT*>(smem_raw);
     const DevModel& M = *Mp;
     const int lane = threadIdx.x;
-    for (int env = blockIdx.x; env < n_envs; env += gridDim.x) {      // (the block of streamed rows belongs to the workgroup)
+    const int n_items = resume.list ? __builtin_amdgcn_readfirstlane(*resume.count) : n_envs;
+    for (int slot_ = blockIdx.x; slot_ < n_items; slot_ += gridDim.x) {      // (the block of streamed rows belongs to the workgroup)
+    const int env = resume.list ? __builtin_amdgcn_readfirstlane(resume.list[slot_]) : slot_;
     if (M.poison) { L.poison(lane); lds_sync(); }
     load_rec(L, recs + (size_t)env * LT::REC, lane);
     if (lane < N) L.targets[lane] = targets[(size_t)env * N + lane];
@@ -1984,8 +2019,12 @@ __global__ __launch_bounds__(64, 2) void substep_kernel(const DevModel* __restri
     load_mf(L, env_mf, lane);
     float* env_box = box_all ? box_all + (size_t)env * kBoxFloats : nullptr;
     load_box(L, env_box, lane);
-    for (int s = 0; s < k; s++) substep(L, M, lane, mu, iters, nc, hint, env_rows, env_mf, ovf);
-    if (info && lane == 0) { info[2 * env] = iters; info[2 * env + 1] = nc; }
+    // (resume: the substeps of this call the register-resident kernel had done before it handed the env over)
+    for (int s = resume.list ? __builtin_amdgcn_readfirstlane(resume.counters[env]) : 0; s < k; s++) {
+        substep(L, M, lane, mu, iters, nc, hint, env_rows, env_mf, ovf);
+        if (nc < 0) { over_push(over, lane, env, s); break; }          // (register-resident solve only: struct Over)
+    }
+    if (info && lane == 0 && nc >= 0) { info[2 * env] = iters; info[2 * env + 1] = nc; }
     store_rec(L, recs + (size_t)env * LT::REC, lane);
     store_mf<LT, false>(L, env_mf, lane);
     store_box<LT, false>(L, env_box, lane);
@@ -2252,7 +2291,8 @@ __device__ __forceinline__ void sched_push(const Sched& sc, int lane, int env, i
 // One block: the queue of a launch, env-steps with the most predicted substeps first (counting sort).
 template <int N>
 __global__ __launch_bounds__(1024) void plan_sched_kernel(const DevModel* __restrict__ Mp, const float* __restrict__ recs,
-                                                          const float* __restrict__ actions, Sched sc, int n_envs) {
+                                                          const float* __restrict__ actions, Sched sc, int n_envs,
+                                                          int32_t* __restrict__ over_count) {
     constexpr int REC = (N <= 16) ? 64 : 128;
     __shared__ uint32_t hist[kBuckets], base[kBuckets];
     const DevModel& M = *Mp;
@@ -2288,6 +2328,7 @@ __global__ __launch_bounds__(1024) void plan_sched_kernel(const DevModel* __rest
         for (int b = kBuckets - 1; b >= 0; b--) { base[b] = run; run += hist[b]; }
         *sc.tail = run;
         *sc.finished = 0;
+        if (over_count) *over_count = 0;        // the list of env-steps handed over to the streamed-row kernel (struct Over)
     }
     if (tid < kBuckets) sc.waiting[tid] = (int32_t)hist[tid];
     __syncthreads();
@@ -2322,6 +2363,7 @@ struct StepArgs {
     float* mf_all;
     unsigned long long* ovf;
     float* box_all;
+    Over over;
     Sched sc;
     int32_t model_slot, vec_mode, n_envs, pad_;
 };
@@ -2450,6 +2492,18 @@ __global__ __launch_bounds__(64, 2) void env_step_sched_kernel(StepArgs args_by_
                 if constexpr (!LT::kV2) env_rows = aq->rows_all + (size_t)blockIdx.x * LT::kRowFloats;   // one block per resident wave
                 substep(L, M, lane, mu, it_dummy, nc_dummy, hint, env_rows, env_mf(aq), aq->ovf);
                 lane = lane_id();       // (not kept in a register across the solve)
+            }
+            if (nc_dummy < 0) {
+                // the contacts do not fit this solve (struct Over): the untouched state goes back to memory, the
+                // streamed-row kernel behind this launch finishes the env-step; for this launch's queue it is done
+                const StepArgPtr ao = step_args();
+                store_rec(L, ao->recs + (size_t)env * LT::REC, lane);
+                store_mf<LT, false>(L, env_mf(ao), lane);
+                Over ov;
+                ov.list = ao->over.list; ov.count = ao->over.count; ov.counters = ao->sc.counter;
+                over_push(ov, lane, env, counter);
+                atomicAdd(ao->sc.finished, lane == 0 ? 1 : 0);
+                break;
             }
 #ifdef SNK_SCHED_DEBUG
             n_sub++;

@@ -491,14 +491,18 @@ __device__ int find_contacts_v2(LT& L, const DevModel& M, int lane, unsigned lon
         int total;
         (void)lane_prefix3(cnt, lane, total);
         const int room = 4 * N - n_ob;               // the solve's contact slots, less the box's contacts
-        const int mask = manifold_keep_mask(cnt, p, lane, total, room);
-        const int kept = __popc(mask);
+        if (total > room) {
+            // More points than this solve has slots for (a snake at rest gathers up to four per cylinder: 128).  Bullet
+            // has no such limit, and neither has the streamed-row solve of this chain (128 + 32 slots): nothing has
+            // been written yet, the caller hands the environment over to it from this substep on (snk_api.hip: the
+            // overflow list).  Counted (snk_contact_overflow), never silent.
+            if (lane == 0) atomicAdd(ovf, 1ull);
+            return -1;
+        }
+        const int mask = (1 << cnt) - 1;
+        const int kept = cnt;
         int tk;
         const int base = lane_prefix3(kept, lane, tk);
-        if (total > room && lane == 0) {             // counted, never silent (snk_contact_overflow)
-            atomicAdd(ovf, 1ull);
-            atomicAdd(ovf + 1, (unsigned long long)(total - tk));
-        }
         if (lane < 2 * N) {
             L.cylbase[c] = (unsigned char)base;
             L.cyln[c] = (unsigned char)kept;
@@ -549,9 +553,8 @@ __device__ int find_contacts_v2(LT& L, const DevModel& M, int lane, unsigned lon
     unsigned long long bal = __ballot(active);
     const int room = 4 * N - n_ob;                   // the solve's contact slots, less the box's contacts
     if (__popcll(bal) > room) {                      // (only with an obstacle: two points per cylinder are 4 N at most)
-        if (lane == 0) { atomicAdd(ovf, 1ull); atomicAdd(ovf + 1, (unsigned long long)(__popcll(bal) - room)); }
-        active = active && __popcll(bal & ((1ull << lane) - 1ull)) < room;      // the last in slot order go
-        bal = __ballot(active);
+        if (lane == 0) atomicAdd(ovf, 1ull);         // over to the streamed-row solve, as above
+        return -1;
     }
     const int np_ = __popcll(bal);
     if (active) {
@@ -1299,6 +1302,7 @@ __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane_in
     // (1) contacts of the current pose, (2) bias forces with gravity, joint damping torque
     const int nc = __builtin_amdgcn_readfirstlane(find_contacts_v2(L, M, lane, ovf));
     ncontacts = nc;
+    if (nc < 0) return;            // does not fit this solve: nothing has been touched, the caller hands the env-step over
     SNK_STAMP(1)
     if (lane < N) {
         float qd = L.qd()[lane];

@@ -513,27 +513,17 @@ def test_sensor_pass_only_when_observable(pkg, n):
         # replay with the substep API: group envs by their substep count
         T = np.zeros((B, n), np.float32)
         T[:, 1::2] = np.clip(a, -1, 1) * np.float32(np.pi / 6)
-        rp.set_state(S, X)
-        if Mf is not None:
-            rp.set_manifold(Mf)
-        left = sub.copy()
-        # advance all envs together; an env that is finished is restored afterwards (it must not move)
-        final = {}
-        for k in range(int(sub.max())):
-            Sb, Xb = rp.get_state()
-            Mb = rp.get_manifold()
-            rp.substep(T, 1)
-            Sa, Xa = rp.get_state()
-            stop = left <= 0
-            if stop.any():
-                Sa[stop], Xa[stop] = Sb[stop], Xb[stop]
-                rp.set_state(Sa, Xa)
-                if Mb is not None:
-                    Ma = rp.get_manifold()
-                    Ma[stop] = Mb[stop]
-                    rp.set_manifold(Ma)
-            left -= 1
-        _, Xf = rp.get_state()
+        # Replay: every env with ONE call of as many substeps as its env-step took -- like the fused kernel, the
+        # substep call hands an env whose contacts outgrow the register-resident solve's 64 slots over to the
+        # streamed-row kernels for the REST of the call, so the two take the same path substep for substep
+        Xf = X.copy()
+        for c in np.unique(sub[sub > 0]):
+            rp.set_state(S, X)
+            if Mf is not None:
+                rp.set_manifold(Mf)
+            rp.substep(T, int(c))
+            Xc = rp.get_state()[1]
+            Xf[sub == c] = Xc[sub == c]
         moved = sub > 0
         assert moved.sum() > B // 2
         assert np.array_equal(obs[moved, 3 * n + 7], Xf[moved, n]), np.abs(obs[moved, 3 * n + 7] - Xf[moved, n]).max()
