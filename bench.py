@@ -312,7 +312,9 @@ def main():
     elapsed = float(t_el.item())
     substeps = float(subs.item())
 
-    overflow = local.stepper.contact_overflow()      # contacts the solve had no room for: must be zeros
+    # [0] substeps that went through the streamed-row solve because their contacts outgrew the register-resident one's
+    # slots (16 links), [1] [2] contacts left without rows: must be zeros
+    overflow = local.stepper.contact_overflow()
     # Not the headline: the same K steps under the round-1 contact model (stateless two-point manifold on implicit
     # cylinders), after and outside the timed region of the headline, so that the record stays comparable
     # with the earlier rounds' numbers.
@@ -403,7 +405,8 @@ def main():
                 "hull_sides": args.hull_sides, "contact_model": args.contact_model,
                 "relative_breaking_threshold": int(local.params.relative_breaking_threshold),
                 "warm_start": int(local.params.warm_start),
-                "contact_overflow": {"substeps": overflow[0], "points": overflow[1], "link_link_or_obstacle": overflow[2]},
+                "contact_overflow": {"substeps_on_streamed_rows": overflow[0], "points_without_rows": overflow[1],
+                                     "link_link_or_obstacle_without_rows": overflow[2]},
                 "self_collision": args.self_collision if NL == 32 else "flag on, inert and not evaluated for 16 links",
                 "world_size": (dist.get_world_size() if dist is not None else 1),
                 "backend": (dist.get_backend() if dist is not None else None),

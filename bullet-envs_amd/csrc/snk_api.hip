@@ -55,13 +55,6 @@ struct snk_handle {
     float* d_rows = nullptr;      // 32-link chains: constraint rows streamed from global memory (snk_device.hpp: pgs_v1)
     unsigned long long* d_ovf = nullptr;   // contacts the solves had no room for (snk_contact_overflow): 3 counters
     float* d_box = nullptr;       // obstacle 2: the free box of every env, [n_envs][kBoxFloats] (state 13, count, manifold 24)
-    // register-resident handles: envs whose contacts outgrow the 64 slots are finished by the streamed-row kernels of
-    // the same chain (snk_device.hpp: struct Over) -- the list, its length, and that kernel's row blocks / launch size
-    int32_t* d_over_list = nullptr;
-    int32_t* d_over_n = nullptr;
-    float* d_over_rows = nullptr;
-    int over_blocks = 0;
-    size_t over_lds = 0;
     int32_t* d_order = nullptr;
     bool plan = true;
     // in-launch scheduler of env_step_sched_kernel (snk_device.hpp): rings, counters, the host-mapped alarm word
@@ -78,57 +71,30 @@ struct snk_handle {
 
 namespace {
 
-// the streamed-row kernel over the envs a register-resident kernel handed over (struct Over); their substep counters
-// sit in the scheduler's per-env counter array
-template <int N>
-void launch_over_step(snk_handle* h, float* act, float* obs, float* rew, uint8_t* done, int32_t* sub, int vec_mode,
-                      hipStream_t st) {
-    snk::Over resume, none;
-    resume.list = h->d_over_list; resume.count = h->d_over_n; resume.counters = h->sched.counter;
-    none.list = nullptr; none.count = nullptr; none.counters = nullptr;
-    hipLaunchKernelGGL((snk::env_step_kernel<N, false>), dim3(h->over_blocks), dim3(64), h->over_lds, st, h->d_model, h->d_recs,
-                       h->d_mu, act, obs, rew, done, sub, vec_mode, h->n_envs, (const int32_t*)nullptr, h->d_over_rows, h->d_mf,
-                       h->d_ovf, h->d_box, resume, none);
-}
 template <int N, bool V2>
 int launch_step(snk_handle* h, float* act, float* obs, float* rew, uint8_t* done, int32_t* sub, int vec_mode,
                 hipStream_t st) {
-    snk::Over none, over;
-    none.list = nullptr; none.count = nullptr; none.counters = nullptr;
-    over.list = h->d_over_list; over.count = h->d_over_n; over.counters = h->sched.counter;
-    if (V2 && !h->use_sched) (void)hipMemsetAsync(h->d_over_n, 0, sizeof(int32_t), st);
     if (h->use_sched) {
         hipLaunchKernelGGL((snk::plan_sched_kernel<N>), dim3(1), dim3(1024), 0, st, h->d_model, h->d_recs, act, h->sched,
-                           h->n_envs, V2 ? h->d_over_n : (int32_t*)nullptr);
+                           h->n_envs);
         snk::StepArgs a;
         a.recs = h->d_recs; a.mu_plane = h->d_mu; a.actions = act; a.obs = obs; a.rew = rew; a.done = done; a.substeps = sub;
         a.rows_all = h->d_rows; a.mf_all = h->d_mf; a.ovf = h->d_ovf; a.box_all = h->d_box; a.sc = h->sched;
-        a.over = over;
         a.model_slot = h->model_slot; a.vec_mode = vec_mode; a.n_envs = h->n_envs; a.pad_ = 0;
         hipLaunchKernelGGL((snk::env_step_sched_kernel<N, V2>), dim3(h->grid_waves), dim3(64), h->lds_bytes, st, a);
-        if constexpr (V2) launch_over_step<N>(h, act, obs, rew, done, sub, vec_mode, st);
         return 0;
     }
     if (h->plan)
         hipLaunchKernelGGL((snk::plan_kernel<N>), dim3(1), dim3(1024), 0, st, h->d_model, h->d_recs, act, h->d_order,
                            h->n_envs);
     hipLaunchKernelGGL((snk::env_step_kernel<N, V2>), dim3(h->grid_waves), dim3(64), h->lds_bytes, st, h->d_model, h->d_recs,
-                       h->d_mu, act, obs, rew, done, sub, vec_mode, h->n_envs, h->plan ? h->d_order : nullptr, h->d_rows, h->d_mf, h->d_ovf, h->d_box,
-                       none, over);
-    if constexpr (V2) launch_over_step<N>(h, act, obs, rew, done, sub, vec_mode, st);
+                       h->d_mu, act, obs, rew, done, sub, vec_mode, h->n_envs, h->plan ? h->d_order : nullptr, h->d_rows, h->d_mf, h->d_ovf, h->d_box);
     return 0;
 }
 template <int N, bool V2>
 int launch_substep(snk_handle* h, const float* tgt, int k, int32_t* info, hipStream_t st) {
-    snk::Over none, over;
-    none.list = nullptr; none.count = nullptr; none.counters = nullptr;
-    over.list = h->d_over_list; over.count = h->d_over_n; over.counters = h->sched.counter;
-    if (V2) (void)hipMemsetAsync(h->d_over_n, 0, sizeof(int32_t), st);
     hipLaunchKernelGGL((snk::substep_kernel<N, V2>), dim3(h->grid_waves), dim3(64), h->lds_bytes, st, h->d_model, h->d_recs,
-                       h->d_mu, tgt, k, info, h->n_envs, h->d_rows, h->d_mf, h->d_ovf, h->d_box, none, over);
-    if constexpr (V2)       // the substeps of the envs whose contacts outgrew the 64 slots, from where they were handed over
-        hipLaunchKernelGGL((snk::substep_kernel<N, false>), dim3(h->over_blocks), dim3(64), h->over_lds, st, h->d_model, h->d_recs,
-                           h->d_mu, tgt, k, info, h->n_envs, h->d_over_rows, h->d_mf, h->d_ovf, h->d_box, over, none);
+                       h->d_mu, tgt, k, info, h->n_envs, h->d_rows, h->d_mf, h->d_ovf, h->d_box);
     return 0;
 }
 template <int N, bool V2>
@@ -321,7 +287,9 @@ int init_handle(snk_handle* h, const snk_params* p, int32_t n_envs, int32_t devi
         if (rc) return rc;
         h->grid_waves = waves > 0 && waves < n_envs ? waves : n_envs;
     }
-    if (!h->v2) {
+    {
+        // (16-link handles on the register-resident solve need them too: a substep whose contacts outgrow its 64 slots
+        //  goes through the streamed-row solve in place, snk_device.hpp: substep())
         // one block of streamed constraint rows per RESIDENT WAVE (every step / substep kernel is launched with that many
         // workgroups and strides over the environments): 2048 x 112 KB = 230 MB for 32 links, whatever n_envs is
         const size_t rf = h->n == 32 ? snk::Lds<32, false>::kRowFloats : snk::Lds<16, false>::kRowFloats;
@@ -341,19 +309,6 @@ int init_handle(snk_handle* h, const snk_params* p, int32_t n_envs, int32_t devi
                 HIP_TRY(hipMemsetAsync(h->d_rows + e * rf + z0, 0, zn * sizeof(float), nullptr));
                 HIP_TRY(hipMemsetAsync(h->d_rows + e * rf + m0, 0, (m1 - m0) * sizeof(float), nullptr));
             }
-    }
-    if (h->v2) {
-        // the streamed-row kernels of this chain stand behind the register-resident ones (struct Over)
-        rc = set_lds_attr<16, false>(sizeof(snk::Lds<16, false>));
-        if (rc) return rc;
-        h->over_lds = sizeof(snk::Lds<16, false>);
-        h->over_blocks = h->grid_waves < 256 ? h->grid_waves : 256;
-        HIP_TRY(hipMalloc(&h->d_over_list, ne * sizeof(int32_t)));
-        HIP_TRY(hipMalloc(&h->d_over_n, sizeof(int32_t)));
-        HIP_TRY(hipMemset(h->d_over_n, 0, sizeof(int32_t)));
-        const size_t rf = snk::Lds<16, false>::kRowFloats, bytes = (size_t)h->over_blocks * rf * sizeof(float);
-        HIP_TRY(hipMalloc(&h->d_over_rows, bytes));
-        HIP_TRY(hipMemset(h->d_over_rows, 0, bytes));       // (what must stay zero in a row block: see d_rows below)
     }
     if (p->obstacle == 2) {
         // the free box where loadURDF puts it (snake.py:84, snake_gait_test.py:51): at rest, identity orientation,
@@ -458,7 +413,7 @@ int snk_destroy(snk_handle* h) {
     (void)hipDeviceSynchronize();
     void* bufs[] = {h->d_model, h->d_recs, h->d_mu, h->d_act, h->d_obs, h->d_rew, h->d_done,
                     h->d_sub, h->d_mask, h->d_tgt, h->d_info, h->d_h, h->d_order, h->d_rows, h->d_linkpos, h->d_mf, h->d_ovf, h->d_box,
-                    h->d_over_list, h->d_over_n, h->d_over_rows,
+
                     h->sched.head, h->sched.tail, h->sched.ent, h->sched.waiting, h->sched.counter, h->sched.finished};
     for (void* b : bufs) (void)hipFree(b);
     if (h->h_alarm) (void)hipHostFree(h->h_alarm);

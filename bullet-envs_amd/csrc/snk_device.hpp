@@ -135,6 +135,14 @@ __device__ __forceinline__ float cols_max(float x) {
 }
 // the lane's index within its wave (= threadIdx.x of the one-wave workgroups here), recomputed instead of kept
 __device__ __forceinline__ int lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+// The lane index as a value the compiler cannot see through: per-lane addresses built from it are computed where they
+// are used.  (Built from the kernel's own threadIdx.x they are loop-invariant, get hoisted in front of the servo loop and
+// stay live across it -- twenty VGPRs in round 3's first build, which the solve's row registers then paid for with
+// reloads from scratch memory inside the Gauss-Seidel loop.)
+__device__ __forceinline__ int launder_lane(int lane) {
+    asm volatile("" : "+v"(lane));
+    return lane;
+}
 __device__ __forceinline__ float lane_bcast(float x, int src_lane_uniform) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), src_lane_uniform));
 }
@@ -808,7 +816,7 @@ __device__ void build_rows_v1(LT& L, const DevModel& M, int lane, int nc, int& n
     }
     // the free box (obstacle 2): a second multibody, block-diagonal in M^-1 -- rows ND .. ND + 5: the world inverse
     // inertia for its angular components, 1 / m for its linear ones
-    const bool fbox = M.obstacle == 2;
+    const bool fbox = N <= 16 && M.obstacle == 2;         // (built for the 16-link chain only: snk_create)
     const bool boxlane = fbox && lane >= ND && lane < ND + 6;
     if (boxlane) {
         const int i = lane - ND;
@@ -1187,7 +1195,7 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
     constexpr int ND = N + 6;
     static_assert(ND <= 64, "this solve is laid out for one row per 64-lane register");
     constexpr int kSpec = LT::kSpec;
-    const bool act = lane < ND + (M.obstacle == 2 ? 6 : 0);      // (the free box's six components sit behind the snake's)
+    const bool act = lane < ND + ((N <= 16 && M.obstacle == 2) ? 6 : 0);      // (the free box's six components sit behind the snake's)
     const int nlim = nn - N;                       // violated joint limits come first in the non-contact list
     // model fields used inside the loops, read once (the model lives in global memory)
     // (v_readfirstlane: the loads go through vector memory, the values must be scalar for the
@@ -1457,7 +1465,7 @@ __device__ void substep_v1(LT& L, const DevModel& M, int lane, float mu, int& it
     unsigned long long prof_t[10];
 #endif
     SNK_STAMP(0)
-    const bool fbox = M.obstacle == 2;         // the obstacle as a free body: six more velocity components (lanes ND ..)
+    const bool fbox = N <= 16 && M.obstacle == 2;         // the obstacle as a free body (16-link chain only): six more velocity components (lanes ND ..)
     if (fbox) box_frame_v1(L, M, lane);
     // (1) contacts of the current pose, (2) bias forces with gravity, joint damping torque
     int nc = find_contacts_v1(L, M, lane, rows, mf, ovf);
@@ -1727,21 +1735,33 @@ __device__ __forceinline__ void substep(LT& L, const DevModel& M0, int lane_in, 
     // ... and the lane id: hundreds of per-lane LDS addresses are loop-invariant and would
     // otherwise be computed in the kernel prologue and spilled.
     asm volatile("" : "+v"(lane));
-    if constexpr (LT::kV2) substep_v2(L, M, lane, mu, iters, ncontacts, hint, ovf);
-    else substep_v1(L, M, lane, mu, iters, ncontacts, rows, hint, mf, ovf);
+    if constexpr (LT::kV2) {
+        substep_v2(L, M, lane, mu, iters, ncontacts, hint, ovf);
+        if (ncontacts < 0) {
+            // The contacts of this pose do not fit the register-resident solve's 64 slots (a snake at rest gathers up to
+            // four points per cylinder: 128; Bullet has no limit).  Nothing has been touched yet: THIS substep goes through
+            // the streamed-row solve of the same chain instead (128 + 32 slots: every point a 16-link snake's manifolds
+            // can hold), in place -- the two LDS images share their first members (record, poses, ABA workspace), the
+            // contact cache travels through its block of global memory, where the streamed-row kernels keep it.  The
+            // rule is per substep and a function of the state alone, so results do not depend on the schedule, and the
+            // single-substep API takes the same path.  Counted (snk_contact_overflow[0]), never silent.
+            using L1 = Lds<LT::kN, false>;
+            static_assert(sizeof(L1) <= sizeof(LT), "the streamed-row image must fit the register-resident one's allocation");
+            L1& Lx = *reinterpret_cast<L1*>(&L);
+            store_mf<LT, true>(L, mf, lane);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            substep_v1(Lx, M, launder_lane(lane), mu, iters, ncontacts, rows, hint, mf, ovf);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            load_mf(L, mf, lane);
+        }
+    } else {
+        substep_v1(L, M, lane, mu, iters, ncontacts, rows, hint, mf, ovf);
+    }
 }
 
 // ----------------------------------------------------------------------------------
 // record <-> LDS, observation packing (snake.py:209-217)
 // ----------------------------------------------------------------------------------
-// The lane index as a value the compiler cannot see through: per-lane addresses built from it are computed where they
-// are used.  (Built from the kernel's own threadIdx.x they are loop-invariant, get hoisted in front of the servo loop and
-// stay live across it -- twenty VGPRs in round 3's first build, which the solve's row registers then paid for with
-// reloads from scratch memory inside the Gauss-Seidel loop.)
-__device__ __forceinline__ int launder_lane(int lane) {
-    asm volatile("" : "+v"(lane));
-    return lane;
-}
 template <class LT>
 __device__ __forceinline__ void load_rec(LT& L, const float* __restrict__ rec, int lane) {
     constexpr int N = LT::kN;
@@ -1861,23 +1881,6 @@ __device__ __forceinline__ void soft_reset(LT& L, int lane) {
     for (int i = lane; i < 13 + 2 * N; i += 64) L.rec[i] = (i == 6) ? 1.0f : 0.0f;
 }
 
-// Environments whose contacts do not fit the register-resident solve's 64 slots in some substep (find_contacts_v2) are
-// taken over, from that substep on, by the streamed-row kernels of the same chain (128 + 32 slots: every point a
-// 16-link snake's manifolds can hold): the register-resident kernel stores the untouched state, the substeps done so
-// far (counters) and appends the env to this list; the host launches the streamed-row kernel over the list right
-// behind it (snk_api.hip).  list == nullptr: no hand-over (the streamed-row kernels themselves).
-struct Over {
-    int32_t* list;
-    int32_t* count;
-    int32_t* counters;      // [n_envs]: substeps of the current env-step (or of the current snk_substep_host call) done so far
-};
-__device__ __forceinline__ void over_push(const Over& ov, int lane, int env, int counter) {
-    if (lane == 0) {
-        ov.counters[env] = counter;
-        ov.list[atomicAdd(ov.count, 1)] = env;
-    }
-}
-
 // ----------------------------------------------------------------------------------
 // kernels
 // ----------------------------------------------------------------------------------
@@ -1889,18 +1892,15 @@ __global__ __launch_bounds__(64, 2) void env_step_kernel(const DevModel* __restr
                                                       int32_t* __restrict__ substeps, int vec_mode, int n_envs,
                                                       const int32_t* __restrict__ order, float* __restrict__ rows_all,
                                                       float* __restrict__ mf_all, unsigned long long* __restrict__ ovf,
-                                                      float* __restrict__ box_all, Over resume, Over over) {
+                                                      float* __restrict__ box_all) {
     extern __shared__ float4 smem_raw[];
     using LT = Lds<N, V2>;
     LT& L = *reinterpret_cast<LT*>(smem_raw);
     const DevModel& M = *Mp;
     // longest-first schedule: workgroup b takes the envs with the b-th, (b + G)-th, ... largest predicted work (G
-    // workgroups: as many as the chip holds at once; the block of streamed constraint rows belongs to the WORKGROUP).
-    // resume.list: only the env-steps another kernel handed over (struct Over), continued from resume.counters
-    const int n_items = resume.list ? __builtin_amdgcn_readfirstlane(*resume.count) : n_envs;
-    for (int slot_ = blockIdx.x; slot_ < n_items; slot_ += gridDim.x) {
-    const int env = resume.list ? __builtin_amdgcn_readfirstlane(resume.list[slot_])
-                                : (order ? __builtin_amdgcn_readfirstlane(order[slot_]) : slot_);
+    // workgroups: as many as the chip holds at once; the block of streamed constraint rows belongs to the WORKGROUP)
+    for (int slot_ = blockIdx.x; slot_ < n_envs; slot_ += gridDim.x) {
+    const int env = order ? __builtin_amdgcn_readfirstlane(order[slot_]) : slot_;
     const int lane = threadIdx.x;
     if (M.poison) { L.poison(lane); lds_sync(); }
     load_rec(L, recs + (size_t)env * LT::REC, lane);
@@ -1922,16 +1922,17 @@ __global__ __launch_bounds__(64, 2) void env_step_kernel(const DevModel* __restr
     }
     lds_sync();
     float mu = fminf(M.mu_link * mu_plane[env], 10.0f);
-    float* env_rows = nullptr;      // constraint rows of chains too long for the register-resident solve
-    if constexpr (!LT::kV2) env_rows = rows_all + (size_t)blockIdx.x * LT::kRowFloats;
+    // constraint rows of the streamed-row solve (also behind the register-resident one, for the substeps whose contacts
+    // outgrow its slots: substep())
+    float* env_rows = rows_all + (size_t)blockIdx.x * Lds<N, false>::kRowFloats;
     float* env_mf = mf_all ? mf_all + (size_t)env * (2 * N * kMfFloats) : nullptr;   // contact cache (contact_model 1)
     load_mf(L, env_mf, lane);
     float* env_box = box_all ? box_all + (size_t)env * kBoxFloats : nullptr;
     load_box(L, env_box, lane);
     fk_vel(L, M, lane);
     // Snake.step servo loop (snake.py:283-304)
-    int counter = resume.list ? __builtin_amdgcn_readfirstlane(resume.counters[env]) : 0;
-    bool end_height = false, handed_over = false;
+    int counter = 0;
+    bool end_height = false;
     int it_dummy = 0, nc_dummy = 0;
     SensorHint hint;
     hint.always = false;
@@ -1942,19 +1943,10 @@ __global__ __launch_bounds__(64, 2) void env_step_kernel(const DevModel* __restr
         if (!(nrm > M.servo_tol)) break;
         hint.counter_next = counter + 1;
         substep(L, M, lane, mu, it_dummy, nc_dummy, hint, env_rows, env_mf, ovf);
-        if (nc_dummy < 0) { handed_over = true; break; }      // (register-resident solve only: struct Over)
         counter++;
         hint.h_prev = mean_height(L, M, lane);
         if (hint.h_prev > M.height_thr) { end_height = true; break; }
         if (counter > M.max_counter) break;
-    }
-    if (handed_over) {
-        // the state as the refused substep found it goes back to memory; the streamed-row kernel carries on from there
-        store_rec(L, recs + (size_t)env * LT::REC, lane);
-        store_mf<LT, false>(L, env_mf, lane);
-        over_push(over, lane, env, counter);
-        lds_sync();
-        continue;
     }
     // SnakeGymEnv.step (SnakeGymEnv.py:36-42)
     float en = (lane < N) ? L.qd()[lane] * L.taum()[lane] * M.energy_dt : 0.f;   // snake.py:336-341
@@ -1995,15 +1987,13 @@ __global__ __launch_bounds__(64, 2) void substep_kernel(const DevModel* __restri
                                                      const float* __restrict__ targets, int k,
                                                      int32_t* __restrict__ info, int n_envs, float* __restrict__ rows_all,
                                                      float* __restrict__ mf_all, unsigned long long* __restrict__ ovf,
-                                                     float* __restrict__ box_all, Over resume, Over over) {
+                                                     float* __restrict__ box_all) {
     extern __shared__ float4 smem_raw[];
     using LT = Lds<N, V2>;
     LT& L = *reinterpret_cast<LT*>(smem_raw);
     const DevModel& M = *Mp;
     const int lane = threadIdx.x;
-    const int n_items = resume.list ? __builtin_amdgcn_readfirstlane(*resume.count) : n_envs;
-    for (int slot_ = blockIdx.x; slot_ < n_items; slot_ += gridDim.x) {      // (the block of streamed rows belongs to the workgroup)
-    const int env = resume.list ? __builtin_amdgcn_readfirstlane(resume.list[slot_]) : slot_;
+    for (int env = blockIdx.x; env < n_envs; env += gridDim.x) {      // (the block of streamed rows belongs to the workgroup)
     if (M.poison) { L.poison(lane); lds_sync(); }
     load_rec(L, recs + (size_t)env * LT::REC, lane);
     if (lane < N) L.targets[lane] = targets[(size_t)env * N + lane];
@@ -2013,18 +2003,13 @@ __global__ __launch_bounds__(64, 2) void substep_kernel(const DevModel* __restri
     int iters = 0, nc = 0;
     SensorHint hint;
     hint.always = true; hint.counter_next = 0; hint.h_prev = 0.f;
-    float* env_rows = nullptr;
-    if constexpr (!LT::kV2) env_rows = rows_all + (size_t)blockIdx.x * LT::kRowFloats;
+    float* env_rows = rows_all + (size_t)blockIdx.x * Lds<N, false>::kRowFloats;
     float* env_mf = mf_all ? mf_all + (size_t)env * (2 * N * kMfFloats) : nullptr;
     load_mf(L, env_mf, lane);
     float* env_box = box_all ? box_all + (size_t)env * kBoxFloats : nullptr;
     load_box(L, env_box, lane);
-    // (resume: the substeps of this call the register-resident kernel had done before it handed the env over)
-    for (int s = resume.list ? __builtin_amdgcn_readfirstlane(resume.counters[env]) : 0; s < k; s++) {
-        substep(L, M, lane, mu, iters, nc, hint, env_rows, env_mf, ovf);
-        if (nc < 0) { over_push(over, lane, env, s); break; }          // (register-resident solve only: struct Over)
-    }
-    if (info && lane == 0 && nc >= 0) { info[2 * env] = iters; info[2 * env + 1] = nc; }
+    for (int s = 0; s < k; s++) substep(L, M, lane, mu, iters, nc, hint, env_rows, env_mf, ovf);
+    if (info && lane == 0) { info[2 * env] = iters; info[2 * env + 1] = nc; }
     store_rec(L, recs + (size_t)env * LT::REC, lane);
     store_mf<LT, false>(L, env_mf, lane);
     store_box<LT, false>(L, env_box, lane);
@@ -2291,8 +2276,7 @@ __device__ __forceinline__ void sched_push(const Sched& sc, int lane, int env, i
 // One block: the queue of a launch, env-steps with the most predicted substeps first (counting sort).
 template <int N>
 __global__ __launch_bounds__(1024) void plan_sched_kernel(const DevModel* __restrict__ Mp, const float* __restrict__ recs,
-                                                          const float* __restrict__ actions, Sched sc, int n_envs,
-                                                          int32_t* __restrict__ over_count) {
+                                                          const float* __restrict__ actions, Sched sc, int n_envs) {
     constexpr int REC = (N <= 16) ? 64 : 128;
     __shared__ uint32_t hist[kBuckets], base[kBuckets];
     const DevModel& M = *Mp;
@@ -2328,7 +2312,6 @@ __global__ __launch_bounds__(1024) void plan_sched_kernel(const DevModel* __rest
         for (int b = kBuckets - 1; b >= 0; b--) { base[b] = run; run += hist[b]; }
         *sc.tail = run;
         *sc.finished = 0;
-        if (over_count) *over_count = 0;        // the list of env-steps handed over to the streamed-row kernel (struct Over)
     }
     if (tid < kBuckets) sc.waiting[tid] = (int32_t)hist[tid];
     __syncthreads();
@@ -2363,7 +2346,6 @@ struct StepArgs {
     float* mf_all;
     unsigned long long* ovf;
     float* box_all;
-    Over over;
     Sched sc;
     int32_t model_slot, vec_mode, n_envs, pad_;
 };
@@ -2488,22 +2470,11 @@ __global__ __launch_bounds__(64, 2) void env_step_sched_kernel(StepArgs args_by_
             }
             hint.counter_next = counter + 1;
             {
-                float* env_rows = nullptr;      // constraint rows of chains too long for the register-resident solve:
-                if constexpr (!LT::kV2) env_rows = aq->rows_all + (size_t)blockIdx.x * LT::kRowFloats;   // one block per resident wave
+                // constraint rows of the streamed-row solve, one block per resident wave (also behind the register-resident
+                // solve, for the substeps whose contacts outgrow its slots: substep())
+                float* env_rows = aq->rows_all + (size_t)blockIdx.x * Lds<N, false>::kRowFloats;
                 substep(L, M, lane, mu, it_dummy, nc_dummy, hint, env_rows, env_mf(aq), aq->ovf);
                 lane = lane_id();       // (not kept in a register across the solve)
-            }
-            if (nc_dummy < 0) {
-                // the contacts do not fit this solve (struct Over): the untouched state goes back to memory, the
-                // streamed-row kernel behind this launch finishes the env-step; for this launch's queue it is done
-                const StepArgPtr ao = step_args();
-                store_rec(L, ao->recs + (size_t)env * LT::REC, lane);
-                store_mf<LT, false>(L, env_mf(ao), lane);
-                Over ov;
-                ov.list = ao->over.list; ov.count = ao->over.count; ov.counters = ao->sc.counter;
-                over_push(ov, lane, env, counter);
-                atomicAdd(ao->sc.finished, lane == 0 ? 1 : 0);
-                break;
             }
 #ifdef SNK_SCHED_DEBUG
             n_sub++;

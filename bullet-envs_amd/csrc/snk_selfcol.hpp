@@ -273,7 +273,7 @@ __device__ int find_self_contacts_v1(LT& L, const DevModel& M, int lane, float m
         Bx.c = mk3(M.obs_c[0], M.obs_c[1], M.obs_c[2]);
 #pragma unroll
         for (int i = 0; i < 9; i++) Bx.R[i] = (i % 4 == 0) ? 1.f : 0.f;
-        if (M.obstacle == 2) {         // the free box: where it is now (LDS: Lds<N, false>::box, bR)
+        if (N <= 16 && M.obstacle == 2) {         // the free box: where it is now (LDS: Lds<N, false>::box, bR)
             Bx.c = ld3(L.box);
 #pragma unroll
             for (int i = 0; i < 9; i++) Bx.R[i] = L.bR[i];
@@ -403,7 +403,7 @@ __device__ int find_self_contacts_v1(LT& L, const DevModel& M, int lane, float m
             st3(geo + 10, ob_n);
             st3(geo + 13, ob_PB);
             geo[16] = (float)((a + 1) >> 1);
-            geo[17] = M.obstacle == 2 ? (float)LT::kBoxBody : -1.0f;      // a free box is the contact's second body
+            geo[17] = (N <= 16 && M.obstacle == 2) ? (float)LT::kBoxBody : -1.0f;      // a free box is the contact's second body
             geo[18] = rho_ob;
             geo[19] = 0.f;
         }

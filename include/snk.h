@@ -190,12 +190,15 @@ int snk_joint3_reaction_fz(snk_handle* h, float* out);
 int snk_get_box(snk_handle* h, float* state, float* manifold);
 int snk_set_box(snk_handle* h, const float* state, const float* manifold);
 
-/* Contacts the solves had no room for, counted on the device since snk_create (Bullet has no such limit; these
- * counters say when this build's structural limits were hit -- DESIGN.md 3):
- *   out[0] physics substeps in which an environment held more ground-contact points than the solve has slots for
- *          (4n; 4n minus the obstacle's contacts for a 16-link handle with an obstacle),
- *   out[1] the manifold points that got no rows in those substeps (the shallowest of their cylinders go first, every
- *          cylinder keeps its deepest point before any keeps a second, and so on),
+/* Where this build's structural limits were met, counted on the device since snk_create (Bullet has no such limits;
+ * DESIGN.md 3):
+ *   out[0] 16-link handles on the register-resident solve: physics substeps in which an environment held more contact
+ *          points than that solve's 64 slots (a snake at rest gathers up to four per cylinder).  Those substeps are
+ *          solved by the streamed-row solve of the same chain instead, in the same launch, with every point -- a
+ *          count of slower substeps, not of lost contacts.  Streamed-row handles: substeps with more ground points
+ *          than slots (4n; 128 for 16 links), which a 2n-cylinder chain cannot reach,
+ *   out[1] manifold points that got no rows in the substeps counted by out[0] (streamed-row handles only; the
+ *          shallowest of their cylinders go first, every cylinder keeps its deepest point before any keeps a second),
  *   out[2] link-link / obstacle contacts beyond the room for them (32; 8 obstacle contacts on a register-resident
  *          16-link handle) -- obstacle contacts are kept before link-link ones.
  * Host buffer of 3. */

@@ -15,8 +15,8 @@ alike.
   oracle, written to gpurun_out/contact_models.json (DESIGN.md 3 quotes it); the device's overflow counters
   (snk_contact_overflow) must stay at zero over those rollouts;
 * beyond 64 contacts: a resting snake accumulates up to four points per cylinder (128 > the register-resident solve's
-  64 slots) -- from that substep on the environment is finished by the streamed-row kernels of the same chain, and the
-  results follow the UNCAPPED oracle (no contact is ever left without rows; the hand-overs are counted)."""
+  64 slots) -- such a substep goes through the streamed-row solve of the same chain, inside the same launch, and the
+  results follow the UNCAPPED oracle (no contact is ever left without rows; those substeps are counted)."""
 import json
 import os
 
@@ -327,11 +327,11 @@ def test_contact_model_error_bar(pkg, oracle_mod):
 
 def test_no_contact_is_left_without_rows(pkg, oracle_mod):
     """Bullet keeps every cached point and gives every one of them rows; the register-resident 16-link solve has 64
-    contact slots.  A snake left at rest under the default model gathers up to four points per cylinder (128): from the
-    substep in which the 65th appears the environment is finished by the streamed-row kernels of the same chain (128 +
-    32 slots), behind the same API call.  Checked substep by substep from synchronised states and caches against the
-    UNCAPPED oracle: all 128 contacts are there, and the device counts the hand-overs (snk_contact_overflow) without
-    ever leaving a point out."""
+    contact slots.  A snake left at rest under the default model gathers up to four points per cylinder (128): a
+    substep with more than 64 goes through the streamed-row solve of the same chain (128 + 32 slots) in place, in the
+    same launch.  Checked substep by substep from synchronised states and caches against the UNCAPPED oracle: all 128
+    contacts are there, and the device counts those substeps (snk_contact_overflow[0]) without ever leaving a point
+    out."""
     B, n = 4, 16
     st = pkg.Stepper(B, residual_threshold=0.0)
     st.reset()
@@ -361,7 +361,7 @@ def test_no_contact_is_left_without_rows(pkg, oracle_mod):
             compared += 1
             worst = max(worst, np.abs(G[i, :7] - ref[:7]).max(), np.abs(G[i, 13:13 + n] - ref[13:13 + n]).max())
     sub, pts, other = st.contact_overflow()
-    print("beyond 64 contacts: substeps", over, "handed over", sub, "most contacts", most,
+    print("beyond 64 contacts: substeps", over, "through the streamed-row solve", sub, "most contacts", most,
           "| worst one-substep difference", worst, "| flips", flips, "of", 150 * B)
     assert most > 4 * n and over > 0 and sub == over and pts == 0 and other == 0
     assert flips <= 150 * B // 10 and compared > 100 * B
@@ -370,9 +370,9 @@ def test_no_contact_is_left_without_rows(pkg, oracle_mod):
 
 
 def test_env_steps_beyond_64_contacts_match_the_oracle(pkg, oracle_mod, monkeypatch):
-    """The hand-over inside the fused env-step kernels (scheduled and unscheduled): small random actions keep the snake
+    """The same inside the fused env-step kernels (scheduled and unscheduled): small random actions keep the snake
     nearly at rest, its manifolds fill up past 64 points, and whole env-steps still match the uncapped oracle from
-    synchronised states; outputs do not depend on the schedule."""
+    synchronised states; outputs and the counters do not depend on the schedule."""
     B, n, J = 16, 16, 14
     rng = np.random.default_rng(5)
     acts = [(0.04 * rng.standard_normal((B, 8))).astype(np.float32) for _ in range(J)]
@@ -405,7 +405,7 @@ def test_env_steps_beyond_64_contacts_match_the_oracle(pkg, oracle_mod, monkeypa
                     worst = max(worst, np.abs(o[i, :16] - oo[:16]).max(), np.abs(o[i, 48:55] - oo[48:55]).max())
         outs[quantum] = (res, st.get_state(), st.get_manifold(), st.contact_overflow())
         if quantum == 1:
-            print("env-steps beyond 64 contacts: worst", worst, "| oracle-f32", cal, "| mismatches", mism, "hand-overs", st.contact_overflow(),
+            print("env-steps beyond 64 contacts: worst", worst, "| oracle-f32", cal, "| mismatches", mism, "counters", st.contact_overflow(),
                   "points cached at the end", st.get_manifold()[:, :, 0].sum(axis=1).max())
             assert st.contact_overflow()[0] > 0 and st.contact_overflow()[1] == 0
             assert st.get_manifold()[:, :, 0].sum(axis=1).max() > 64
@@ -415,3 +415,4 @@ def test_env_steps_beyond_64_contacts_match_the_oracle(pkg, oracle_mod, monkeypa
         for x, y in zip(a, b):
             assert np.array_equal(x, y)
     assert np.array_equal(outs[1][1][0], outs[0][1][0]) and np.array_equal(outs[1][2], outs[0][2])
+    assert tuple(outs[1][3]) == tuple(outs[0][3])
