@@ -1456,7 +1456,7 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
 // one physics substep
 // ----------------------------------------------------------------------------------
 template <class LT>
-__device__ void substep_v1(LT& L, const DevModel& M, int lane, float mu, int& iters, int& ncontacts, float* __restrict__ rows,
+__device__ __forceinline__ void substep_v1(LT& L, const DevModel& M, int lane, float mu, int& iters, int& ncontacts, float* __restrict__ rows,
                            const SensorHint& hint, float* __restrict__ mf, unsigned long long* __restrict__ ovf) {
     constexpr int N = LT::kN;
     constexpr int ND = N + 6;
@@ -1722,6 +1722,16 @@ __device__ void substep_v1(LT& L, const DevModel& M, int lane, float mu, int& it
 #include "snk_freebox.hpp"
 namespace snk {
 
+// One out-of-line copy of the streamed-row substep for the register-resident kernels' rare substeps (below): inlined
+// there it would double those kernels; the streamed-row kernels themselves inline it (as a called function its LDS
+// accesses go through flat addresses: -10 % on those kernels when the compiler chose that by itself, round 3).
+template <class LT>
+__device__ __noinline__ void substep_v1_call(LT& L, const DevModel& M, int lane, float mu, int& iters, int& ncontacts,
+                                             float* __restrict__ rows, const SensorHint& hint, float* __restrict__ mf,
+                                             unsigned long long* __restrict__ ovf) {
+    substep_v1(L, M, lane, mu, iters, ncontacts, rows, hint, mf, ovf);
+}
+
 template <class LT>
 __device__ __forceinline__ void substep(LT& L, const DevModel& M0, int lane_in, float mu, int& iters, int& ncontacts,
                                         const SensorHint& hint, float* __restrict__ rows, float* __restrict__ mf,
@@ -1750,7 +1760,7 @@ __device__ __forceinline__ void substep(LT& L, const DevModel& M0, int lane_in, 
             L1& Lx = *reinterpret_cast<L1*>(&L);
             store_mf<LT, true>(L, mf, lane);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            substep_v1(Lx, M, launder_lane(lane), mu, iters, ncontacts, rows, hint, mf, ovf);
+            substep_v1_call(Lx, M, launder_lane(lane), mu, iters, ncontacts, rows, hint, mf, ovf);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             load_mf(L, mf, lane);
         }
