@@ -405,7 +405,10 @@ __device__ __forceinline__ int find_obstacle_v2(LT& L, const DevModel& M, int la
     const f3 ca = ld3(L.o[ba]) + mulRv(L.R[ba], ld3(M.cyl_c[a]));
     const f3 d = ca - Bx.c;
     const float reach_ob = rb + rbox + M.break_thr;
-    const bool cand = lane < 2 * N && dot(d, d) <= reach_ob * reach_ob;
+    const f3 axa = mulRv(L.R[ba], mk3(M.cyl_R[a][2], M.cyl_R[a][5], M.cyl_R[a][8]));
+    // (the box's bounding sphere is 0.42 m wide: every cylinder of a snake in front of it passes that test; the face
+    //  normals of the box decide -- snk_selfcol.hpp)
+    const bool cand = lane < 2 * N && dot(d, d) <= reach_ob * reach_ob && cyl_box_may_touch(M, ca, axa, Bx.c, Bx.R, Bx.half);
     if (!__any(cand)) return 0;
     if (cand) {
         Cvx A;
@@ -494,8 +497,8 @@ __device__ int find_contacts_v2(LT& L, const DevModel& M, int lane, unsigned lon
         if (total > room) {
             // More points than this solve has slots for (a snake at rest gathers up to four per cylinder: 128).  Bullet
             // has no such limit, and neither has the streamed-row solve of this chain (128 + 32 slots): nothing has
-            // been written yet, the caller hands the environment over to it from this substep on (snk_api.hip: the
-            // overflow list).  Counted (snk_contact_overflow), never silent.
+            // been written yet, the caller runs THIS substep through that solve instead (snk_device.hpp: substep()).
+            // Counted (snk_contact_overflow), never silent.
             if (lane == 0) atomicAdd(ovf, 1ull);
             return -1;
         }
@@ -1311,7 +1314,7 @@ __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane_in
     // (1) contacts of the current pose, (2) bias forces with gravity, joint damping torque
     const int nc = __builtin_amdgcn_readfirstlane(find_contacts_v2(L, M, lane, ovf));
     ncontacts = nc;
-    if (nc < 0) return;            // does not fit this solve: nothing has been touched, the caller hands the env-step over
+    if (nc < 0) return;            // does not fit this solve: nothing has been touched (substep() takes the other one)
     SNK_STAMP(1)
     if (lane < N) {
         float qd = L.qd()[lane];

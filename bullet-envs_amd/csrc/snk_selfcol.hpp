@@ -223,6 +223,38 @@ __device__ __forceinline__ f3 aniso_scale(const DevModel& M, const float* Rw, f3
     return mulRv(Rw, mk3(l.x * M.aniso[0], l.y * M.aniso[1], l.z * M.aniso[2]));
 }
 
+// Separating-axis culls in front of the GJK (round 3).  A lower bound on the distance between the NOMINAL shapes along one
+// axis; a pair goes to the narrow phase only when that bound, less both margins, is within the breaking threshold -- the
+// narrow phase would reject every pair culled here (dist = GJK distance - 2 margins >= bound - 2 margins > threshold), so
+// the contact set is the oracle's, which has no such cull.  A 32-gon hull lies inside its cylinder.  (Under the relative
+// breaking threshold, 1.2 mm, the neighbours across one joint -- 15 to 29 mm apart -- never pass; their bounding spheres
+// always overlap, and 62 of them went through the GJK every substep: 12 % of the 32-link kernel.)
+__device__ __forceinline__ float cyl_extent(const DevModel& M, f3 axis, f3 u) {      // |u| = 1
+    const float c = dot(axis, u);
+    return M.cyl_hl * fabsf(c) + M.cyl_r * sqrtf(fmaxf(0.f, 1.0f - c * c));
+}
+__device__ __forceinline__ bool cyl_cyl_may_touch(const DevModel& M, f3 ca, f3 axa, f3 cb, f3 axb) {
+    const f3 d = ca - cb;
+    const float n2 = dot(d, d);
+    if (!(n2 > 1e-12f)) return true;
+    const float n = sqrtf(n2);
+    const f3 u = d * (1.0f / n);
+    const float bound = n - cyl_extent(M, axa, u) - cyl_extent(M, axb, u);
+    return bound - 2.0f * M.margin <= M.break_thr + 1e-5f;
+}
+// cylinder against the box (centre bc, rotation Rb row-major, half extents hb): the three face normals of the box
+__device__ __forceinline__ bool cyl_box_may_touch(const DevModel& M, f3 ca, f3 axa, f3 bc, const float* Rb, f3 hb) {
+    const f3 d = ca - bc;
+    float bound = -3.0e38f;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const f3 e = mk3(Rb[i], Rb[3 + i], Rb[6 + i]);          // column i: the box's axis i in the world
+        const float hi = i == 0 ? hb.x : (i == 1 ? hb.y : hb.z);
+        bound = fmaxf(bound, fabsf(dot(d, e)) - (hi - M.margin) - cyl_extent(M, axa, e));
+    }
+    return bound - 2.0f * M.margin <= M.break_thr + 1e-5f;
+}
+
 // Link-link contacts of the current pose, appended behind the ground contacts: geometry records at slots
 // NC .. NC + count - 1 of the environment's global block.  Returns their number (<= kMaxSelf).
 template <class LT>
@@ -256,6 +288,7 @@ __device__ int find_self_contacts_v1(LT& L, const DevModel& M, int lane, float m
     const int a = lane < NCYL ? lane : NCYL - 1;
     const int ba = (a + 1) >> 1;
     const f3 ca = ld3(L.o[ba]) + mulRv(L.R[ba], ld3(M.cyl_c[a]));
+    const f3 axa = mulRv(L.R[ba], mk3(M.cyl_R[a][2], M.cyl_R[a][5], M.cyl_R[a][8]));      // the cylinder's axis in the world
     // The obstacle box (static): lane = cylinder, one point per (cylinder, box) pair, normal from the box to the link,
     // friction mu_link x mu_obstacle, directions scaled by the link's anisotropy only.  Its records FOLLOW the link-link
     // ones (row order: ground, link-link, obstacle -- the oracle's), but the narrow phase runs first: when the room for
@@ -283,7 +316,7 @@ __device__ int find_self_contacts_v1(LT& L, const DevModel& M, int lane, float m
         const float rbox = sqrtf(dot(Bx.half, Bx.half));
         const f3 d = ca - Bx.c;
         const float reach_ob = rb + rbox + M.break_thr;
-        const bool cand = lane < NCYL && dot(d, d) <= reach_ob * reach_ob;
+        const bool cand = lane < NCYL && dot(d, d) <= reach_ob * reach_ob && cyl_box_may_touch(M, ca, axa, Bx.c, Bx.R, Bx.half);
         if (__any(cand)) {
             if (cand) {
                 Cvx A;
@@ -329,6 +362,13 @@ __device__ int find_self_contacts_v1(LT& L, const DevModel& M, int lane, float m
         if (valid) {
             const f3 d = ca - cb;
             cand = dot(d, d) <= reach * reach;
+        }
+        if (!__any(cand)) continue;
+        {
+            const f3 axb = mk3(__int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(axa.x))),
+                               __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(axa.y))),
+                               __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(axa.z))));
+            cand = cand && cyl_cyl_may_touch(M, ca, axa, cb, axb);
         }
         if (!__any(cand)) continue;
         bool hit = false;
