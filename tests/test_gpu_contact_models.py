@@ -416,3 +416,54 @@ def test_env_steps_beyond_64_contacts_match_the_oracle(pkg, oracle_mod, monkeypa
             assert np.array_equal(x, y)
     assert np.array_equal(outs[1][1][0], outs[0][1][0]) and np.array_equal(outs[1][2], outs[0][2])
     assert tuple(outs[1][3]) == tuple(outs[0][3])
+
+
+def test_thirty_two_links_at_rest_meet_their_cap_counted_and_like_the_oracle(pkg, oracle_mod):
+    """The one structural limit on ground contacts that is left: a 32-link handle has 128 slots for the up to 256 points
+    its 64 cylinders can cache.  The gait holds ~70; a snake rocked gently at rest goes to ~250.  Then a spread-aware rule
+    decides which points keep rows (per cylinder: the deepest, then the farthest from it, ...), the device counts the
+    substeps and the points without rows (snk_contact_overflow[0], [1]), the cache keeps every point, and the oracle
+    with max_contacts = 128 applies the same rule: one-substep parity from synchronised states and caches."""
+    B, n = 3, 32
+    st = pkg.Stepper(B, n_modules=n, residual_threshold=0.0)
+    st.reset()
+    T = np.zeros((B, n), np.float32)
+    T[:, 1::2] = 0.025 + 0.005 * np.arange(B)[:, None]
+    refs = [oracle_mod.OracleEnv(n_modules=n, residual_threshold=0.0, max_contacts=4 * n) for _ in range(B)]
+    ref32 = oracle_mod.OracleEnv(n_modules=n, residual_threshold=0.0, max_contacts=4 * n, f32=True)      # calibration
+    worst = cal = 0.0
+    flips = compared = 0
+    most = 0
+    for k in range(170):
+        # a slight rocking about the other joint axes: the cylinders roll by a vertex or two and keep the old vertices'
+        # points (within the 1.2-mm threshold) next to the new ones -- up to four per cylinder
+        T[:, 0::2] = 0.005 * np.sin(k / 8.0)
+        S, X = st.get_state()
+        Mf = st.get_manifold()
+        info = st.substep(T, 1)
+        G, _ = st.get_state()
+        Mg = st.get_manifold()
+        most = max(most, int(Mg[:, :, 0].sum(axis=1).max()))
+        assert int(info[:, 1].max()) <= 4 * n          # rows: never more than the slots
+        for i in range(B):
+            refs[i].sync(S[i], X[i], Mf[i])
+            refs[i].substep(T[i].astype(np.float64))
+            if refs[i].last_num_contacts != info[i, 1] or _manifold_mismatch(Mg[i], refs[i].get_manifold(), n):
+                flips += 1
+                continue
+            ref = refs[i].get_state()
+            compared += 1
+            worst = max(worst, np.abs(G[i, :7] - ref[:7]).max(), np.abs(G[i, 13:13 + n] - ref[13:13 + n]).max())
+            if k % 2 == 0:
+                ref32.sync(S[i], X[i], Mf[i])
+                ref32.substep(T[i].astype(np.float64))
+                if ref32.last_num_contacts == refs[i].last_num_contacts:
+                    r32 = ref32.get_state()
+                    cal = max(cal, np.abs(r32[:7] - ref[:7]).max(), np.abs(r32[13:13 + n] - ref[13:13 + n]).max())
+    sub, pts, other = st.contact_overflow()
+    print("32 links at rest: most cached points", most, "| substeps past the cap", sub, "points without rows", pts,
+          "| compared", compared, "flips", flips, "| worst one-substep difference", worst, "| oracle-f32", cal)
+    assert most > 4 * n and sub > 0 and pts > 0 and other == 0
+    assert flips <= 170 * B // 8 and compared > 100 * B
+    assert worst < max(1e-3, 3 * cal)      # (one substep of a 128-row, 32-link resting snake: float32 against float64)
+    st.close()
