@@ -1532,6 +1532,12 @@ __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane_in
             int exceeded = 0;
             int ncl = nc;
             asm volatile("" : "+s"(ncl));   // keeps the group-active compares from being hoisted and spilled
+            // ... and once more at the top of every iteration (no instruction, only a point where every row must be in a
+            // register): with the split in front of the loop alone two rows stayed in scratch memory and were reloaded
+            // in every iteration, behind a full s_waitcnt each, although twenty registers are unused inside the loop
+            // (tools/dbg/loop_spills.sh: 2 -> 0 scratch operations in the loop; 350.4 k -> 353.0 k env-steps/s).
+#pragma unroll
+            for (int s2 = 0; s2 < kSlots; s2++) asm volatile("" : "+v"(RJ[s2]), "+v"(RM[s2]));
             auto limit_rows = [&](bool fwd) {
                 for (int jj = 0; jj < nlim; jj++) {
                     const int idx = fwd ? jj : nlim - 1 - jj;
