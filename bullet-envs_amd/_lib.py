@@ -252,8 +252,9 @@ class Stepper:
     def contact_overflow(self):
         """snk_contact_overflow since the handle was created: (substeps with more contact points than the solve's slots
         -- on a register-resident 16-link handle those are solved by the streamed-row solve with every point, so this is
-        a count of slower substeps --, points left without rows, link-link / obstacle contacts left out).  The last two
-        at zero mean Bullet's 'no limit' held."""
+        a count of slower substeps --, points left without rows (structurally zero: the streamed-row solve has a slot for
+        every point the manifolds can hold), link-link / obstacle contacts left out).  The last two at zero mean Bullet's
+        'no limit' held."""
         out = (C.c_uint64 * 3)()
         check(self.lib.snk_contact_overflow(self.h, out), "snk_contact_overflow")
         return int(out[0]), int(out[1]), int(out[2])

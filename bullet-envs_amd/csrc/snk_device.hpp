@@ -214,7 +214,9 @@ struct Lds<N, false> : LdsCommon<N, 2 * N> {
     // 16-link chain every point its 32 cylinders' manifolds can hold (4 each) -- this solve is where an environment
     // goes whose contacts do not fit the register-resident solve's 64 slots (snk_api.hip: overflow list), so that no
     // 16-link contact is ever left without rows
-    static constexpr int NC = (N <= 16) ? 128 : 4 * N, NR = 3 * NC, ND = N + 6;
+    // contact slots: every point the 2N cylinders' manifolds can hold (4 each) -- Bullet has no limit, and neither has
+    // this solve for the ground contacts
+    static constexpr int NC = 8 * N, NR = 3 * NC, ND = N + 6;
     float ext_[LdsCommon<N, 2 * N>::NB][6];      // link forces of the constraint pass
     __device__ __forceinline__ float* ext(int b) { return ext_[b]; }
     __device__ __forceinline__ void poison(int lane) {
@@ -1371,40 +1373,39 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
                 // whole phase (the normal impulses are this iteration's final ones, a pair's own impulses only change
                 // at its own step), built with four ballots and kept in SGPRs, so a step's test is scalar.
                 constexpr int kC = LT::kRingF;
-                unsigned long long m0, m1, m2;
-                {
-                    unsigned long long b[4];
+                // (the solve runs on lanes 0 .. kMO - 1: one ballot covers kMO contacts; kP ballots, kW 64-bit words)
+                constexpr int kP = (LT::NCT + LT::kMO - 1) / LT::kMO, kW = (kP * LT::kMO + 63) / 64;
+                unsigned long long mw[kW + 1];
 #pragma unroll
-                    for (int p = 0; p < 4; p++) {
-                        const int c = LT::kMO * p + lane;
-                        bool lv = false;
-                        if (c < nc_pad) {
-                            const float4 a = *reinterpret_cast<const float4*>(L.acc[c]);
-                            lv = (mu * a.x > 0.f) || (a.y != 0.f) || (a.z != 0.f);     // (-0 counts as zero: a pair projected onto radius 0)
-                        }
-                        b[p] = __ballot(lv);
+                for (int w = 0; w <= kW; w++) mw[w] = 0ull;
+#pragma unroll
+                for (int p = 0; p < kP; p++) {
+                    const int c = LT::kMO * p + lane;
+                    bool lv = false;
+                    if (c < nc_pad) {
+                        const float4 a = *reinterpret_cast<const float4*>(L.acc[c]);
+                        lv = (mu * a.x > 0.f) || (a.y != 0.f) || (a.z != 0.f);     // (-0 counts as zero: a pair projected onto radius 0)
                     }
-                    static_assert(LT::kMO == 40 && LT::NCT <= 160, "the bit arithmetic below");
-                    m0 = b[0] | (b[1] << 40);                           // contacts 0 .. 63
-                    m1 = (b[1] >> 24) | (b[2] << 16) | (b[3] << 56);    // 64 .. 127
-                    m2 = b[3] >> 8;                                      // 128 .. 159
+                    const unsigned long long b = __ballot(lv);
+                    const int w = (LT::kMO * p) / 64, sh = (LT::kMO * p) % 64;       // compile-time after unrolling
+                    mw[w] |= b << sh;
+                    if (sh + LT::kMO > 64) mw[w + 1] |= b >> (64 - sh);
                 }
-                // (m2:m1:m0 is shifted down by kC contacts per trip)
+                // (the register is shifted down by kC contacts per trip)
                 constexpr unsigned kZeroB = (unsigned)(LT::kRows - 3) * kRecB;   // 960 bytes of zeros: the refill of a skipped pair
                 float jA[kC], jB[kC], mA[kC], mB[kC];
                 {
-                    const unsigned long long l0 = m0;
+                    const unsigned long long l0 = mw[0];
 #pragma unroll
                     for (int k = 0; k < kC; k++)
                         ldF((l0 >> k) & 1ull ? kFricB + (unsigned)k * 2u * kRecB : kZeroB, jA[k], jB[k], mA[k], mB[k]);
                 }
                 float4 fn = *reinterpret_cast<const float4*>(L.acc[0]);
                 for (int base = 0; base < nc_pad; base += kC) {
-                    unsigned long long lv = m0;                     // bits 0 .. kC - 1: this trip, kC .. 2 kC - 1: the next
+                    unsigned long long lv = mw[0];                  // bits 0 .. kC - 1: this trip, kC .. 2 kC - 1: the next
                     static_assert(2 * kC <= 64, "two trips' bits in one word");
-                    m0 = (m0 >> kC) | (m1 << (64 - kC));
-                    m1 = (m1 >> kC) | (m2 << (64 - kC));
-                    m2 >>= kC;
+#pragma unroll
+                    for (int w = 0; w < kW; w++) mw[w] = (mw[w] >> kC) | (mw[w + 1] << (64 - kC));      // (mw[kW] stays 0)
 #pragma unroll
                     for (int k = 0; k < kC; k++) {
                         if ((k & 7) == 0 && k > 0 && base + k >= nc_pad) break;  // wave-uniform

@@ -191,14 +191,13 @@ int snk_get_box(snk_handle* h, float* state, float* manifold);
 int snk_set_box(snk_handle* h, const float* state, const float* manifold);
 
 /* Where this build's structural limits were met, counted on the device since snk_create (Bullet has no such limits;
- * DESIGN.md 3):
+ * DESIGN.md 3).  Ground contacts have none left: the streamed-row solve has a slot for every point its chain's manifolds
+ * can hold (8n), and the register-resident 16-link solve hands the substeps that outgrow its 64 slots to it.
  *   out[0] 16-link handles on the register-resident solve: physics substeps in which an environment held more contact
  *          points than that solve's 64 slots (a snake at rest gathers up to four per cylinder).  Those substeps are
  *          solved by the streamed-row solve of the same chain instead, in the same launch, with every point -- a
- *          count of slower substeps, not of lost contacts.  Streamed-row handles: substeps with more ground points
- *          than slots (4n; 128 for 16 links), which a 2n-cylinder chain cannot reach,
- *   out[1] manifold points that got no rows in the substeps counted by out[0] (streamed-row handles only; the
- *          shallowest of their cylinders go first, every cylinder keeps its deepest point before any keeps a second),
+ *          count of slower substeps, not of lost contacts.  Streamed-row handles: always 0,
+ *   out[1] manifold points that got no rows: always 0 (kept as a tripwire: the finders still count against the slots),
  *   out[2] link-link / obstacle contacts beyond the room for them (32; 8 obstacle contacts on a register-resident
  *          16-link handle) -- obstacle contacts are kept before link-link ones.
  * Host buffer of 3. */

@@ -54,8 +54,8 @@ def test_obstacle_env_step_parity(pkg, oracle_mod, n, model):
     st = pkg.Stepper(B, **over)
     st.reset()
     sc = 1 if n == 32 else 0                       # what the kernels evaluate for this chain length
-    refs = [oracle_mod.OracleEnv(self_collision=sc, max_self_contacts=32, max_contacts=0 if n == 16 else 4 * n, **over) for _ in range(B)]
-    refs32 = [oracle_mod.OracleEnv(self_collision=sc, max_self_contacts=32, max_contacts=0 if n == 16 else 4 * n, f32=True, **over)
+    refs = [oracle_mod.OracleEnv(self_collision=sc, max_self_contacts=32, max_contacts=0, **over) for _ in range(B)]
+    refs32 = [oracle_mod.OracleEnv(self_collision=sc, max_self_contacts=32, max_contacts=0, f32=True, **over)
               for _ in range(B)]
     w = dict(q=0.0, qd=0.0, r=0.0, f3=0.0)
     c = dict(q=0.0, qd=0.0, r=0.0, f3=0.0)
@@ -282,8 +282,8 @@ def test_free_box_env_step_parity(pkg, oracle_mod, world):
         over.update(GAIT_TEST_WORLD)
     st = pkg.Stepper(B, **over)
     st.reset()
-    refs = [oracle_mod.OracleEnv(max_self_contacts=32, max_contacts=0 if n == 16 else 4 * n, **over) for _ in range(B)]
-    refs32 = [oracle_mod.OracleEnv(max_self_contacts=32, max_contacts=0 if n == 16 else 4 * n, f32=True, **over) for _ in range(B)]
+    refs = [oracle_mod.OracleEnv(max_self_contacts=32, max_contacts=0, **over) for _ in range(B)]
+    refs32 = [oracle_mod.OracleEnv(max_self_contacts=32, max_contacts=0, f32=True, **over) for _ in range(B)]
     ids = np.arange(B)
     w = dict(q=0.0, qd=0.0, r=0.0, f3=0.0, box=0.0)
     c = dict(q=0.0, qd=0.0, r=0.0, f3=0.0, box=0.0)
