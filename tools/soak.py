@@ -39,5 +39,6 @@ for case, (n, B, over) in enumerate(CASES):
     print("   %d random-action steps finite; max |qd| %.1f, max |obs fz| %.1f, substeps %d..%d; contact overflow "
           "(substeps, points, link-link/obstacle) %s"
           % (steps // 4, np.abs(o[:, n:2 * n]).max(), np.abs(o[:, -1]).max(), s.min(), s.max(), st.contact_overflow()), flush=True)
+    assert st.contact_overflow()[1] == 0, "a ground-contact point was left without rows"     # (structurally zero)
     st.close()
 print("soak ok")
