@@ -377,8 +377,12 @@ def test_env_steps_beyond_64_contacts_match_the_oracle(pkg, oracle_mod, monkeypa
     rng = np.random.default_rng(5)
     acts = [(0.04 * rng.standard_normal((B, 8))).astype(np.float32) for _ in range(J)]
     outs = {}
-    for quantum in (1, 0):
-        monkeypatch.setenv("SNK_QUANTUM", str(quantum))
+    # third run: the scheduled kernel with NaN-filled LDS images and allocations (SNK_POISON) -- the streamed-row substep
+    # runs on an LDS image laid over the register-resident one's and must not read what it has not written
+    for quantum in (1, 0, "poison"):
+        monkeypatch.setenv("SNK_QUANTUM", "1" if quantum == "poison" else str(quantum))
+        if quantum == "poison":
+            monkeypatch.setenv("SNK_POISON", "1")
         st = pkg.Stepper(B)
         st.reset()
         refs = [oracle_mod.OracleEnv() for _ in range(B)]
@@ -411,11 +415,13 @@ def test_env_steps_beyond_64_contacts_match_the_oracle(pkg, oracle_mod, monkeypa
             assert st.get_manifold()[:, :, 0].sum(axis=1).max() > 64
             assert worst < max(2e-3, 3 * cal) and mism <= B * J // 10
         st.close()
-    for (a, b) in zip(outs[1][0], outs[0][0]):
-        for x, y in zip(a, b):
-            assert np.array_equal(x, y)
-    assert np.array_equal(outs[1][1][0], outs[0][1][0]) and np.array_equal(outs[1][2], outs[0][2])
-    assert tuple(outs[1][3]) == tuple(outs[0][3])
+    monkeypatch.delenv("SNK_POISON")
+    for other in (0, "poison"):
+        for (a, b) in zip(outs[1][0], outs[other][0]):
+            for x, y in zip(a, b):
+                assert np.array_equal(x, y), other
+        assert np.array_equal(outs[1][1][0], outs[other][1][0]) and np.array_equal(outs[1][2], outs[other][2]), other
+        assert tuple(outs[1][3]) == tuple(outs[other][3]), other
 
 
 def test_thirty_two_links_at_rest_keep_every_point(pkg, oracle_mod):
