@@ -322,7 +322,9 @@ class SnakeVecEnv(VecEnv):
         obs, rew, done, sub = self._stepper.step(self._pending, vec_mode=True)
         self.waiting = False
         self.last_substeps = sub
-        return obs, rew, done, tuple({} for _ in range(self.nenvs))
+        if getattr(self, "_infos", None) is None or len(self._infos) != self.nenvs:
+            self._infos = tuple({} for _ in range(self.nenvs))      # train mode: empty dicts (SnakeGymEnv.py:46-47), made once
+        return obs, rew, done, self._infos
 
     def reset(self):
         return self._stepper.reset()
