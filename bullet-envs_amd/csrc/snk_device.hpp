@@ -1533,7 +1533,10 @@ __device__ __forceinline__ void substep_v1(LT& L, const DevModel& M, int lane, f
     SNK_STAMP(4)
     build_rows_v1(L, M, lane, nc, nn, rows);
     SNK_STAMP(5)
+    // the solve runs at a higher wave priority than everything around it (snk_pgs_v2.hpp: substep_v2)
+    __builtin_amdgcn_s_setprio(3);
     float dv = pgs_v1(L, M, lane, nc, nn, mu, iters, rows);
+    __builtin_amdgcn_s_setprio(0);
     SNK_STAMP(6)
     if (M.contact_model == 1 && lane < 2 * N) {
         // the normal impulses go back into the contact cache (btManifoldPoint::m_appliedImpulse [U]), write-through
