@@ -774,27 +774,32 @@ __device__ void build_rows_v1(LT& L, const DevModel& M, int lane, int nc, int& n
     constexpr int kMO = LT::kMO;
     float* const Mmx = rows + LT::kMmOff;           // M^-1, ND rows of kMO floats (columns >= ND stay zero)
     float mden = 0.f;                               // lane 6+j: M^-1[6+j][6+j], motor j's denominator
-    // ---- (a) the columns of M^-1: lane = velocity component, unit generalized force on it
-    if (lane < ND) {
+    // ---- (a) the columns of M^-1: lane = velocity component d, unit generalized force on it -- the ABA delta sweeps of
+    // btMultiBody::calcAccelerationDeltasMultiDof [U].  Backward sweep here; the forward sweep runs body by body inside
+    // the contact loop below (fwd), because the spatial acceleration (al, a) it gives body b IS what the contacts of
+    // body b need:  Y_b[d] = response of component d to a unit wrench on body b = (M^-1 symmetric) response of body b's
+    // twist to a unit force on component d.  Until the end of round 3 Y_b was rebuilt from the TRANSPOSED entries -- the
+    // wrench moved rigidly to the base plus a torque on every joint up to b, the responses of all of those summed --
+    // which is the same number with ~30 x the round-off (the terms are large and cancel; 32 links: one-substep velocity
+    // errors p90 5.9e-2 against the float32 oracle's 2.0e-3, tools/acc_distribution.py 1024 32).
+    const bool dofl = lane < ND;
+    float* const Mrow = Mmx + (size_t)(dofl ? lane : 0) * kMO;
+    const int kj = lane - 5;                        // the joint's body (lanes >= 6)
+    f3 al = mk3(0, 0, 0), a = mk3(0, 0, 0);         // this lane's sweep: spatial acceleration of the body reached so far
+    if (dofl) {
         const bool isbase = lane < 6;
-        const int k = lane - 5;                     // the joint's body (lanes >= 6)
-        float* Mrow = Mmx + (size_t)lane * kMO;
-        float uu[N];
         f3 pN = mk3(0, 0, 0), pF = mk3(0, 0, 0);
-#pragma unroll
+#pragma unroll 4
         for (int b = N; b >= 1; b--) {
             f3 ax = ld3(L.ax[b]);
             float u = -dot(ax, pN);
-            if (!isbase && b == k) u += 1.0f;
-            uu[b - 1] = u;
+            if (!isbase && b == kj) u += 1.0f;
+            Mrow[6 + b - 1] = u;                    // (parked in the row the forward sweep overwrites with qdd_b)
             float t = u * L.Dinv[b];
             f3 paN = pN + ld3(L.Ua[b]) * t, paF = pF + ld3(L.Ub[b]) * t;
             pN = paN + cross(ld3(L.r[b]), paF);
             pF = paF;
         }
-        // the forward sweep re-reads each body from LDS instead of finding 13 values per body kept -- spilled -- from
-        // the backward sweep (there is no LDS store in between that would make the compiler reload them)
-        asm volatile("" : : : "memory");
         float p0[6] = {pN.x, pN.y, pN.z, pF.x, pF.y, pF.z}, a0[6];
 #pragma unroll
         for (int i = 0; i < 6; i++) if (lane == i) p0[i] = -1.0f;      // unit force on the base: bias -e_i
@@ -806,15 +811,8 @@ __device__ void build_rows_v1(LT& L, const DevModel& M, int lane, int nc, int& n
             a0[i] = sacc;
             Mrow[i] = sacc;
         }
-        f3 al = mk3(a0[0], a0[1], a0[2]), a = mk3(a0[3], a0[4], a0[5]);
-#pragma unroll
-        for (int b = 1; b <= N; b++) {
-            a = a + cross(al, ld3(L.r[b]));
-            float qdd = (uu[b - 1] - (dot(ld3(L.Ua[b]), al) + dot(ld3(L.Ub[b]), a))) * L.Dinv[b];
-            al = al + ld3(L.ax[b]) * qdd;
-            Mrow[6 + b - 1] = qdd;
-            if (b == k) mden = qdd;
-        }
+        al = mk3(a0[0], a0[1], a0[2]);
+        a = mk3(a0[3], a0[4], a0[5]);
     }
     // the free box (obstacle 2): a second multibody, block-diagonal in M^-1 -- rows ND .. ND + 5: the world inverse
     // inertia for its angular components, 1 / m for its linear ones
@@ -828,8 +826,6 @@ __device__ void build_rows_v1(LT& L, const DevModel& M, int lane, int nc, int& n
         Mrow[ND + 0] = i < 3 ? r0.x : 0.f; Mrow[ND + 1] = i < 3 ? r0.y : 0.f; Mrow[ND + 2] = i < 3 ? r0.z : 0.f;
         Mrow[ND + 3] = i == 3 ? M.obs_minv : 0.f; Mrow[ND + 4] = i == 4 ? M.obs_minv : 0.f; Mrow[ND + 5] = i == 5 ? M.obs_minv : 0.f;
     }
-    __threadfence();          // M^-1 was written lane = row, it is read lane = column
-    lds_sync();
     // ---- (b) lane = velocity component d: what J[d] is made of, and the current velocity
     const int d = lane;
     const int jb = d >= 6 ? d - 5 : 0;              // the body this component's joint belongs to (0: the base)
@@ -847,8 +843,8 @@ __device__ void build_rows_v1(LT& L, const DevModel& M, int lane, int nc, int& n
     // does this lane's component move a point of body k?  (the snake's: the joints up to k; the box's six: the box)
     auto moves = [&](int k) { return boxlane ? k == LT::kBoxBody : (k <= N && jb <= k); };
     const bool colv = d < kMO;                      // lanes that own a column of the records
-    auto mm = [&](int row) { return colv ? Mmx[(size_t)row * kMO + d] : 0.f; };
-    f3 Yt = mk3(mm(0), mm(1), mm(2)), Yf = mk3(mm(3), mm(4), mm(5));    // Y_0
+    // Y of the body the sweep has reached: (Yt, Yf) = (al, a); zero on the lanes without a velocity component
+    f3 Yt = al, Yf = a;                             // Y_0
     const bool two_body = nc > L.nplane;            // link-link / obstacle contacts: any body, so every Y_k is kept
     float* const Yb = rows + LT::kYOff;
     auto storeY = [&](int k) {
@@ -859,14 +855,17 @@ __device__ void build_rows_v1(LT& L, const DevModel& M, int lane, int nc, int& n
     };
     storeY(0);
     int kcur = 0;
-    float colnext = mm(6);                          // M^-1[:, 6 + k] of the next body, requested one body ahead
-    auto advance = [&]() {                          // Y_kcur -> Y_kcur+1
+    auto advance = [&]() {                          // the forward sweep's step to body kcur + 1: Y_kcur -> Y_kcur+1
         kcur++;
-        const float col = colnext;
-        colnext = mm(kcur < N ? 6 + kcur : 6);
-        const f3 r = ld3(L.r[kcur]), ax = ld3(L.ax[kcur]);
-        Yf = mk3(Yf.x + (Yt.y * r.z - Yt.z * r.y), Yf.y + (Yt.z * r.x - Yt.x * r.z), Yf.z + (Yt.x * r.y - Yt.y * r.x));
-        Yt = Yt + ax * col;
+        if (dofl) {
+            const int b = kcur;
+            Yf = Yf + cross(Yt, ld3(L.r[b]));
+            const float u = Mrow[6 + b - 1];
+            const float qdd = (u - (dot(ld3(L.Ua[b]), Yt) + dot(ld3(L.Ub[b]), Yf))) * L.Dinv[b];
+            Yt = Yt + ld3(L.ax[b]) * qdd;
+            Mrow[6 + b - 1] = qdd;
+            if (b == kj) mden = qdd;
+        }
         storeY(kcur);
     };
     // one contact: three rows from its geometry record and the Y of its body (and of the other body of a pair)
@@ -975,9 +974,9 @@ __device__ void build_rows_v1(LT& L, const DevModel& M, int lane, int nc, int& n
             }
         }
     }
-    // ---- (d) link-link and obstacle contacts: any two bodies, their Y from the block the recursion left behind
+    while (kcur < N) advance();                     // (the rest of M^-1's rows: the motors need every joint's)
+    // ---- (d) link-link and obstacle contacts: any two bodies, their Y from the block the sweep left behind
     if (two_body) {
-        while (kcur < N) advance();
         if (fbox && colv) {
             // Y of the box: a unit wrench (tau, f) about its centre moves its own six components only --
             // angular component i: row i of the world inverse inertia . tau, linear component i: f_i / m

@@ -287,7 +287,7 @@ def test_free_box_env_step_parity(pkg, oracle_mod, world):
     ids = np.arange(B)
     w = dict(q=0.0, qd=0.0, r=0.0, f3=0.0, box=0.0)
     c = dict(q=0.0, qd=0.0, r=0.0, f3=0.0, box=0.0)
-    mism = touched = compared = 0
+    mism = mism32 = touched = compared = 0
     peak = 0.0
     for j in range(J):
         S, X = st.get_state()
@@ -320,6 +320,8 @@ def test_free_box_env_step_parity(pkg, oracle_mod, world):
             if k32 == k and d32 == d:
                 for key, v in errs(o32, r32, g32, b32).items():
                     c[key] = max(c[key], v)
+            else:
+                mism32 += 1                      # (the float32 oracle leaves the servo loop a substep apart as well)
             if k != sub[i] or d != bool(done[i]):
                 mism += 1
                 assert abs(k - sub[i]) <= 1
@@ -329,10 +331,10 @@ def test_free_box_env_step_parity(pkg, oracle_mod, world):
             compared += 1
             for key, v in errs(obs[i].astype(np.float64), float(rew[i]), float(f3[i]), BS2[i].astype(np.float64)).items():
                 w[key] = max(w[key], v)
-    print("free box parity,", world, "GPU-f32", w, "| oracle-f32", c, "| boundary mismatches", mism, "| steps touching the box",
+    print("free box parity,", world, "GPU-f32", w, "| oracle-f32", c, "| boundary mismatches", mism, "(oracle-f32:", mism32, ") | steps touching the box",
           touched, "| peak joint-3 reaction", peak, "| overflow", st.contact_overflow())
     assert touched >= B and compared >= B * J // 2
-    assert mism <= max(2, B * J // 8)
+    assert mism <= max(2, B * J // 8, 2 * mism32)          # threshold decisions (servo tolerance, 41-substep cap)
     assert w["q"] < max(1e-3, 4 * c["q"]) and w["qd"] < max(5e-2, 4 * c["qd"])
     assert w["r"] < max(5e-3, 4 * c["r"]) and w["f3"] < max(2.0, 4 * c["f3"])
     assert w["box"] < max(1e-5, 4 * c["box"])

@@ -1,15 +1,15 @@
 """Distribution of GPU-float32 vs oracle-float64 errors after K physics substeps on the ground (512 random
 states; K = 1 and 3: under the default contact model the cache starts empty and fills over the first substeps), next to
-oracle-float32 vs oracle-float64 on the same inputs.   python tools/acc_distribution.py [states]  The maxima are heavy-tailed
+oracle-float32 vs oracle-float64 on the same inputs.   python tools/acc_distribution.py [states] [links]  The maxima are heavy-tailed
 (stick-slip states amplify round-off by 1e5); medians and 90th percentiles are what to compare
 between builds."""
-import importlib, sys
+import importlib, os, sys
 import numpy as np
 sys.path.insert(0, '.'); sys.path.insert(0, 'oracle'); sys.path.insert(0, 'tests')
 import oracle as orc
 from conftest import random_state
 pkg = importlib.import_module("bullet-envs_amd")
-n, B = 16, int(sys.argv[1]) if len(sys.argv) > 1 else 512
+n, B = (int(sys.argv[2]) if len(sys.argv) > 2 else 16), (int(sys.argv[1]) if len(sys.argv) > 1 else 512)
 rng = np.random.default_rng(4321)
 S = np.zeros((B, 13 + 2 * n))
 for i in range(B):
@@ -18,11 +18,12 @@ for i in range(B):
 S32 = S.astype(np.float32)
 T = rng.uniform(-0.5, 0.5, (B, n)).astype(np.float32)
 for K in (1, 3):
-    st = pkg.Stepper(B, residual_threshold=0.0)
+    over = dict(self_collision=int(os.environ.get("ACC_SELF_COLLISION", "1")))       # (experiments: link-link contacts off)
+    st = pkg.Stepper(B, n_modules=n, residual_threshold=0.0, **over)
     st.set_state(S32); st.substep(T, K)
     G, _ = st.get_state()
     st.close()
-    o = orc.OracleEnv(residual_threshold=0.0); o32 = orc.OracleEnv(residual_threshold=0.0, f32=True)
+    o = orc.OracleEnv(n_modules=n, residual_threshold=0.0, max_contacts=0, **over); o32 = orc.OracleEnv(n_modules=n, residual_threshold=0.0, max_contacts=0, f32=True, **over)
     eg, e32 = [], []
     for i in range(B):
         o.hard_reset(); o32.hard_reset()   # (an empty contact cache, as the device's after set_state on a fresh handle)
