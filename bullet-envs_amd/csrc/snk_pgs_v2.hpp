@@ -376,8 +376,8 @@ __device__ __forceinline__ int lane_prefix3(int cnt, int lane, int& total) {
 }
 
 // Contacts with the obstacle box for the register-resident solve (lane = cylinder, the two-tier GJK of
-// snk_selfcol.hpp): at most LT::kObs of them (more are counted: snk_contact_overflow), appended behind the ground
-// contacts by find_contacts_v2.  The narrow phase runs BEFORE the ground contacts are compacted, because the slots the
+// snk_selfcol.hpp): at most LT::kObs of them on this solve (a substep with more goes through the streamed-row solve,
+// like one with more ground points than slots: find_contacts_v2 returns -1), appended behind the ground contacts.  The narrow phase runs BEFORE the ground contacts are compacted, because the slots the
 // box's contacts take come out of the ground's share (64 in all).
 struct ObsHit {
     bool hit;
@@ -438,9 +438,8 @@ __device__ __forceinline__ int find_obstacle_v2(LT& L, const DevModel& M, int la
         h.dA = aniso_scale(M, A.R, h.dA);
         h.dB = aniso_scale(M, A.R, h.dB);
     }
-    const int n_ob = __popcll(__ballot(h.hit));
-    if (n_ob > LT::kObs && lane == 0) atomicAdd(ovf + 2, (unsigned long long)(n_ob - LT::kObs));
-    return n_ob > LT::kObs ? LT::kObs : n_ob;
+    // (more than kObs of them: the caller sends the substep to the streamed-row solve, which has room for every cylinder)
+    return __popcll(__ballot(h.hit));
 }
 // ... and their records, behind the nplane ground contacts
 template <class LT>
@@ -494,7 +493,7 @@ __device__ int find_contacts_v2(LT& L, const DevModel& M, int lane, unsigned lon
         int total;
         (void)lane_prefix3(cnt, lane, total);
         const int room = 4 * N - n_ob;               // the solve's contact slots, less the box's contacts
-        if (total > room) {
+        if (total > room || n_ob > LT::kObs) {
             // More points than this solve has slots for (a snake at rest gathers up to four per cylinder: 128).  Bullet
             // has no such limit, and neither has the streamed-row solve of this chain (128 + 32 slots): nothing has
             // been written yet, the caller runs THIS substep through that solve instead (snk_device.hpp: substep()).
@@ -555,7 +554,7 @@ __device__ int find_contacts_v2(LT& L, const DevModel& M, int lane, unsigned lon
     bool active = dist < M.break_thr;
     unsigned long long bal = __ballot(active);
     const int room = 4 * N - n_ob;                   // the solve's contact slots, less the box's contacts
-    if (__popcll(bal) > room) {                      // (only with an obstacle: two points per cylinder are 4 N at most)
+    if (__popcll(bal) > room || n_ob > LT::kObs) {   // (only with an obstacle: two points per cylinder are 4 N at most)
         if (lane == 0) atomicAdd(ovf, 1ull);         // over to the streamed-row solve, as above
         return -1;
     }

@@ -194,12 +194,14 @@ int snk_set_box(snk_handle* h, const float* state, const float* manifold);
  * DESIGN.md 3).  Ground contacts have none left: the streamed-row solve has a slot for every point its chain's manifolds
  * can hold (8n), and the register-resident 16-link solve hands the substeps that outgrow its 64 slots to it.
  *   out[0] 16-link handles on the register-resident solve: physics substeps in which an environment held more contact
- *          points than that solve's 64 slots (a snake at rest gathers up to four per cylinder).  Those substeps are
+ *          points than that solve's 64 slots (a snake at rest gathers up to four per cylinder) or touched the
+ *          obstacle with more than eight cylinders.  Those substeps are
  *          solved by the streamed-row solve of the same chain instead, in the same launch, with every point -- a
  *          count of slower substeps, not of lost contacts.  Streamed-row handles: always 0,
  *   out[1] manifold points that got no rows: always 0 (kept as a tripwire: the finders still count against the slots),
- *   out[2] link-link / obstacle contacts beyond the room for them (32; 8 obstacle contacts on a register-resident
- *          16-link handle) -- obstacle contacts are kept before link-link ones.
+ *   out[2] 32-link handles: link-link / obstacle contacts beyond the room for them (32 in all; obstacle contacts are
+ *          kept before link-link ones).  16-link handles: always 0 (a substep with more than the register-resident
+ *          solve's eight box contacts goes through the other solve as well, which has room for every cylinder).
  * Host buffer of 3. */
 int snk_contact_overflow(snk_handle* h, uint64_t* out);
 

@@ -3,7 +3,7 @@ states; K = 1 and 3: under the default contact model the cache starts empty and 
 oracle-float32 vs oracle-float64 on the same inputs.   python tools/acc_distribution.py [states] [links]  The maxima are heavy-tailed
 (stick-slip states amplify round-off by 1e5); medians and 90th percentiles are what to compare
 between builds."""
-import importlib, os, sys
+import importlib, json, os, sys
 import numpy as np
 sys.path.insert(0, '.'); sys.path.insert(0, 'oracle'); sys.path.insert(0, 'tests')
 import oracle as orc
@@ -19,6 +19,7 @@ S32 = S.astype(np.float32)
 T = rng.uniform(-0.5, 0.5, (B, n)).astype(np.float32)
 for K in (1, 3):
     over = dict(self_collision=int(os.environ.get("ACC_SELF_COLLISION", "1")))       # (experiments: link-link contacts off)
+    over.update(json.loads(os.environ.get("ACC_OVER", "{}")))                       # (... any other parameter set)
     st = pkg.Stepper(B, n_modules=n, residual_threshold=0.0, **over)
     st.set_state(S32); st.substep(T, K)
     G, _ = st.get_state()
