@@ -22,10 +22,10 @@ for K in (1, 3):
     over.update(json.loads(os.environ.get("ACC_OVER", "{}")))                       # (... any other parameter set)
     st = pkg.Stepper(B, n_modules=n, residual_threshold=0.0, **over)
     st.set_state(S32); st.substep(T, K)
-    G, _ = st.get_state()
+    G, GX = st.get_state()
     st.close()
     o = orc.OracleEnv(n_modules=n, residual_threshold=0.0, max_contacts=0, **over); o32 = orc.OracleEnv(n_modules=n, residual_threshold=0.0, max_contacts=0, f32=True, **over)
-    eg, e32 = [], []
+    eg, e32, fg, f32_ = [], [], [], []
     for i in range(B):
         o.hard_reset(); o32.hard_reset()   # (an empty contact cache, as the device's after set_state on a fresh handle)
         o.set_state(S32[i].astype(np.float64)); o32.set_state(S32[i].astype(np.float64))
@@ -34,5 +34,11 @@ for K in (1, 3):
         r = o.get_state(); r32 = o32.get_state()
         f = lambda x: (np.abs(x[13 + n:] - r[13 + n:]) / (1 + np.abs(r[13 + n:]))).max()
         eg.append(f(G[i])); e32.append(f(r32))
-    for name, e in (("GPU float32   ", np.array(eg)), ("oracle float32", np.array(e32))):
-        print("K = %d  " % K + name, "median %.3e  p90 %.3e  p99 %.3e  max %.3e" % (np.median(e), np.percentile(e, 90), np.percentile(e, 99), e.max()))
+        # the joint-0 force sensor (obs[55] / obs[103]) and the motor torques of the last substep: aux = [torques n, fz, ..]
+        ta, fza, _ = o.get_aux(); tb, fzb, _ = o32.get_aux()
+        sc = 1.0 + np.abs(ta).max() + abs(fza)
+        fg.append(max(np.abs(GX[i, :n] - ta).max(), abs(GX[i, n] - fza)) / sc)
+        f32_.append(max(np.abs(tb - ta).max(), abs(fzb - fza)) / sc)
+    for name, e, ff in (("GPU float32   ", np.array(eg), np.array(fg)), ("oracle float32", np.array(e32), np.array(f32_))):
+        print("K = %d  " % K + name, "median %.3e  p90 %.3e  p99 %.3e  max %.3e" % (np.median(e), np.percentile(e, 90), np.percentile(e, 99), e.max()),
+              "| torques + force sensor: median %.3e  p90 %.3e" % (np.median(ff), np.percentile(ff, 90)))
