@@ -1330,7 +1330,7 @@ void substep(orc_env* e, const Real* targets) {
         /* the box: a btMultiBody without links [U] -- gravity, the same base damping m v (k + k|v|), I w (k + k|w|),
          * the gyroscopic term; v += a dt, clamped */
         box_frame(e);
-        const Real m = (Real)P.obstacle_mass, kl = (Real)P.lin_damping, ka = (Real)P.ang_damping;
+        const Real kl = (Real)P.lin_damping, ka = (Real)P.ang_damping;      /* (the mass cancels: a = F / m) */
         Real nv = std::sqrt(dot3(e->bvel, e->bvel)), nw = std::sqrt(dot3(e->bomega, e->bomega));
         Real wl[3], Iw[3], Iww[3], gy[3], tq[3], al[3];
         mat3T_vec(e->bR, e->bomega, wl);
