@@ -237,7 +237,9 @@ inline void build_dev_model(const snk_params& P, const HostModel& H, DevModel& D
     D.warm_factor = (float)P.warmstarting_factor;
     D.cyl_r = 0.026f; D.cyl_hl = 0.0165f;                               // snake.urdf:809
     D.hull_sides = P.hull_sides; D.contact_model = P.contact_model;
-    D.self_collision = (P.self_collision && n == 32) ? 1 : 0;    // only the streamed-row solve builds link-link rows
+    // (link-link rows are built by the streamed-row solve; a 16-link substep with a pair of links within reach of each
+    //  other goes there: snk_pgs_v2.hpp, find_contacts_v2)
+    D.self_collision = P.self_collision ? 1 : 0;
     D.obstacle = P.obstacle;
     for (int i = 0; i < 3; i++) { D.obs_c[i] = (float)P.obstacle_pos[i]; D.obs_h[i] = (float)P.obstacle_half[i]; }
     D.mu_obs = (float)P.mu_obstacle;

@@ -466,6 +466,12 @@ template <class LT>
 __device__ int find_contacts_v2(LT& L, const DevModel& M, int lane, unsigned long long* __restrict__ ovf) {
     constexpr int N = LT::kN;
     static_assert(4 * N == 64, "one contact slot per lane");
+    // link-link contacts have two-body rows, which only the streamed-row solve builds: a substep in which a pair of links
+    // may be within the breaking threshold goes there (never under the reference's command range: snk_selfcol.hpp)
+    if (M.self_collision && any_self_pair_v2(L, M, lane)) {
+        if (lane == 0) atomicAdd(ovf, 1ull);
+        return -1;
+    }
     ObsHit oh;
     const int n_ob = find_obstacle_v2(L, M, lane, oh, ovf);      // 0 without an obstacle
     if (M.contact_model == 1) {

@@ -13,8 +13,11 @@
 // threshold, at most kMaxSelf per environment (what does not fit is counted: snk_contact_overflow), ordered by (b - a, a) -- the same rules as oracle/snake_oracle.cpp
 // (find_self_contacts), restated independently here in float32.
 //
-// Only the streamed-row solve (32-link chains) builds rows for these contacts: for the 16-link snake they can never
-// act inside the joint limits (tools/self_collision_clearance.py), and its register-resident solve has no slot left.
+// Only the streamed-row solve builds rows for these contacts.  The register-resident 16-link solve has no two-body rows:
+// it runs the broad phase and the separating-axis cull (any_self_pair_v2 below), and a substep in which some pair of links
+// may be within the breaking threshold goes through the streamed-row solve instead -- never under the reference's
+// command range (|target| <= 30 deg: 15 mm of clearance, tools/self_collision_clearance.py), but a snake bent further
+// (a larger scaling_factor, states set from outside) does fold onto itself.
 #pragma once
 
 namespace snk {
@@ -253,6 +256,43 @@ __device__ __forceinline__ bool cyl_box_may_touch(const DevModel& M, f3 ca, f3 a
         bound = fmaxf(bound, fabsf(dot(d, e)) - (hi - M.margin) - cyl_extent(M, axa, e));
     }
     return bound - 2.0f * M.margin <= M.break_thr + 1e-5f;
+}
+
+// Does any pair of cylinder links (parent-child pairs excepted) pass the broad phase and the separating-axis cull?
+// Wave-uniform answer.  Centres and axes are staged in LDS (the row staging area, idle at this point of a substep);
+// lane = (half, cylinder a): the lower half takes the even offsets b - a, the upper half the odd ones, no cross-lane
+// traffic and one ballot at the end (the first version walked the offsets with three ds_bpermutes and a ballot each:
+// 1.1 % of the kernel in dependent latency).
+template <class LT>
+__device__ __forceinline__ bool any_self_pair_v2(LT& L, const DevModel& M, int lane) {
+    constexpr int NCYL = 2 * LT::kN;
+    static_assert(NCYL == 32, "one cylinder per lane of a half");
+    const float rb = sqrtf(M.cyl_r * M.cyl_r + M.cyl_hl * M.cyl_hl) + M.margin;
+    const float reach = 2.0f * rb + M.break_thr;
+    const int a = lane & 31, h = lane >> 5;
+    const int ba = (a + 1) >> 1;
+    const f3 ca = ld3(L.o[ba]) + mulRv(L.R[ba], ld3(M.cyl_c[a]));
+    const f3 axa = mulRv(L.R[ba], mk3(M.cyl_R[a][2], M.cyl_R[a][5], M.cyl_R[a][8]));
+    if (h == 0) {
+        st3(&L.stM[a][0], ca);
+        st3(&L.stM[a][3], axa);
+    }
+    lds_sync();
+    bool hit = false;
+#pragma unroll 5
+    for (int t = 0; t < 15; t++) {
+        const int bc = a + 2 + h + 2 * t;
+        const bool valid = bc < NCYL;
+        const int bb = valid ? bc : a;
+        const f3 cb = ld3(&L.stM[bb][0]);
+        const f3 d = ca - cb;
+        bool cand = valid && dot(d, d) <= reach * reach;
+        if (cand) cand = cyl_cyl_may_touch(M, ca, axa, cb, ld3(&L.stM[bb][3]));
+        hit = hit || cand;
+    }
+    const bool any = __any(hit) != 0;
+    lds_sync();                 // (the staging area is written again further down)
+    return any;
 }
 
 // Link-link contacts of the current pose, appended behind the ground contacts: geometry records at slots

@@ -37,9 +37,10 @@ typedef struct snk_params {
                                    breaking threshold; 0: stateless -- both end-cap points of
                                    every cylinder, every step (the round-1 model)                      */
     int32_t self_collision;     /* 1 (default): link-link contacts between non-adjacent cylinder links, what
-                                   URDF_USE_SELF_COLLISION (snake.py:93) switches on [U].  Evaluated for
-                                   n_modules 32; for the 16-link snake they can never act inside the joint
-                                   limits and no rows are built                               */
+                                   URDF_USE_SELF_COLLISION (snake.py:93) switches on [U].  Their two-body rows are
+                                   built by the streamed-row solve; a 16-link substep in which some pair of links may
+                                   be within the breaking threshold goes through it (never inside the reference's
+                                   command range)                                              */
     int32_t obstacle;           /* the box of snake/block.urdf that Snake.add_obstacle (snake.py:83-84, commented out
                                    at :94) and snake_gait_test.py:51 put in front of the snake.  0 (default): none.
                                    1: STATIC (16 links: up to 8 contacts with it, out of the solve's 64 slots).
@@ -194,8 +195,9 @@ int snk_set_box(snk_handle* h, const float* state, const float* manifold);
  * DESIGN.md 3).  Ground contacts have none left: the streamed-row solve has a slot for every point its chain's manifolds
  * can hold (8n), and the register-resident 16-link solve hands the substeps that outgrow its 64 slots to it.
  *   out[0] 16-link handles on the register-resident solve: physics substeps in which an environment held more contact
- *          points than that solve's 64 slots (a snake at rest gathers up to four per cylinder) or touched the
- *          obstacle with more than eight cylinders.  Those substeps are
+ *          points than that solve's 64 slots (a snake at rest gathers up to four per cylinder), touched the
+ *          obstacle with more than eight cylinders, or had two of its links within reach of each other (that
+ *          solve has no two-body rows).  Those substeps are
  *          solved by the streamed-row solve of the same chain instead, in the same launch, with every point -- a
  *          count of slower substeps, not of lost contacts.  Streamed-row handles: always 0,
  *   out[1] manifold points that got no rows: always 0 (kept as a tripwire: the finders still count against the slots),

@@ -1696,7 +1696,7 @@ void orc_default_params(orc_params* p) {
     p->collision_margin = 0.001;
     p->hull_sides = 32;  /* PyBullet's import of a URDF <cylinder> [U]: find_contacts, DESIGN.md §3 (0: implicit cylinder) */
     p->max_contacts = 0;
-    p->self_collision = 0;   /* 1 = link-link contacts (URDF_USE_SELF_COLLISION, snake.py:93); tests switch it on */
+    p->self_collision = 1;   /* link-link contacts (URDF_USE_SELF_COLLISION, snake.py:93): the reference's load flag */
     p->max_self_contacts = 0;
     p->obstacle = 0;
     p->obstacle_pos[0] = 2.0; p->obstacle_pos[1] = 0.0; p->obstacle_pos[2] = 0.1;      /* snake.py:94 */

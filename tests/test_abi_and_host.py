@@ -62,11 +62,6 @@ def test_oracle_and_product_defaults_agree(pkg, oracle_mod):
         if name.startswith("reserved"):
             assert getattr(a, name) == 0
             continue
-        if name == "self_collision":
-            # the product follows the reference's load flag (on) and evaluates it for 32 links only; the oracle can
-            # evaluate it for any chain, so it defaults to off and the self-collision tests switch it on
-            assert getattr(a, name) == 1 and getattr(b, name) == 0
-            continue
         va, vb = getattr(a, name), getattr(b, name)
         if name in ("aniso", "obstacle_pos", "obstacle_half"):
             assert list(va) == list(vb), name

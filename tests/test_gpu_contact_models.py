@@ -303,9 +303,10 @@ def test_contact_model_error_bar(pkg, oracle_mod):
                 S, X = st.get_state()                            # = reset obs, so the next reward starts from x = 0
                 X[d, 16 + 1] = 0.0
                 st.set_state(S, X)
-        # Bullet has no contact limit; the solve has 64 slots.  Over these rollouts the limit must never have been hit,
-        # so the oracle runs UNCAPPED (max_contacts = 0)
-        assert st.contact_overflow() == (0, 0, 0), (name, st.contact_overflow())
+        # Bullet has no contact limit: nothing may have been left without rows, so the oracle runs UNCAPPED
+        # (max_contacts = 0).  ([0] counts substeps that took the streamed-row solve: under the 0.02-m threshold the
+        #  neighbours across a bent joint are within reach of each other and get their -- inert -- link-link rows there.)
+        assert st.contact_overflow()[1:] == (0, 0), (name, st.contact_overflow())
         st.close()
         g /= B * T
         _, _, agg = oracle_mod.bench_gait(B, bench.env_phases(ids), 0, T, threads, want_agg=True, max_contacts=0, **over)

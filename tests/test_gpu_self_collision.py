@@ -156,3 +156,47 @@ def test_sixteen_link_self_contacts_are_inert_in_the_oracle(oracle_mod, relative
             extra = a_env.last_normal_impulses(512)[b_env.last_num_contacts:]
             assert np.all(extra == 0.0)
     assert (seen == 0) if relative else (seen > 0)
+
+
+@pytest.mark.gpu
+def test_sixteen_links_folded_onto_themselves(pkg, oracle_mod):
+    """URDF_USE_SELF_COLLISION (snake.py:93) holds for the 16-link snake too.  Inside the reference's command range its
+    links never come within reach of each other (tools/self_collision_clearance.py), but a snake bent further -- a larger
+    scaling_factor, a state set from outside -- folds onto itself, and the link-link contacts then carry real impulses.
+    The register-resident solve has no two-body rows: a substep in which a pair may touch goes through the streamed-row
+    solve, which builds them.  Random states with joint angles up to 1.7 rad (a third of them with link-link contacts in
+    the oracle): the distribution of one-substep errors against the float64 oracle is the float32 oracle's.  (Until the
+    end of round 3 the 16-link kernels built no such rows: the 90th percentile here was 0.59 against 3e-4.)"""
+    from conftest import random_state
+    B, n = 384, 16
+    rng = np.random.default_rng(4321)
+    S = np.zeros((B, 13 + 2 * n), np.float32)
+    for i in range(B):
+        s = random_state(rng, n, z=0.026, qamp=1.7, vamp=0.3, flat=True)
+        s[9] *= 0.1; s[7:9] *= 0.1
+        S[i] = s
+    T = rng.uniform(-0.5, 0.5, (B, n)).astype(np.float32)
+    st = pkg.Stepper(B, residual_threshold=0.0)
+    st.set_state(S)
+    st.substep(T, 1)
+    G, _ = st.get_state()
+    ov = st.contact_overflow()
+    st.close()
+    o = oracle_mod.OracleEnv(residual_threshold=0.0, max_contacts=0)
+    o32 = oracle_mod.OracleEnv(residual_threshold=0.0, max_contacts=0, f32=True)
+    eg, e32, touching = [], [], 0
+    for i in range(B):
+        for e in (o, o32):
+            e.hard_reset()
+            e.set_state(S[i].astype(np.float64))
+            e.substep(T[i].astype(np.float64))
+        lc = o.last_contacts_full()
+        touching += int(len(lc) and (lc[:, 5] >= 0).any())
+        r, r32 = o.get_state(), o32.get_state()
+        f = lambda x: (np.abs(x[13 + n:] - r[13 + n:]) / (1 + np.abs(r[13 + n:]))).max()
+        eg.append(f(G[i])); e32.append(f(r32))
+    eg, e32 = np.array(eg), np.array(e32)
+    print("folded 16-link snakes: states with link-link contacts", touching, "of", B, "| counters", ov,
+          "| GPU median / p90", np.median(eg), np.percentile(eg, 90), "| oracle-f32", np.median(e32), np.percentile(e32, 90))
+    assert touching >= B // 8 and ov[0] >= touching and ov[1] == 0 and ov[2] == 0
+    assert np.median(eg) < 2 * np.median(e32) and np.percentile(eg, 90) < 3 * np.percentile(e32, 90)

@@ -13,7 +13,7 @@ n, B = (int(sys.argv[2]) if len(sys.argv) > 2 else 16), (int(sys.argv[1]) if len
 rng = np.random.default_rng(4321)
 S = np.zeros((B, 13 + 2 * n))
 for i in range(B):
-    S[i] = random_state(rng, n, z=0.026, qamp=0.3, vamp=0.3, flat=True)
+    S[i] = random_state(rng, n, z=0.026, qamp=float(os.environ.get("ACC_QAMP", "0.3")), vamp=0.3, flat=True)
     S[i, 9] *= 0.1; S[i, 7:9] *= 0.1
 S32 = S.astype(np.float32)
 T = rng.uniform(-0.5, 0.5, (B, n)).astype(np.float32)
@@ -21,6 +21,9 @@ for K in (1, 3):
     over = dict(self_collision=int(os.environ.get("ACC_SELF_COLLISION", "1")))       # (experiments: link-link contacts off)
     over.update(json.loads(os.environ.get("ACC_OVER", "{}")))                       # (... any other parameter set)
     st = pkg.Stepper(B, n_modules=n, residual_threshold=0.0, **over)
+    MU = rng.uniform(0.5, 1.5, B).astype(np.float32) if os.environ.get("ACC_MU") else None     # per-env plane friction
+    if MU is not None:
+        st.set_ground_friction(MU)
     st.set_state(S32); st.substep(T, K)
     G, GX = st.get_state()
     st.close()
@@ -28,6 +31,8 @@ for K in (1, 3):
     eg, e32, fg, f32_ = [], [], [], []
     for i in range(B):
         o.hard_reset(); o32.hard_reset()   # (an empty contact cache, as the device's after set_state on a fresh handle)
+        if MU is not None:
+            o.set_plane_friction(float(MU[i])); o32.set_plane_friction(float(MU[i]))
         o.set_state(S32[i].astype(np.float64)); o32.set_state(S32[i].astype(np.float64))
         for _ in range(K):
             o.substep(T[i].astype(np.float64)); o32.substep(T[i].astype(np.float64))
