@@ -1022,6 +1022,22 @@ void find_self_contacts(orc_env* e) {
             Real d[3] = {cv[a].c[0] - cv[b].c[0], cv[a].c[1] - cv[b].c[1], cv[a].c[2] - cv[b].c[2]};
             Real reach = 2 * rb + thr;
             if (dot3(d, d) > reach * reach) continue;         /* bounding spheres */
+            {
+                /* a separating axis: along the line of centres the two nominal cylinders (a hull lies inside its
+                 * cylinder) are at least `bound` apart; when that, less both margins, is beyond the threshold the
+                 * narrow phase below would reject the pair as well -- same contact set, fewer GJK runs (under the
+                 * 1.2-mm relative threshold the neighbours across one joint, 15..29 mm apart, all stop here) */
+                const Real nn = std::sqrt(dot3(d, d));
+                if (nn > Real(1e-6)) {
+                    Real ext = 0;
+                    for (int s2 = 0; s2 < 2; s2++) {
+                        const Real* R = s2 ? cv[b].R : cv[a].R;
+                        const Real c = (R[2] * d[0] + R[5] * d[1] + R[8] * d[2]) / nn;      /* axis (local z) . u */
+                        ext += e->cyl_len / 2 * std::fabs(c) + e->cyl_r * std::sqrt(std::max(Real(0), 1 - c * c));
+                    }
+                    if (nn - ext - 2 * mg > thr + Real(1e-5)) continue;
+                }
+            }
             Real pa[3], pb[3];
             Real dist = gjk_distance(cv[a], cv[b], pa, pb);
             Real mgx = mg;
