@@ -13,7 +13,8 @@ n, B = (int(sys.argv[2]) if len(sys.argv) > 2 else 16), (int(sys.argv[1]) if len
 rng = np.random.default_rng(4321)
 S = np.zeros((B, 13 + 2 * n))
 for i in range(B):
-    S[i] = random_state(rng, n, z=0.026, qamp=float(os.environ.get("ACC_QAMP", "0.3")), vamp=0.3, flat=True)
+    S[i] = random_state(rng, n, z=float(os.environ.get("ACC_Z", "0.026")), qamp=float(os.environ.get("ACC_QAMP", "0.3")),
+                        vamp=float(os.environ.get("ACC_VAMP", "0.3")), flat=os.environ.get("ACC_FLAT", "1") == "1")
     S[i, 9] *= 0.1; S[i, 7:9] *= 0.1
 S32 = S.astype(np.float32)
 T = rng.uniform(-0.5, 0.5, (B, n)).astype(np.float32)
