@@ -69,6 +69,8 @@ SYMBOLS = {
     "snk_get_manifold": (C.c_int, [_vp, _F]),
     "snk_set_manifold": (C.c_int, [_vp, _F]),
     "snk_contact_overflow": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
+    "snk_contact_histogram_bins": (C.c_int32, []),
+    "snk_contact_histogram": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.c_int32]),
     "snk_get_box": (C.c_int, [_vp, _F, _F]),
     "snk_set_box": (C.c_int, [_vp, _F, _F]),
     "snk_get_obs": (C.c_int, [_vp, _F]),
@@ -258,6 +260,14 @@ class Stepper:
         out = (C.c_uint64 * 3)()
         check(self.lib.snk_contact_overflow(self.h, out), "snk_contact_overflow")
         return int(out[0]), int(out[1]), int(out[2])
+
+    def contact_histogram(self, reset=False):
+        """snk_contact_histogram: out[k] = physics substeps that ran with k contact points since the handle was created
+        (or since the last call with reset=True); the last bin collects everything beyond it."""
+        n = int(self.lib.snk_contact_histogram_bins())
+        out = (C.c_uint64 * n)()
+        check(self.lib.snk_contact_histogram(self.h, out, 1 if reset else 0), "snk_contact_histogram")
+        return np.array(out[:], dtype=np.uint64)
 
     def get_obs(self):
         o = np.zeros((self.n_envs, self.obs_dim), dtype=np.float32)

@@ -322,8 +322,8 @@ int init_handle(snk_handle* h, const snk_params* p, int32_t n_envs, int32_t devi
         HIP_TRY(hipMalloc(&h->d_box, b.size() * sizeof(float)));
         HIP_TRY(hipMemcpy(h->d_box, b.data(), b.size() * sizeof(float), hipMemcpyHostToDevice));
     }
-    HIP_TRY(hipMalloc(&h->d_ovf, 3 * sizeof(unsigned long long)));
-    HIP_TRY(hipMemset(h->d_ovf, 0, 3 * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc(&h->d_ovf, (snk::kOvfCounters + snk::kHistBins) * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(h->d_ovf, 0, (snk::kOvfCounters + snk::kHistBins) * sizeof(unsigned long long)));
     if (p->contact_model == 1) {
         const size_t bytes = ne * 2 * h->n * snk::kMfFloats * sizeof(float);
         HIP_TRY(hipMalloc(&h->d_mf, bytes));
@@ -677,6 +677,18 @@ int snk_contact_overflow(snk_handle* h, uint64_t* out) {
     unsigned long long v[3];
     HIP_TRY(hipMemcpy(v, h->d_ovf, sizeof(v), hipMemcpyDeviceToHost));
     for (int i = 0; i < 3; i++) out[i] = (uint64_t)v[i];
+    return 0;
+}
+
+int32_t snk_contact_histogram_bins(void) { return snk::kHistBins; }
+int snk_contact_histogram(snk_handle* h, uint64_t* out, int32_t reset) {
+    if (!h || !out) return fail("snk_contact_histogram: null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipDeviceSynchronize());
+    std::vector<unsigned long long> v(snk::kHistBins);
+    HIP_TRY(hipMemcpy(v.data(), h->d_ovf + snk::kOvfCounters, v.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    for (int i = 0; i < snk::kHistBins; i++) out[i] = (uint64_t)v[i];
+    if (reset) HIP_TRY(hipMemset(h->d_ovf + snk::kOvfCounters, 0, v.size() * sizeof(unsigned long long)));
     return 0;
 }
 

@@ -1725,6 +1725,11 @@ __device__ __forceinline__ void substep_v1(LT& L, const DevModel& M, int lane, f
 #include "snk_freebox.hpp"
 namespace snk {
 
+// snk_contact_overflow's three counters, then the histogram of contact points per physics substep (kHistBins values;
+// a 32-link snake's manifolds hold 256 ground points at most, plus 32 link-link / obstacle contacts)
+constexpr int kOvfCounters = 3;
+constexpr int kHistBins = 320;
+
 // One out-of-line copy of the streamed-row substep for the register-resident kernels' rare substeps (below): inlined
 // there it would double those kernels; the streamed-row kernels themselves inline it (as a called function its LDS
 // accesses go through flat addresses: -10 % on those kernels when the compiler chose that by itself, round 3).
@@ -1769,6 +1774,14 @@ __device__ __forceinline__ void substep(LT& L, const DevModel& M0, int lane_in, 
         }
     } else {
         substep_v1(L, M, lane, mu, iters, ncontacts, rows, hint, mf, ovf);
+    }
+    // contact points of this substep, counted per value (snk_contact_histogram): what decides how many row slots a
+    // register-resident solve needs.  One fire-and-forget atomic per substep (every lane with its own operand, folded
+    // into one memory operation: see sched_pop for why there is no `if (lane == 0)`).
+    {
+        int bin = __builtin_amdgcn_readfirstlane(ncontacts);
+        bin = bin < 0 ? 0 : (bin > kHistBins - 1 ? kHistBins - 1 : bin);
+        atomicAdd(ovf + kOvfCounters + bin, lane_id() == 0 ? 1ull : 0ull);
     }
 }
 

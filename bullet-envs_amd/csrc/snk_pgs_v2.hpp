@@ -1077,55 +1077,71 @@ __device__ __forceinline__ void cone_step(float& RJ, const float RM, const float
 // `new - a` updates are one v_pk_fma_f32 with the two sums in an SGPR pair -- 52 VALU instead of 56.  Inline asm cannot
 // name the halves of a 64-bit operand, so these temporaries are PINNED registers (v250..v255, s84..s89), declared as
 // clobbers: the compiler keeps nothing in them across a step.
-#define SNK_CONE2_BODY \
+#define SNK_STR_(x) #x
+#define SNK_V1(a) "v" SNK_STR_(a)
+#define SNK_S1(a) "s" SNK_STR_(a)
+#define SNK_VP(a, b) "v[" SNK_STR_(a) ":" SNK_STR_(b) "]"
+#define SNK_SP(a, b) "s[" SNK_STR_(a) ":" SNK_STR_(b) "]"
+#define SNK_CONE2_BODY_(P0, P1, P2, P3, P4, P5, Q0, Q1, Q2, Q3, Q4, Q5) \
     "v_mul_f32 %[t1], %[RJ1], %[dv]\n\t" \
     "v_mul_f32 %[t2], %[RJ2], %[dv]\n\t" \
-    "v_readlane_b32 s84, %[RJ1], 31\n\t" \
-    "v_readlane_b32 s85, %[RJ1], 63\n\t" \
+    "v_readlane_b32 " SNK_S1(Q0) ", %[RJ1], 31\n\t" \
+    "v_readlane_b32 " SNK_S1(Q1) ", %[RJ1], 63\n\t" \
     SNK_RED2("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1") \
-    "v_readlane_b32 s86, %[RJ2], 31\n\t" \
-    "v_readlane_b32 s87, %[RJ2], 63\n\t" \
+    "v_readlane_b32 " SNK_S1(Q2) ", %[RJ2], 31\n\t" \
+    "v_readlane_b32 " SNK_S1(Q3) ", %[RJ2], 63\n\t" \
     SNK_RED2("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1") \
     "v_readlane_b32 %[l1], %[RJn], 31\n\t" \
     "v_readlane_b32 %[l2], %[RJn], 63\n\t" \
     SNK_RED2("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1") \
-    "v_mov_b64 v[250:251], s[84:85]\n\t" \
+    "v_mov_b64 " SNK_VP(P0, P1) ", " SNK_SP(Q0, Q1) "\n\t" \
     SNK_RED2("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1") \
-    "v_mov_b64 v[252:253], s[86:87]\n\t" \
+    "v_mov_b64 " SNK_VP(P2, P3) ", " SNK_SP(Q2, Q3) "\n\t" \
     SNK_RED2("row_bcast:15 row_mask:0xa bank_mask:0xf") \
-    "v_readlane_b32 s88, %[t1], 31\n\t" \
-    "v_readlane_b32 s89, %[t1], 63\n\t" \
+    "v_readlane_b32 " SNK_S1(Q4) ", %[t1], 31\n\t" \
+    "v_readlane_b32 " SNK_S1(Q5) ", %[t1], 63\n\t" \
     "s_nop 0\n\t" \
-    "v_fma_f32 v254, s88, s88, 1\n\t" \
-    "v_fma_f32 v254, s89, s89, v254\n\t" \
-    "v_rsq_f32 v254, v254\n\t" \
+    "v_fma_f32 " SNK_V1(P4) ", " SNK_S1(Q4) ", " SNK_S1(Q4) ", 1\n\t" \
+    "v_fma_f32 " SNK_V1(P4) ", " SNK_S1(Q5) ", " SNK_S1(Q5) ", " SNK_V1(P4) "\n\t" \
+    "v_rsq_f32 " SNK_V1(P4) ", " SNK_V1(P4) "\n\t" \
     "s_nop 0\n\t" \
-    "v_mul_f32_e64 v254, %[l1], v254 clamp\n\t" \
-    "v_pk_fma_f32 v[250:251], v[254:255], s[88:89], v[250:251] op_sel_hi:[0,1,1] neg_lo:[0,1,1] neg_hi:[0,1,1]\n\t" \
-    "v_fmac_f32_dpp %[t2], %[RJ2], v250 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
-    "v_fmac_f32_dpp %[t2], %[RJ2], v251 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
-    "v_cndmask_b32_e64 v250, v251, v250, %[lowmask]\n\t" \
-    "v_readlane_b32 s88, %[t2], 31\n\t" \
-    "v_readlane_b32 s89, %[t2], 63\n\t" \
-    "v_mul_f32 v251, %[RM1], v250\n\t" \
-    SNK_ACC3163("%[RJ1]", "v250") \
-    "v_fma_f32 v254, s88, s88, 1\n\t" \
-    "v_fma_f32 v254, s89, s89, v254\n\t" \
-    "v_rsq_f32 v254, v254\n\t" \
+    "v_mul_f32_e64 " SNK_V1(P4) ", %[l1], " SNK_V1(P4) " clamp\n\t" \
+    "v_pk_fma_f32 " SNK_VP(P0, P1) ", " SNK_VP(P4, P5) ", " SNK_SP(Q4, Q5) ", " SNK_VP(P0, P1) " op_sel_hi:[0,1,1] neg_lo:[0,1,1] neg_hi:[0,1,1]\n\t" \
+    "v_fmac_f32_dpp %[t2], %[RJ2], " SNK_V1(P0) " row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+    "v_fmac_f32_dpp %[t2], %[RJ2], " SNK_V1(P1) " row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+    "v_cndmask_b32_e64 " SNK_V1(P0) ", " SNK_V1(P1) ", " SNK_V1(P0) ", %[lowmask]\n\t" \
+    "v_readlane_b32 " SNK_S1(Q4) ", %[t2], 31\n\t" \
+    "v_readlane_b32 " SNK_S1(Q5) ", %[t2], 63\n\t" \
+    "v_mul_f32 " SNK_V1(P1) ", %[RM1], " SNK_V1(P0) "\n\t" \
+    SNK_ACC3163("%[RJ1]", SNK_V1(P0)) \
+    "v_fma_f32 " SNK_V1(P4) ", " SNK_S1(Q4) ", " SNK_S1(Q4) ", 1\n\t" \
+    "v_fma_f32 " SNK_V1(P4) ", " SNK_S1(Q5) ", " SNK_S1(Q5) ", " SNK_V1(P4) "\n\t" \
+    "v_rsq_f32 " SNK_V1(P4) ", " SNK_V1(P4) "\n\t" \
     "s_nop 0\n\t" \
-    "v_mul_f32_e64 v254, %[l2], v254 clamp\n\t" \
-    "v_pk_fma_f32 v[252:253], v[254:255], s[88:89], v[252:253] op_sel_hi:[0,1,1] neg_lo:[0,1,1] neg_hi:[0,1,1]\n\t" \
-    "v_cndmask_b32_e64 v252, v253, v252, %[lowmask]\n\t" \
-    "v_mul_f32 v253, %[RM2], v252\n\t"
-#define SNK_CONE2_TAIL                           \
-    "v_add_f32 v251, v251, v253\n\t"           \
-    "v_mov_b32 v253, v251\n\t"                 \
-    SNK_ACC3163("%[RJ2]", "v252")                \
+    "v_mul_f32_e64 " SNK_V1(P4) ", %[l2], " SNK_V1(P4) " clamp\n\t" \
+    "v_pk_fma_f32 " SNK_VP(P2, P3) ", " SNK_VP(P4, P5) ", " SNK_SP(Q4, Q5) ", " SNK_VP(P2, P3) " op_sel_hi:[0,1,1] neg_lo:[0,1,1] neg_hi:[0,1,1]\n\t" \
+    "v_cndmask_b32_e64 " SNK_V1(P2) ", " SNK_V1(P3) ", " SNK_V1(P2) ", %[lowmask]\n\t" \
+    "v_mul_f32 " SNK_V1(P3) ", %[RM2], " SNK_V1(P2) "\n\t"
+#define SNK_CONE2_TAIL_(P0, P1, P2, P3, P4, P5, Q0, Q1, Q2, Q3, Q4, Q5)                           \
+    "v_add_f32 " SNK_V1(P1) ", " SNK_V1(P1) ", " SNK_V1(P3) "\n\t"           \
+    "v_mov_b32 " SNK_V1(P3) ", " SNK_V1(P1) "\n\t"                 \
+    SNK_ACC3163("%[RJ2]", SNK_V1(P2))                \
     "s_nop 0\n\t"                              \
-    "v_permlane32_swap_b32 v251, v253\n\t"     \
-    "v_add_f32 %[dv], %[dv], v251\n\t"         \
-    "v_add_f32 %[dv], %[dv], v253\n\t"
-template <bool RES>
+    "v_permlane32_swap_b32 " SNK_V1(P1) ", " SNK_V1(P3) "\n\t"     \
+    "v_add_f32 %[dv], %[dv], " SNK_V1(P1) "\n\t"         \
+    "v_add_f32 %[dv], %[dv], " SNK_V1(P3) "\n\t"
+// PIN 1: the pinned temporaries of a kernel built for three waves per SIMD (168 registers): v162..v167, s84..s89
+#define SNK_PINS_HI 250, 251, 252, 253, 254, 255, 84, 85, 86, 87, 88, 89
+#define SNK_PINS_LO 162, 163, 164, 165, 166, 167, 84, 85, 86, 87, 88, 89
+#define SNK_PINS_128 122, 123, 124, 125, 126, 127, 84, 85, 86, 87, 88, 89      /* (tools/ubench_solve.hip: four waves) */
+#define SNK_CONE2_X(M_, ...) M_(__VA_ARGS__)
+#define SNK_CONE2_ASM(RESLINE, PINS, CLOB)                                                                               \
+    asm volatile(SNK_CONE2_X(SNK_CONE2_BODY_, PINS) RESLINE SNK_CONE2_X(SNK_CONE2_TAIL_, PINS)                              \
+                 : [t1] "=&v"(t1), [t2] "=&v"(t2), [l1] "=&s"(l1), [l2] "=&s"(l2), [RJ1] "+v"(RJ1), [RJ2] "+v"(RJ2),       \
+                   [dv] "+v"(dv), [lsq] "+v"(lsq)                                                                         \
+                 : [RM1] "v"(RM1), [RM2] "v"(RM2), [RJn] "v"(RJnorm), [lowmask] "s"(lowmask)                             \
+                 : CLOB, "s84", "s85", "s86", "s87", "s88", "s89")
+template <bool RES, int PIN = 0>
 __device__ __forceinline__ void cone2_step(float& RJ1, const float RM1, float& RJ2, const float RM2, const float RJnorm,
                                            float& dv, float EPS, float E3163, unsigned long long lowmask, float& lsq) {
     float t1, t2;
@@ -1134,23 +1150,19 @@ __device__ __forceinline__ void cone2_step(float& RJ1, const float RM1, float& R
     // s[84:85] = (a1A, a1B), s[86:87] = (a2A, a2B), s[88:89] = the current pair's two sums.
     // After the body v251 = RM1 dI_1, v253 = RM2 dI_2 (lane 24 / 56: den dI of the A / B rows: the residual); ONE asm
     // statement, so that nothing can be scheduled into the pinned registers on the way
-    if (RES)
-        asm volatile(SNK_CONE2_BODY
-                     "v_max3_f32 %[lsq], %[lsq], |v251|, |v253|\n\t"
-                     SNK_CONE2_TAIL
-                     : [t1] "=&v"(t1), [t2] "=&v"(t2), [l1] "=&s"(l1), [l2] "=&s"(l2), [RJ1] "+v"(RJ1), [RJ2] "+v"(RJ2),
-                       [dv] "+v"(dv), [lsq] "+v"(lsq)
-                     : [RM1] "v"(RM1), [RM2] "v"(RM2), [RJn] "v"(RJnorm),
-                       [lowmask] "s"(lowmask)
-                     : "v250", "v251", "v252", "v253", "v254", "v255", "s84", "s85", "s86", "s87", "s88", "s89");
-    else
-        asm volatile(SNK_CONE2_BODY
-                     SNK_CONE2_TAIL
-                     : [t1] "=&v"(t1), [t2] "=&v"(t2), [l1] "=&s"(l1), [l2] "=&s"(l2), [RJ1] "+v"(RJ1), [RJ2] "+v"(RJ2),
-                       [dv] "+v"(dv)
-                     : [RM1] "v"(RM1), [RM2] "v"(RM2), [RJn] "v"(RJnorm),
-                       [lowmask] "s"(lowmask)
-                     : "v250", "v251", "v252", "v253", "v254", "v255", "s84", "s85", "s86", "s87", "s88", "s89");
+#define SNK_CLOB_HI "v250", "v251", "v252", "v253", "v254", "v255"
+#define SNK_CLOB_LO "v162", "v163", "v164", "v165", "v166", "v167"
+#define SNK_CLOB_128 "v122", "v123", "v124", "v125", "v126", "v127"
+    if constexpr (PIN == 0) {
+        if (RES) SNK_CONE2_ASM("v_max3_f32 %[lsq], %[lsq], |v251|, |v253|\n\t", SNK_PINS_HI, SNK_CLOB_HI);
+        else SNK_CONE2_ASM("", SNK_PINS_HI, SNK_CLOB_HI);
+    } else if constexpr (PIN == 1) {
+        if (RES) SNK_CONE2_ASM("v_max3_f32 %[lsq], %[lsq], |v163|, |v165|\n\t", SNK_PINS_LO, SNK_CLOB_LO);
+        else SNK_CONE2_ASM("", SNK_PINS_LO, SNK_CLOB_LO);
+    } else {
+        if (RES) SNK_CONE2_ASM("v_max3_f32 %[lsq], %[lsq], |v123|, |v125|\n\t", SNK_PINS_128, SNK_CLOB_128);
+        else SNK_CONE2_ASM("", SNK_PINS_128, SNK_CLOB_128);
+    }
 }
 
 // The four coupling scalars of cone2_step for the friction slots (S, S+1) of two consecutive contacts, written into

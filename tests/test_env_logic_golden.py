@@ -1,0 +1,168 @@
+"""The env-logic rows of SURVEY 8(a) -- a1 SnakeGymEnv.step, a2 checkBound, a3 the servo loop, a4 createAction, a7
+checkFeedback, a9 checkSnakeHeight, a10-a12 energy / reward / termination, a13 soft reset, and the SubprocVecEnv
+worker's auto-reset -- against vectors produced by EXECUTING the reference's own Python
+(tests/golden/make_env_logic_vectors.py: /root/reference/snake.py, SnakeGymEnv.py, ppo/multiprocessing_env.py::worker
+behind their injected client, which the CPU oracle answers).  What these vectors pin is the reference's control flow
+and arithmetic around stepSimulation; stepSimulation itself stays the oracle's restatement of Bullet (parity unpinned,
+DESIGN.md 3).
+
+CPU (`-m "not gpu"`): oracle/'s orc_env_step, given the state a step started from, returns the reference's clipped
+action, substep count, done flag bit for bit and its reward / observation to 1e-9 -- per step, and over whole sequences
+without re-synchronisation (the stale `_observation` of SnakeGymEnv.py:41-42 and the worker's second reset live in the
+state that is carried across steps).
+GPU (`-m gpu`): the fused HIP kernel from the same states: clipped actions, counts and dones exact (a count may differ
+by one only when the servo error ends within 1e-3 of the tolerance), rewards and observations within the float32
+tolerances of tests/test_gpu_env.py, calibrated against the float32 build of the oracle with a hard outer cap."""
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+VEC = os.path.join(HERE, "golden", "env_logic_vectors.npz")
+N = 16
+
+
+@pytest.fixture(scope="module")
+def vec():
+    d = np.load(VEC)
+    return {k: d[k] for k in d.files}
+
+
+def _params(v, i):
+    over = dict(gait=int(v["gait"][i]))
+    if np.isfinite(v["max_motor_impulse"][i]):
+        over["max_motor_impulse"] = float(v["max_motor_impulse"][i])
+    return over
+
+
+def _sequences(v):
+    """Row indices of each scenario, in order."""
+    return [np.nonzero(v["scenario"] == s)[0] for s in np.unique(v["scenario"])]
+
+
+def test_vectors_cover_the_branches(vec):
+    v = vec
+    k = v["substeps"]
+    assert (k == 0).any() and (k == 41).any() and (k == 1).any()            # loop never entered / capped / height exit
+    assert v["done"].sum() >= 10 and (v["done"] & (v["vec_mode"] == 1)).any() and (v["done"] & (v["vec_mode"] == 0)).any()
+    assert (np.abs(v["action_in"]) > 1).any() and np.abs(v["action_out"]).max() <= 1.0
+    assert set(np.unique(v["gait"])) == {0, 1, 2}
+    assert (v["reward"] == -10.0).any()                                      # the collision term alone
+    # done by obs[9] alone (no height exit): a step that ran its servo loop to the end and still terminated
+    assert (v["done"] & (k > 1)).any()
+
+
+def test_oracle_env_step_reproduces_the_reference_step_by_step(vec, oracle_mod):
+    v = vec
+    envs = {}
+    for i in range(len(v["scenario"])):
+        over = _params(v, i)
+        key = tuple(sorted(over.items()))
+        e = envs.setdefault(key, oracle_mod.OracleEnv(**over))
+        e.hard_reset()
+        e.sync(v["state"][i], v["aux"][i], v["manifold"][i])
+        A = int(v["act_dim"][i])
+        o, r, d, k, a = e.env_step(v["action_in"][i, :A].copy(), vec_mode=bool(v["vec_mode"][i]))
+        assert np.array_equal(a, v["action_out"][i, :A]), i                 # checkBound, in place
+        assert k == v["substeps"][i] and d == bool(v["done"][i]), (i, k, v["substeps"][i], d)
+        assert abs(r - v["reward"][i]) < 1e-9, (i, r, v["reward"][i])
+        assert np.abs(o - v["obs"][i]).max() < 1e-9, i
+
+
+def test_oracle_sequences_carry_the_stale_observation(vec, oracle_mod):
+    """No re-synchronisation inside a scenario: prev_x (the reference's `_observation[48]`, stale after a done in the
+    single-env seam, refreshed by the worker's reset in the VecEnv seam) must evolve as the reference's does."""
+    v = vec
+    for rows in _sequences(v):
+        i0 = rows[0]
+        e = oracle_mod.OracleEnv(**_params(v, i0))
+        e.hard_reset()
+        e.sync(v["state"][i0], v["aux"][i0], v["manifold"][i0])
+        for i in rows:
+            # (scenarios that set the state up from outside do so before their first step only)
+            assert abs(e.get_aux()[2] - v["aux"][i, N + 1]) < 1e-12, (i, e.get_aux()[2], v["aux"][i, N + 1])
+            A = int(v["act_dim"][i])
+            o, r, d, k, _ = e.env_step(v["action_in"][i, :A].copy(), vec_mode=bool(v["vec_mode"][i]))
+            assert k == v["substeps"][i] and d == bool(v["done"][i]), i
+            assert abs(r - v["reward"][i]) < 1e-9 and np.abs(o - v["obs"][i]).max() < 1e-9, i
+
+
+def test_oracle_substeps_reproduce_the_test_mode_telemetry(vec, oracle_mod):
+    """info['internal_observations'] / ['link_positions'] of test mode (SnakeGymEnv.py:43-44, snake.py:292-293): one
+    entry per substep, getObservation / getLinkPositions after it."""
+    v = vec
+    assert len(v["telemetry_rows"]) >= 3
+    for t, i in enumerate(v["telemetry_rows"]):
+        e = oracle_mod.OracleEnv(**_params(v, i))
+        e.hard_reset()
+        e.sync(v["state"][i], v["aux"][i], v["manifold"][i])
+        targets = np.zeros(N)
+        targets[1::2] = v["action_out"][i, :8] * e.params.scaling_factor          # gait 1
+        for s in range(int(v["substeps"][i])):
+            e.substep(targets)
+            assert np.abs(e.get_obs() - v["internal_observations"][t, s]).max() < 1e-12
+            lp = e.link_com_world()[1::3][:N + 1].T.reshape(-1)                     # Bullet links 0, 3, ..., 48
+            assert np.abs(lp - v["link_positions"][t, s]).max() < 1e-12
+
+
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_gpu_env_step_reproduces_the_reference(vec, pkg, oracle_mod):
+    v = vec
+    n_rows = len(v["scenario"])
+    groups = {}
+    for i in range(n_rows):
+        over = _params(v, i)
+        groups.setdefault((tuple(sorted(over.items())), int(v["vec_mode"][i])), []).append(i)
+    worst = dict(q=0.0, r=0.0, qd=[])
+    cal = dict(q=0.0, r=0.0, qd=[])
+    mism = compared = 0
+    for (key, vec_mode), rows in groups.items():
+        over = dict(key)
+        B = len(rows)
+        A = int(v["act_dim"][rows[0]])
+        st = pkg.Stepper(B, **over)
+        st.reset()
+        st.set_state(v["state"][rows], v["aux"][rows])
+        st.set_manifold(v["manifold"][rows])
+        a = np.ascontiguousarray(v["action_in"][rows][:, :A], dtype=np.float32)
+        obs, rew, done, sub = st.step(a, vec_mode=bool(vec_mode))
+        S1, X1 = st.get_state()
+        st.close()
+        # checkBound on the device buffer (SnakeGymEnv.py:82-88)
+        assert np.array_equal(a, v["action_out"][rows][:, :A].astype(np.float32))
+        e32 = oracle_mod.OracleEnv(f32=True, **over)
+        for b, i in enumerate(rows):
+            k_ref, d_ref, o_ref, r_ref = int(v["substeps"][i]), bool(v["done"][i]), v["obs"][i], float(v["reward"][i])
+            if sub[b] != k_ref or bool(done[b]) != d_ref:
+                mism += 1
+                assert abs(int(sub[b]) - k_ref) <= 1, (i, sub[b], k_ref, done[b], d_ref)
+                continue
+            compared += 1
+            if d_ref and vec_mode:
+                # the worker's reset(): the post-reset observation -- zeros, unit quaternion, the stale caches
+                assert np.all(obs[b, :2 * N] == 0) and np.all(obs[b, 3 * N:3 * N + 3] == 0)
+                assert np.all(obs[b, 3 * N + 3:3 * N + 7] == [0, 0, 0, 1])
+            worst["q"] = max(worst["q"], np.abs(obs[b, :N] - o_ref[:N]).max(), np.abs(obs[b, 3 * N:3 * N + 7] - o_ref[3 * N:3 * N + 7]).max())
+            worst["qd"].append((np.abs(obs[b, N:2 * N] - o_ref[N:2 * N]) / (1 + np.abs(o_ref[N:2 * N]))).max())
+            worst["r"] = max(worst["r"], abs(float(rew[b]) - r_ref))
+            # _observation for the next step: the terminal x in the single-env seam, the reset x behind the worker
+            want_px = 0.0 if (d_ref and vec_mode) else o_ref[3 * N]
+            assert abs(X1[b, N + 1] - want_px) < 5e-3, (i, X1[b, N + 1], want_px)
+            # calibration: the float32 build of the oracle on the same step
+            e32.hard_reset()
+            e32.sync(v["state"][i], v["aux"][i], v["manifold"][i])
+            o32, r32, d32, k32, _ = e32.env_step(v["action_in"][i, :A].copy(), vec_mode=bool(vec_mode))
+            if k32 == k_ref and d32 == d_ref:
+                cal["q"] = max(cal["q"], np.abs(o32[:N] - o_ref[:N]).max(), np.abs(o32[3 * N:3 * N + 7] - o_ref[3 * N:3 * N + 7]).max())
+                cal["qd"].append((np.abs(o32[N:2 * N] - o_ref[N:2 * N]) / (1 + np.abs(o_ref[N:2 * N]))).max())
+                cal["r"] = max(cal["r"], abs(r32 - r_ref))
+    p90, p90c = float(np.percentile(worst["qd"], 90)), float(np.percentile(cal["qd"], 90))
+    print("GPU vs the reference's own env logic (%d env-steps compared, %d boundary mismatches): worst q/pose %.2e reward %.2e "
+          "qd p90 %.2e | float32 oracle: %.2e %.2e %.2e" % (compared, mism, worst["q"], worst["r"], p90, cal["q"], cal["r"], p90c))
+    assert compared >= n_rows - max(3, n_rows // 20)
+    # float32 sensitivity of one env-step (tests/test_gpu_env.py): calibrated, with a hard outer cap next to it
+    assert worst["q"] < min(max(5e-3, 2 * cal["q"]), 2.5e-2)
+    assert worst["r"] < min(max(5e-3, 2 * cal["r"] + 2e-3), 2.5e-2)
+    assert p90 < min(max(5e-2, 2 * p90c), 0.25)
