@@ -87,11 +87,12 @@ def env_friction(global_ids, seed):
     return 0.5 + (h >> np.uint64(11)).astype(np.float64) / float(1 << 53)
 
 
-def cpu_baseline(steps=2000, warmup=20, n_links=16, friction_seed=None, hull_sides=32, contact_model=1):
+def cpu_baseline(steps=2000, warmup=20, n_links=16, friction_seed=None, hull_sides=32, contact_model=1, warm_start=0,
+                 self_collision=1, one_thread_only=False):
     """BASELINE.md row B3 / SURVEY 8(d): the float64 C++ oracle on the configs[0] action stream, timed from C++
     (oracle/snake_oracle.cpp: orc_bench_gait -- no Python in the timed loop), 1 thread and all cores, `steps`
     env-steps after `warmup` warm-up steps each.  PyBullet itself is probed at run time and reported, never
-    substituted silently."""
+    substituted silently.  one_thread_only: the short form the variants use (no all-cores leg)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as orc
     import pybullet_live
@@ -111,13 +112,25 @@ def cpu_baseline(steps=2000, warmup=20, n_links=16, friction_seed=None, hull_sid
     cores = max(1, min(nproc, quota) if quota else nproc)
     if quota is None and nproc > 64:
         cores = 64          # no quota visible: one thread per physical core of a 64-core socket at most
-    kw = dict(n_modules=n_links, hull_sides=hull_sides, contact_model=contact_model,
-              self_collision=1)     # (inert for 16 links under the gait; the device evaluates the flag for both chains)
+    # the same model switches as the GPU run (self_collision: inert for 16 links under the gait; the device evaluates
+    # the flag for both chains)
+    kw = dict(n_modules=n_links, hull_sides=hull_sides, contact_model=contact_model, self_collision=self_collision,
+              warm_start=warm_start)
 
     def mu_of(ids):
         return None if friction_seed is None else env_friction(ids, friction_seed)
     # one thread: env 0 (the canonical gait, phi_0 = 0) for `steps` env-steps
     sec1, sub1 = orc.bench_gait(1, env_phases([0]), warmup, steps, 1, mu_plane=mu_of([0]), **kw)
+    one = {"value": steps / sec1, "unit": "env-steps/s", "cores": 1, "substeps_per_s": sub1 / sec1,
+           "mean_substeps": sub1 / float(steps), "env_steps": steps, "seconds": sec1}
+    pb_note = ("a PyBullet IS importable on this box: run oracle/pybullet_live.py to pin the oracle against it"
+               if have_pb else "`import pybullet` fails on this box, probed at run time")
+    fr_note = "" if friction_seed is None else ", plane friction U[0.5,1.5) seed %d" % friction_seed
+    if one_thread_only:
+        one.update({"kind": "port", "cpu_model": _cpu_model(), "n_links": n_links,
+                    "sample": "float64 C++ oracle (oracle/; %s), gait stream of BASELINE configs[0]%s, one thread: env 0 x %d "
+                              "env-steps after %d warm-up steps (%.1f s)" % (pb_note, fr_note, steps, warmup, sec1)})
+        return one
     # all cores: one env per core, the same number of env-steps in total (at least 20 batched steps)
     per = max(20, -(-steps // cores))
     ids = np.arange(cores)
@@ -126,16 +139,138 @@ def cpu_baseline(steps=2000, warmup=20, n_links=16, friction_seed=None, hull_sid
         "value": cores * per / secN, "unit": "env-steps/s", "cores": cores, "kind": "port",
         "sample": "float64 C++ oracle (oracle/, restates PyBullet's pipeline; %s), gait stream of BASELINE configs[0]%s, "
                   "timed inside C++ after %d warm-up steps: all cores = %d envs x %d env-steps on %d threads (%.1f s); "
-                  "one thread = env 0 x %d env-steps (%.1f s)" % (
-                      "a PyBullet IS importable on this box: run oracle/pybullet_live.py to pin the oracle against it"
-                      if have_pb else "`import pybullet` fails on this box, probed at run time",
-                      "" if friction_seed is None else ", plane friction U[0.5,1.5) seed %d" % friction_seed,
-                      warmup, cores, per, cores, secN, steps, sec1),
+                  "one thread = env 0 x %d env-steps (%.1f s)" % (pb_note, fr_note, warmup, cores, per, cores, secN, steps, sec1),
         "substeps_per_s": subN / secN, "mean_substeps": subN / float(cores * per),
-        "one_thread": {"value": steps / sec1, "unit": "env-steps/s", "cores": 1, "substeps_per_s": sub1 / sec1,
-                       "mean_substeps": sub1 / float(steps), "env_steps": steps, "seconds": sec1},
+        "one_thread": one,
         "cpu_model": _cpu_model(), "nproc": nproc, "cgroup_cpu_quota": quota, "n_links": n_links,
     }
+
+
+# --------------------------------------------------------------------------------------
+# roofline block: algorithmic bytes over the HIP-event launch time, + what the committed rocprofv3 summaries of this
+# configuration say (PMC counters need the profiler around the process: replayed, and labelled so)
+# --------------------------------------------------------------------------------------
+# tools/ubench_solve.hip (round 4, profiles/r04_ubench_solve.txt): the row steps of the register-resident solve -- the
+# instruction mix that is 82 % of this kernel's VALU instructions -- saturate a SIMD at this rate from two waves per
+# SIMD on (0.241 at two, 0.247 at four; one wave alone 0.20), although a plain v_fma stream issues every 2 clocks
+SOLVE_MIX_VALU_PER_CLK_PER_SIMD = 0.247
+N_SIMDS = 1024
+
+
+def profile_replay(cfg_key):
+    import glob
+    traffic = traffic_src = valu = None
+    try:
+        # (round 3 changed the default contact model: summaries of earlier rounds describe other kernels)
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[3-9]_%s_pmc_summary.json" % cfg_key)))
+        if cands:
+            with open(cands[-1]) as f:
+                pm = json.load(f)
+            traffic = pm.get("hbm_bytes_per_launch")
+            traffic_src = os.path.relpath(cands[-1], ROOT)
+            sq = pm.get("sq_per_launch", {})
+            if sq.get("SQ_INSTS_VALU") and sq.get("GRBM_GUI_ACTIVE"):
+                # the path is VALU-bound.  GRBM_GUI_ACTIVE is summed over the 8 XCDs: / 8 = the launch's
+                # clocks; a SIMD-32 takes a wave64 VALU instruction every 2 clocks at best (MI355X_MICROARCH.md).
+                cycles = sq["GRBM_GUI_ACTIVE"] / 8.0
+                per_clk = sq["SQ_INSTS_VALU"] / (cycles * N_SIMDS)
+                valu = {"wave_insts_per_launch": sq["SQ_INSTS_VALU"], "launch_clocks": cycles,
+                        "valu_per_clk_per_simd": per_clk,
+                        "valu_pipe_frac": 2.0 * per_clk,
+                        "valu_pipe_frac_note": "SQ_INSTS_VALU x 2 clocks / (launch clocks x 1024 SIMDs): the fraction of the "
+                                               "2-clock issue slots a plain v_fma stream could fill",
+                        "solve_mix_ceiling_valu_per_clk_per_simd": SOLVE_MIX_VALU_PER_CLK_PER_SIMD,
+                        "frac_of_solve_mix_ceiling": per_clk / SOLVE_MIX_VALU_PER_CLK_PER_SIMD,
+                        "valu_active_per_wave": pm.get("derived", {}).get("valu_active_fraction_of_wave_cycles"),
+                        "profiled_kernel_ms": pm.get("kernel_trace_average_ms")}
+    except Exception:  # noqa: BLE001
+        pass
+    return traffic, traffic_src, valu
+
+
+def roofline_block(NL, E, K, local_sub, kernel_ms, kcount, cfg_key):
+    per_sub = BYTES_PER_SUBSTEP if NL == 16 else 744
+    per_env = BYTES_PER_ENVSTEP if NL == 16 else 64 + 416 + 4 + 1 + 4
+    alg_bytes_launch = (local_sub * per_sub + E * K * per_env) / K
+    achieved = alg_bytes_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+    traffic, traffic_src, valu = profile_replay(cfg_key)
+    return {
+        "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+        "traffic_note": "HBM bytes per launch from separate rocprofv3 --pmc passes of this configuration, "
+                        "replayed from the committed summary (not collected in this run)",
+        "kernel": "env_step_sched_kernel<%d> (+ its plan kernel)" % NL, "kernel_ms": kernel_ms, "launches": kcount,
+        "algorithmic_bytes_per_launch": alg_bytes_launch,
+        "valu_replayed_from_profile": valu,
+        # measured bytes over the profiled launch's duration: what the memory system actually carried
+        "traffic_rate_GBps_profiled": (traffic / (valu["profiled_kernel_ms"] * 1e-3) / 1e9
+                                       if (traffic and valu and valu.get("profiled_kernel_ms")) else None),
+        "note": ("recurrence-bound path: ~1e3 flop per algorithmic byte; the HBM fraction is reported as the contract asks, "
+                 "it is not the limiter: the VALU issue rate of the solve's instruction mix is "
+                 "(valu_replayed_from_profile, DESIGN.md 5)") if NL == 16 else
+                ("38 velocity components do not fit the register-resident solve: the constraint rows stream from memory "
+                 "50 times per substep, and THAT stream bounds this kernel (traffic_rate_GBps_profiled against the "
+                 "8 TB/s peak); the algorithmic-byte fraction above is reported as the contract asks (DESIGN.md 8)"),
+    }
+
+
+def histogram_summary(stepper):
+    """Contact points per physics substep since the last reset of the counters (snk_contact_histogram)."""
+    h = stepper.contact_histogram(reset=True).astype(np.int64)
+    n = int(h.sum())
+    if n == 0:
+        return None
+    c = np.cumsum(h)
+    out = {"substeps": n, "mean": float((h * np.arange(len(h))).sum() / n)}
+    for p in (50, 90, 99):
+        out["p%d" % p] = int(np.searchsorted(c, p / 100.0 * n))
+    out["max"] = int(np.nonzero(h)[0].max())
+    return out
+
+
+def measure_variant(pkg, torch, dev, device_index, E, NL, K, W, friction_seed=None, cpu_steps=0, cfg_key=None, **params):
+    """One more single-GPU configuration, after and outside the headline's timed region: K batched env-steps after W
+    warm-up steps on its own handle, HIP-event kernel time, roofline block, and (cpu_steps > 0) the one-thread leg of
+    the CPU baseline on the same configuration."""
+    A = NL // 2
+    env = pkg.DeviceVecEnv(E, device_index=device_index, n_modules=NL, **params)
+    if friction_seed is not None:
+        env.set_ground_friction(env_friction(np.arange(E), friction_seed).astype(np.float32))
+    gids = np.arange(E)
+    acts = torch.empty((W + K, E, A), dtype=torch.float32, device=dev)
+    for j in range(W + K):
+        acts[j] = torch.from_numpy(gait_actions(gids, j, A).astype(np.float32)).to(dev)
+    env.reset()
+    sub = torch.zeros((), dtype=torch.int64, device=dev)
+    for j in range(W):
+        env.step(acts[j])
+    torch.cuda.synchronize()
+    env.stepper.contact_histogram(reset=True)
+    env.stepper.timing_enable(K)
+    t0 = time.perf_counter()
+    for j in range(W, W + K):
+        env.step(acts[j])
+        sub.add_(env.substeps.sum())
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    kernel_ms, kcount = env.stepper.timing_read()
+    nsub = float(sub.item())
+    ov = env.stepper.contact_overflow()
+    out = {"value": E * K / el, "unit": "env-steps/s", "steps": K, "warmup": W, "ms_per_step": 1e3 * el / K,
+           "n_links": NL, "friction_seed": friction_seed, "substeps_per_s": nsub / el,
+           "mean_substeps_per_env_step": nsub / (E * K),
+           "contact_overflow": {"substeps_on_streamed_rows": ov[0], "points_without_rows": ov[1],
+                                "link_link_or_obstacle_without_rows": ov[2]},
+           "contacts_per_substep": histogram_summary(env.stepper),
+           "roofline": roofline_block(NL, E, K, nsub, kernel_ms, kcount, cfg_key) if cfg_key else None}
+    out.update({k: v for k, v in params.items()})
+    env.close()
+    del acts
+    if cpu_steps > 0:
+        out["cpu_baseline"] = cpu_baseline(steps=cpu_steps, warmup=5, n_links=NL, friction_seed=friction_seed,
+                                           hull_sides=params.get("hull_sides", 32), contact_model=params.get("contact_model", 1),
+                                           self_collision=params.get("self_collision", 1), one_thread_only=True)
+    return out
 
 
 def main():
@@ -187,8 +322,11 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # C++ threads inside this process (no fork): safe before or after GPU initialisation, profiler or not
-        cpu = cpu_baseline(steps=args.cpu_steps, n_links=args.links, friction_seed=args.friction_seed,
-                           hull_sides=args.hull_sides, contact_model=args.contact_model)
+        if args.obstacle is None and not args.policy:
+            cpu = cpu_baseline(steps=args.cpu_steps, n_links=args.links, friction_seed=args.friction_seed,
+                               hull_sides=args.hull_sides, contact_model=args.contact_model, warm_start=args.warm_start,
+                               self_collision=args.self_collision)
+        # (with --obstacle / --policy the C++ gait driver would time another workload than the GPU: no baseline then)
 
     import importlib
     import torch
@@ -315,79 +453,42 @@ def main():
     # [0] substeps that went through the streamed-row solve because their contacts outgrew the register-resident one's
     # slots (16 links), [1] [2] contacts left without rows: must be zeros
     overflow = local.stepper.contact_overflow()
-    # Not the headline: the same K steps under the round-1 contact model (stateless two-point manifold on implicit
-    # cylinders), after and outside the timed region of the headline, so that the record stays comparable
-    # with the earlier rounds' numbers.
+    # Not the headline: further single-GPU measurements, after and outside its timed region (default run only).
+    #   configs3_c32 / configs4_c16_fric: BASELINE configs[3] and [4], so that the driver's record carries a timed line
+    #     for every single-GPU configuration (own K, ms_per_step, mean substeps, roofline block, one-thread CPU leg);
+    #   round1_contact_model: the stateless two-point manifold on implicit cylinders that rounds 1 and 2 measured
+    #     (self_collision 0: those rounds built no link-link rows for 16 links), keeps the record comparable.
     variants = None
+    headline_hist = histogram_summary(local.stepper) if rank == 0 else None
     if (world == 1 and not args.no_variants and not args.policy and NL == 16 and args.hull_sides == 32
-            and args.contact_model == 1 and not args.warm_start and args.friction_seed is None):
-        # (self_collision 0: rounds 1 and 2 built no link-link rows for 16 links -- under this model's 0.02-m threshold
-        #  the neighbours across a bent joint carry speculative, inert rows, and since round 3 a substep with such a pair
-        #  goes through the streamed-row solve)
-        v_env = pkg.DeviceVecEnv(E, device_index=local_rank, n_modules=NL, hull_sides=0, contact_model=0,
-                                 relative_breaking_threshold=0, self_collision=0)
-        v_env.reset()
-        v_sub = torch.zeros((), dtype=torch.int64, device=dev)
-        for j in range(W):
-            v_env.step(acts_all[j].clone())
-        torch.cuda.synchronize()
-        tv = time.perf_counter()
-        for j in range(W, W + K):
-            v_env.step(acts_all[j].clone())
-            v_sub.add_(v_env.substeps.sum())
-        torch.cuda.synchronize()
-        tv = time.perf_counter() - tv
-        variants = {"round1_contact_model": {
-            "value": E * K / tv, "unit": "env-steps/s", "hull_sides": 0, "contact_model": 0, "relative_breaking_threshold": 0,
-            "self_collision": 0,
-            "mean_substeps_per_env_step": float(v_sub.item()) / (E * K),
-            "note": "same action stream; the stateless two-point manifold on implicit cylinders that rounds 1 and 2 "
-                    "measured, instead of PyBullet's 32-gon hull import + Bullet's persistent <= 4-point manifold at "
-                    "the dispatcher's relative breaking threshold (the default since round 3, DESIGN.md 3)"}}
-        v_env.close()
+            and args.contact_model == 1 and not args.warm_start and args.friction_seed is None
+            and not args.streamed_rows and args.obstacle is None and args.self_collision == 1):
+        local.close()
+        variants = {}
+        Kv = min(K, 50)
+        variants["configs4_c16_fric"] = measure_variant(pkg, torch, dev, local_rank, E, 16, Kv, min(W, 10), friction_seed=1,
+                                                        cpu_steps=min(args.cpu_steps, 400), cfg_key="c16_fric")
+        variants["configs4_c16_fric"]["workload"] = "BASELINE configs[4]: 4096 envs x 16-link snake, ground friction mu_e ~ U[0.5,1.5) seed 1"
+        variants["configs3_c32"] = measure_variant(pkg, torch, dev, local_rank, E, 32, min(K, 20), min(W, 6),
+                                                   cpu_steps=min(args.cpu_steps, 120), cfg_key="c32")
+        variants["configs3_c32"]["workload"] = "BASELINE configs[3]: 4096 envs x 32-link snake (obs 104, action 16), flat ground"
+        v = measure_variant(pkg, torch, dev, local_rank, E, 16, Kv, min(W, 10), hull_sides=0, contact_model=0,
+                            relative_breaking_threshold=0, self_collision=0)
+        v["note"] = ("same action stream; the stateless two-point manifold on implicit cylinders that rounds 1 and 2 "
+                     "measured, instead of PyBullet's 32-gon hull import + Bullet's persistent <= 4-point manifold at "
+                     "the dispatcher's relative breaking threshold (the default since round 3, DESIGN.md 3)")
+        variants["round1_contact_model"] = v
 
     if rank == 0:
         n_env_steps = world * E * K
-        # per-launch algorithmic bytes of the dominant kernel on this rank
         local_sub = float(sub_total.item())
-        per_sub = BYTES_PER_SUBSTEP if NL == 16 else 744
-        per_env = BYTES_PER_ENVSTEP if NL == 16 else 64 + 416 + 4 + 1 + 4
-        alg_bytes_launch = (local_sub * per_sub + E * K * per_env) / K
-        achieved = alg_bytes_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-        # HBM traffic per launch comes from rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 +
-        # WRITE_SIZE, calibrated on reset_kernel), run separately and committed under profiles/
-        # rocprofv3 summaries of THIS configuration (profiles/README.md), replayed here -- they are measured in
-        # separate --pmc runs of the same command, not in this run; the key names say so.
+        # rocprofv3 summaries of THIS configuration (profiles/README.md) are replayed into the roofline block: they are
+        # measured in separate --pmc runs of the same command, not in this run; the key names say so.
         cfg_key = ("c%d" % NL) + ("_fric" if args.friction_seed is not None else "") + ("_policy" if args.policy else "") + (
             "_hull%d_cm%d" % (args.hull_sides, args.contact_model) if (args.hull_sides != 32 or args.contact_model != 1) else "") + (
             "_warm" if args.warm_start else "") + (
             "_nosc" if (NL == 32 and not args.self_collision) else "") + ("_streamed" if args.streamed_rows else "") + (
             ("_obstacle2" if args.obstacle_free else "_obstacle") if args.obstacle is not None else "")
-        traffic, traffic_src, valu = None, None, None
-        try:
-            import glob
-            # (round 3 changed the default contact model: summaries of earlier rounds describe other kernels)
-            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[3-9]_%s_pmc_summary.json" % cfg_key)))
-            if cands:
-                with open(cands[-1]) as f:
-                    pm = json.load(f)
-                traffic = pm.get("hbm_bytes_per_launch")
-                traffic_src = os.path.relpath(cands[-1], ROOT)
-                sq = pm.get("sq_per_launch", {})
-                if sq.get("SQ_INSTS_VALU") and pm.get("kernel_trace_average_ms"):
-                    # the path is VALU/latency-bound -- wave-instructions per second of the
-                    # profiled launch against the rate measured with 8 waves/SIMD of the same
-                    # instruction mix (tools/ubench_step.hip: one 28-instruction step per 65 clocks per SIMD)
-                    rate = sq["SQ_INSTS_VALU"] / (pm["kernel_trace_average_ms"] * 1e-3) / 1e9
-                    peak = 1024 * 2.4 * 28.0 / 65.0
-                    valu = {"wave_insts_per_launch": sq["SQ_INSTS_VALU"], "achieved_G_wave_insts_per_s": rate,
-                            "measured_ceiling_G_wave_insts_per_s": peak, "frac": rate / peak,
-                            "valu_active_per_wave": pm.get("derived", {}).get("valu_active_fraction_of_wave_cycles"),
-                            # two waves per SIMD share one VALU pipe: its busy fraction is what bounds this kernel
-                            "simd_valu_busy": 2.0 * (pm.get("derived", {}).get("valu_active_fraction_of_wave_cycles") or 0.0),
-                            "profiled_kernel_ms": pm["kernel_trace_average_ms"]}
-        except Exception:  # noqa: BLE001
-            pass
         cfg_index = 3 if NL == 32 else (4 if args.friction_seed is not None else (1 if world == 1 else 2))
         out = {
             "metric": "env-steps/sec (whole node), %d-link snake, 4096 envs/GPU" % NL + (
@@ -411,6 +512,9 @@ def main():
                 "warm_start": int(local.params.warm_start),
                 "contact_overflow": {"substeps_on_streamed_rows": overflow[0], "points_without_rows": overflow[1],
                                      "link_link_or_obstacle_without_rows": overflow[2]},
+                # contact points per physics substep over the timed steps of rank 0 (snk_contact_histogram): what sizes
+                # the register-resident solve's 64 slots
+                "contacts_per_substep": headline_hist,
                 "self_collision": args.self_collision if NL == 32 else
                 ("flag on: a substep with a pair of links within the breaking threshold goes through the streamed-row solve "
                  "(none under the gait: contact_overflow.substeps_on_streamed_rows)" if args.self_collision else 0),
@@ -423,25 +527,7 @@ def main():
             },
             "substeps_per_s": substeps / elapsed,
             "mean_substeps_per_env_step": substeps / n_env_steps,
-            "roofline": {
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                "traffic_note": "HBM bytes per launch from separate rocprofv3 --pmc passes of this configuration, "
-                                "replayed from the committed summary (not collected in this run)",
-                "kernel": "env_step_sched_kernel<%d> (+ its plan kernel)" % NL, "kernel_ms": kernel_ms, "launches": kcount,
-                "algorithmic_bytes_per_launch": alg_bytes_launch,
-                "valu_replayed_from_profile": valu,
-                # measured bytes over the profiled launch's duration: what the memory system actually carried
-                "traffic_rate_GBps_profiled": (traffic / (valu["profiled_kernel_ms"] * 1e-3) / 1e9
-                                               if (traffic and valu and valu.get("profiled_kernel_ms")) else None),
-                "note": ("recurrence-bound path: ~1e3 flop per algorithmic byte; the HBM fraction is "
-                         "reported as the contract asks, it is not the limiter (DESIGN.md §5)") if NL == 16 else
-                        ("38 velocity components do not fit the register-resident solve: the constraint rows (112 KB per env "
-                         "and iteration) stream from memory 50 times per substep, and THAT stream bounds this kernel "
-                         "(traffic_rate_GBps_profiled against the 8 TB/s peak; throughput flat from 6 to 8 waves/CU, "
-                         "SIMDs 57 % busy); the algorithmic-byte fraction above is reported as the contract asks "
-                         "(DESIGN.md §5)"),
-            },
+            "roofline": roofline_block(NL, E, K, local_sub, kernel_ms, kcount, cfg_key),
             "cpu_baseline": cpu,
             "variants": variants,
         }

@@ -60,6 +60,7 @@ SYMBOLS = {
     "snk_record_floats": (C.c_int32, [_vp]),
     "snk_reset": (C.c_int, [_vp, _vp, _vp, _vp]),
     "snk_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int32, _vp]),
+    "snk_step_packed": (C.c_int, [_vp, _vp, _vp, C.c_int32, _vp, C.c_int32, _vp]),
     "snk_reset_host": (C.c_int, [_vp, _U8, _F]),
     "snk_step_host": (C.c_int, [_vp, _F, _F, _F, _U8, _I32, C.c_int32]),
     "snk_substep_host": (C.c_int, [_vp, _F, C.c_int32, _I32]),
@@ -316,6 +317,11 @@ class Stepper:
     def step_device(self, actions_ptr, obs_ptr, rew_ptr, done_ptr, sub_ptr=0, vec_mode=True, stream=0):
         check(self.lib.snk_step(self.h, actions_ptr, obs_ptr, rew_ptr, done_ptr, sub_ptr or None,
                                 1 if vec_mode else 0, stream or None), "snk_step")
+
+    def step_packed_device(self, actions_ptr, packed_ptr, row_stride, sub_ptr=0, vec_mode=True, stream=0):
+        """snk_step_packed: rows [obs | reward f32 | done u32] of `row_stride` floats in one device buffer."""
+        check(self.lib.snk_step_packed(self.h, actions_ptr, packed_ptr, int(row_stride), sub_ptr or None,
+                                       1 if vec_mode else 0, stream or None), "snk_step_packed")
 
     def reset_device(self, mask_ptr=0, obs_ptr=0, stream=0):
         check(self.lib.snk_reset(self.h, mask_ptr or None, obs_ptr or None, stream or None), "snk_reset")

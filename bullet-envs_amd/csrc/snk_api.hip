@@ -71,16 +71,20 @@ struct snk_handle {
 
 namespace {
 
+// packed_stride > 0 (snk_step_packed): obs rows of that stride, reward and done flag behind each row's observation
 template <int N, bool V2>
 int launch_step(snk_handle* h, float* act, float* obs, float* rew, uint8_t* done, int32_t* sub, int vec_mode,
-                hipStream_t st) {
+                hipStream_t st, int packed_stride = 0) {
+    const int stride = packed_stride > 0 ? packed_stride : h->D.obs_dim;
+    const int packed = packed_stride > 0 ? 1 : 0;
     if (h->use_sched) {
         hipLaunchKernelGGL((snk::plan_sched_kernel<N>), dim3(1), dim3(1024), 0, st, h->d_model, h->d_recs, act, h->sched,
                            h->n_envs);
         snk::StepArgs a;
         a.recs = h->d_recs; a.mu_plane = h->d_mu; a.actions = act; a.obs = obs; a.rew = rew; a.done = done; a.substeps = sub;
         a.rows_all = h->d_rows; a.mf_all = h->d_mf; a.ovf = h->d_ovf; a.box_all = h->d_box; a.sc = h->sched;
-        a.model_slot = h->model_slot; a.vec_mode = vec_mode; a.n_envs = h->n_envs; a.pad_ = 0;
+        a.model_slot = h->model_slot; a.vec_mode = vec_mode; a.n_envs = h->n_envs;
+        a.obs_stride = stride; a.packed = packed; a.pad_ = 0;
         hipLaunchKernelGGL((snk::env_step_sched_kernel<N, V2>), dim3(h->grid_waves), dim3(64), h->lds_bytes, st, a);
         return 0;
     }
@@ -88,7 +92,8 @@ int launch_step(snk_handle* h, float* act, float* obs, float* rew, uint8_t* done
         hipLaunchKernelGGL((snk::plan_kernel<N>), dim3(1), dim3(1024), 0, st, h->d_model, h->d_recs, act, h->d_order,
                            h->n_envs);
     hipLaunchKernelGGL((snk::env_step_kernel<N, V2>), dim3(h->grid_waves), dim3(64), h->lds_bytes, st, h->d_model, h->d_recs,
-                       h->d_mu, act, obs, rew, done, sub, vec_mode, h->n_envs, h->plan ? h->d_order : nullptr, h->d_rows, h->d_mf, h->d_ovf, h->d_box);
+                       h->d_mu, act, obs, rew, done, sub, vec_mode, h->n_envs, h->plan ? h->d_order : nullptr, h->d_rows, h->d_mf, h->d_ovf, h->d_box,
+                       stride, packed);
     return 0;
 }
 template <int N, bool V2>
@@ -456,6 +461,24 @@ int snk_step(snk_handle* h, float* actions_dev, float* obs_dev, float* rew_dev, 
     const bool timed = 2 * h->ev_used + 1 < (int)h->ev.size();
     if (timed) HIP_TRY(hipEventRecord(h->ev[2 * h->ev_used], st));
     SNK_DISPATCH(h, launch_step, h, actions_dev, obs_dev, rew_dev, done_dev, substeps_dev, vec_mode, st);
+    if (timed) {
+        HIP_TRY(hipEventRecord(h->ev[2 * h->ev_used + 1], st));
+        h->ev_used++;
+    }
+    return check_launch();
+}
+
+int snk_step_packed(snk_handle* h, float* actions_dev, float* packed_dev, int32_t row_stride, int32_t* substeps_dev,
+                    int32_t vec_mode, void* stream) {
+    if (!h) return fail("snk_step_packed: null handle");
+    if (!actions_dev || !packed_dev) return fail("snk_step_packed: null buffer");
+    if (row_stride < h->D.obs_dim + 2) return fail("snk_step_packed: row_stride must be at least obs_dim + 2");
+    if (check_alarm(h)) return 1;
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream;
+    const bool timed = 2 * h->ev_used + 1 < (int)h->ev.size();
+    if (timed) HIP_TRY(hipEventRecord(h->ev[2 * h->ev_used], st));
+    SNK_DISPATCH(h, launch_step, h, actions_dev, packed_dev, nullptr, nullptr, substeps_dev, vec_mode, st, row_stride);
     if (timed) {
         HIP_TRY(hipEventRecord(h->ev[2 * h->ev_used + 1], st));
         h->ev_used++;

@@ -1778,11 +1778,13 @@ __device__ __forceinline__ void substep(LT& L, const DevModel& M0, int lane_in, 
     // contact points of this substep, counted per value (snk_contact_histogram): what decides how many row slots a
     // register-resident solve needs.  One fire-and-forget atomic per substep (every lane with its own operand, folded
     // into one memory operation: see sched_pop for why there is no `if (lane == 0)`).
+#ifndef SNK_NO_HIST      /* (A/B builds only: what the one atomic per substep costs) */
     {
         int bin = __builtin_amdgcn_readfirstlane(ncontacts);
         bin = bin < 0 ? 0 : (bin > kHistBins - 1 ? kHistBins - 1 : bin);
         atomicAdd(ovf + kOvfCounters + bin, lane_id() == 0 ? 1ull : 0ull);
     }
+#endif
 }
 
 // ----------------------------------------------------------------------------------
@@ -1918,7 +1920,7 @@ __global__ __launch_bounds__(64, 2) void env_step_kernel(const DevModel* __restr
                                                       int32_t* __restrict__ substeps, int vec_mode, int n_envs,
                                                       const int32_t* __restrict__ order, float* __restrict__ rows_all,
                                                       float* __restrict__ mf_all, unsigned long long* __restrict__ ovf,
-                                                      float* __restrict__ box_all) {
+                                                      float* __restrict__ box_all, int obs_stride, int packed) {
     extern __shared__ float4 smem_raw[];
     using LT = Lds<N, V2>;
     LT& L = *reinterpret_cast<LT*>(smem_raw);
@@ -1984,7 +1986,7 @@ __global__ __launch_bounds__(64, 2) void env_step_kernel(const DevModel* __restr
     if (!dn) dn = mean_height(L, M, lane) > M.height_thr;
     if (!dn) dn = end_height;
     if (dn) r += M.done_pen;
-    float* ob = obs + (size_t)env * (3 * N + 8);
+    float* ob = obs + (size_t)env * obs_stride;
     if (!(dn && vec_mode)) write_obs(L, ob, lane);
     lds_sync();
     if (dn) {
@@ -1996,8 +1998,13 @@ __global__ __launch_bounds__(64, 2) void env_step_kernel(const DevModel* __restr
     if (lane == 0) {
         // _observation = terminal obs (SnakeGymEnv.py:42); the worker's reset() refreshes it
         L.prev_x() = (dn && vec_mode) ? 0.0f : x;
-        rew[env] = r;
-        done[env] = dn ? 1 : 0;
+        if (packed) {       // snk_step_packed: [obs | reward | done] rows (StepArgs::packed)
+            ob[3 * N + 8] = r;
+            reinterpret_cast<uint32_t*>(ob)[3 * N + 9] = dn ? 1u : 0u;
+        } else {
+            rew[env] = r;
+            done[env] = dn ? 1 : 0;
+        }
         if (substeps) substeps[env] = counter;
     }
     store_rec(L, recs + (size_t)env * LT::REC, lane);
@@ -2373,7 +2380,11 @@ struct StepArgs {
     unsigned long long* ovf;
     float* box_all;
     Sched sc;
-    int32_t model_slot, vec_mode, n_envs, pad_;
+    int32_t model_slot, vec_mode, n_envs;
+    // obs row stride in floats (3n + 8 for the dense [n_envs x obs_dim] output).  packed != 0 (snk_step_packed): reward
+    // and done flag of env e go into its obs row, at float index obs_dim (f32) and obs_dim + 1 (u32 0 / 1), instead of
+    // rew[] / done[]: one [n_envs x stride] buffer that a sharded vector env gathers as it is (device_env.py)
+    int32_t obs_stride, packed, pad_;
 };
 typedef const StepArgs __attribute__((address_space(4))) * StepArgPtr;
 __device__ __forceinline__ StepArgPtr step_args() {
@@ -2524,7 +2535,7 @@ __global__ __launch_bounds__(64, 2) void env_step_sched_kernel(StepArgs args_by_
         if (!dn) dn = end_height;
         if (dn) r += M.done_pen;
         const int vec_mode = af->vec_mode;
-        float* ob = af->obs + (size_t)env * (3 * N + 8);
+        float* ob = af->obs + (size_t)env * af->obs_stride;
         if (!(dn && vec_mode)) write_obs(L, ob, lane);
         lds_sync();
         if (dn) {
@@ -2536,8 +2547,13 @@ __global__ __launch_bounds__(64, 2) void env_step_sched_kernel(StepArgs args_by_
         if (lane == 0) {
             // _observation = terminal obs (SnakeGymEnv.py:42); the worker's reset() refreshes it
             L.prev_x() = (dn && vec_mode) ? 0.0f : x;
-            af->rew[env] = r;
-            af->done[env] = dn ? 1 : 0;
+            if (af->packed) {
+                ob[3 * N + 8] = r;
+                reinterpret_cast<uint32_t*>(ob)[3 * N + 9] = dn ? 1u : 0u;
+            } else {
+                af->rew[env] = r;
+                af->done[env] = dn ? 1 : 0;
+            }
             int32_t* substeps = af->substeps;
             if (substeps) substeps[env] = counter;
         }

@@ -13,6 +13,8 @@ ShardedVecEnv  one process per GPU (torch.distributed, backend "nccl" = RCCL ove
 Replaces the Pipe fan-out/fan-in of SubprocVecEnv (ppo/multiprocessing_env.py:119-128).
 torch is plumbing here (device memory, streams, process groups); it computes nothing.
 """
+import types
+
 import numpy as np
 
 from . import _lib
@@ -51,6 +53,19 @@ class DeviceVecEnv(object):
         self.stepper.step_device(actions.data_ptr(), self.obs.data_ptr(), self.rew.data_ptr(),
                                  self.done.data_ptr(), self.substeps.data_ptr(), vec_mode, self._stream())
         return self.obs, self.rew, self.done
+
+    def step_packed(self, actions, packed, vec_mode=True):
+        """The same step, written by the kernel as rows [obs | reward | done] of `packed` ([E, >= O + 2] float32 on this
+        device; the done cell holds the integer 0 / 1): the block a sharded env gathers (snk_step_packed).  self.obs /
+        rew / done are NOT updated by this call.  Asynchronous."""
+        t = self.torch
+        assert actions.is_cuda and actions.dtype == t.float32 and actions.is_contiguous()
+        assert tuple(actions.shape) == (self.num_envs, self.act_dim)
+        assert packed.is_cuda and packed.dtype == t.float32 and packed.is_contiguous()
+        assert packed.shape[0] == self.num_envs and packed.shape[1] >= self.obs_dim + 2
+        self.stepper.step_packed_device(actions.data_ptr(), packed.data_ptr(), packed.shape[1], self.substeps.data_ptr(),
+                                        vec_mode, self._stream())
+        return packed
 
     def set_ground_friction(self, mu):
         self.stepper.set_ground_friction(np.asarray(mu, dtype=np.float32))
@@ -91,11 +106,11 @@ class ShardedVecEnv(object):
         if self.rank == root:
             # one preallocated [world * E, O + 2] buffer; the gather writes each rank's block into its slice
             self._all = torch.zeros((self.num_envs, self.O + 2), dtype=torch.float32, device=self._xdev)
-            self._gather = list(self._all.split(self.E, dim=0))
+            self._gather_list = list(self._all.split(self.E, dim=0))
             self._all_dev = self._all if self._xdev == self.device else torch.zeros_like(self._all, device=self.device)
             self._act_all = torch.zeros((self.num_envs, self.A), dtype=torch.float32, device=self._xdev)
         else:
-            self._gather = None
+            self._gather_list = None
         self._infos = None
 
     def __len__(self):
@@ -105,15 +120,11 @@ class ShardedVecEnv(object):
         r = self.rank if rank is None else rank
         return slice(r * self.E, (r + 1) * self.E)
 
-    def _gather_pack(self, obs, rew=None, done=None):
-        t = self.torch
-        self._pack[:, :self.O] = obs
-        if rew is not None:
-            self._pack[:, self.O] = rew
-            self._pack[:, self.O + 1] = done.to(t.float32)
-        else:
-            self._pack[:, self.O:] = 0
-        self.dist.gather(self._pack.to(self._xdev), self._gather, dst=self.root, group=self.group)
+    def _gather(self):
+        """self._pack (this rank's [E, O + 2] block) -> the root's [world * E, O + 2] buffer: the ONE collective of the
+        return path (ppo/multiprocessing_env.py:125-128 is a recv per worker)."""
+        self.dist.gather(self._pack if self._xdev == self.device else self._pack.to(self._xdev), self._gather_list,
+                         dst=self.root, group=self.group)
         if self.rank != self.root:
             return None
         if self._all_dev is not self._all:
@@ -121,7 +132,10 @@ class ShardedVecEnv(object):
         return self._all_dev
 
     def reset(self):
-        allp = self._gather_pack(self.env.reset())
+        # (a reset is once per run, not per step: the observation is copied into the block's first O columns)
+        self._pack[:, :self.O] = self.env.reset()
+        self._pack[:, self.O:] = 0
+        allp = self._gather()
         return None if allp is None else allp[:, :self.O]
 
     def step(self, actions=None):
@@ -139,13 +153,19 @@ class ShardedVecEnv(object):
             a2 = None
             chunks = None
         self.dist.scatter(self._act, chunks, src=self.root, group=self.group)
-        obs, rew, done = self.env.step(self._act.to(self.device))
-        allp = self._gather_pack(obs, rew, done)
+        # the local env writes its rows [obs | reward | done] into the block itself (DeviceVecEnv: the step kernel does,
+        # snk_step_packed): nothing is copied between the physics and the gather
+        self.env.step_packed(self._act if self._xdev == self.device else self._act.to(self.device), self._pack)
+        allp = self._gather()
         if allp is None:
             return None, None, None, ()
-        if self._infos is None:       # train mode: empty dicts (SnakeGymEnv.py:46-47); made once -- 32 768 of them per step
-            self._infos = tuple({} for _ in range(self.num_envs))      # at 8 ranks would cost the root 2 ms of every step
-        return allp[:, :self.O], allp[:, self.O], allp[:, self.O + 1] > 0.5, self._infos
+        if self._infos is None:
+            # train mode: empty dicts (SnakeGymEnv.py:46-47).  Made once -- 32 768 fresh dicts per step at 8 ranks would
+            # cost the root 2 ms of every step -- and READ-ONLY, so that a wrapper writing into infos[i] fails loudly
+            # instead of leaking its entries into every later step's infos
+            self._infos = (types.MappingProxyType({}),) * self.num_envs
+        # the done cell holds the integer 0 / 1 (its bits travel in the float32 block)
+        return allp[:, :self.O], allp[:, self.O], allp.view(t.int32)[:, self.O + 1] != 0, self._infos
 
     def close(self):
         if hasattr(self.env, "close"):

@@ -13,6 +13,8 @@ and nothing here falls back to a CPU path.
 """
 import math
 
+import types
+
 import numpy as np
 
 from . import _lib
@@ -323,7 +325,10 @@ class SnakeVecEnv(VecEnv):
         self.waiting = False
         self.last_substeps = sub
         if getattr(self, "_infos", None) is None or len(self._infos) != self.nenvs:
-            self._infos = tuple({} for _ in range(self.nenvs))      # train mode: empty dicts (SnakeGymEnv.py:46-47), made once
+            # train mode: empty dicts (SnakeGymEnv.py:46-47), made once and READ-ONLY (the reference's workers send fresh
+            # dicts every step; a wrapper that writes into infos[i] gets a TypeError here instead of seeing its entries
+            # leak into every later step)
+            self._infos = (types.MappingProxyType({}),) * self.nenvs
         return obs, rew, done, self._infos
 
     def reset(self):

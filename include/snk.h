@@ -144,6 +144,14 @@ int snk_reset(snk_handle* h, const uint8_t* mask_dev, float* obs_dev, void* stre
 int snk_step(snk_handle* h, float* actions_dev, float* obs_dev, float* rew_dev,
              uint8_t* done_dev, int32_t* substeps_dev, int32_t vec_mode, void* stream);
 
+/* The same step with ONE output buffer: packed_dev [n_envs x row_stride] f32 (row_stride >= obs_dim + 2), row e =
+ * [obs of env e (obs_dim floats) | reward (f32) | done (u32: 0 or 1) | untouched padding].  This is the block a rank of a
+ * sharded vector env sends to the trainer rank -- the reference's workers send (ob, reward, done, info) per env through
+ * their Pipe (ppo/multiprocessing_env.py:11-16, 125-128) -- written by the step kernel itself, so that no copy kernel
+ * stands between the physics and the gather (bullet-envs_amd/device_env.py: ShardedVecEnv). */
+int snk_step_packed(snk_handle* h, float* actions_dev, float* packed_dev, int32_t row_stride,
+                    int32_t* substeps_dev, int32_t vec_mode, void* stream);
+
 /* Host-buffer convenience forms (upload, run, download, synchronise). */
 int snk_reset_host(snk_handle* h, const uint8_t* mask, float* obs);
 int snk_step_host(snk_handle* h, float* actions, float* obs, float* rew, uint8_t* done,

@@ -18,7 +18,7 @@ class OrcParams(C.Structure):
         ("n_modules", C.c_int32), ("inertia_from_file", C.c_int32),
         ("default_mass", C.c_double), ("collision_margin", C.c_double),
         ("hull_sides", C.c_int32), ("contact_model", C.c_int32), ("max_contacts", C.c_int32),
-        ("self_collision", C.c_int32), ("max_self_contacts", C.c_int32), ("obstacle", C.c_int32),
+        ("self_collision", C.c_int32), ("max_self_contacts", C.c_int32), ("obstacle", C.c_int32), ("pair_manifold", C.c_int32),
         ("obstacle_pos", C.c_double * 3), ("obstacle_half", C.c_double * 3), ("mu_obstacle", C.c_double),
         ("obstacle_mass", C.c_double),
         ("dt", C.c_double), ("gravity_z", C.c_double),

@@ -35,6 +35,7 @@
 #include <limits>
 #include <mutex>
 #include <thread>
+#include <map>
 #include <vector>
 
 #ifndef ORC_REAL
@@ -204,6 +205,15 @@ struct Manifold {
     int n;
     ManifoldPoint p[4];
 };
+/* btPersistentManifold of a pair of MOVING colliders (link-link, link-box; pair_manifold 1) [U]: a cached point keeps
+ * its two witness points in the coordinates of their own bodies and the world normal it was added with. */
+struct PairPoint {
+    Real localA[3], localB[3], nB[3], dist, lambda;
+};
+struct PairManifold {
+    int n;
+    PairPoint p[4];
+};
 
 }  // namespace
 
@@ -236,6 +246,9 @@ struct orc_env {
     Real bR[9];               /* its world rotation (from bquat, refreshed by find_contacts / substep) */
     Real bI[3];               /* inertia diagonal in box axes */
     Manifold bman;            /* its persistent manifold with the plane */
+    /* pair_manifold 1: persistent manifolds of the link-link pairs (key a * 4096 + b, a < b: link indices) and of the
+     * link-box pairs (key a * 4096 + 4095) */
+    std::map<long long, PairManifold> pairs;
 };
 
 namespace {
@@ -998,6 +1011,95 @@ Real gjk_distance(const Convex& a, const Convex& b, Real* pa, Real* pb) {
     return std::sqrt(dot3(v, v));
 }
 
+/* pair_manifold 1 [U].  btCompoundCompoundCollisionAlgorithm::processCollision first refreshes the child pair's manifold
+ * (btPersistentManifold::refreshContactPoints: world points from both poses, distance = (A - B) . stored normal; then,
+ * last to first, removal of a point whose distance exceeds the breaking threshold or whose witness points have drifted
+ * apart by more than it in the contact plane), then the child's btConvexConvexAlgorithm runs GJK once and hands its one
+ * point to btManifoldResult::addContactPoint (nothing when deeper... farther than the threshold; getCacheEntry: nearest
+ * cached point in A's coordinates within the threshold -> replaceContactPoint, keeping its applied impulse; else
+ * addManifoldPoint, evicting by sortCachedPoints when four are held).  RA / oA, RB / oB: world rotation and origin of the
+ * two bodies.  Returns the manifold's points as world-space contacts through `emit`. */
+int pair_sort_cached(const PairManifold& m, const PairPoint& pt) {
+    int maxPenIdx = -1;
+    Real maxPen = pt.dist;
+    for (int i = 0; i < 4; i++)
+        if (m.p[i].dist < maxPen) { maxPenIdx = i; maxPen = m.p[i].dist; }
+    Real res[4] = {0, 0, 0, 0};
+    auto area = [&](const Real* a1, const Real* a0, const Real* b1, const Real* b0) {
+        Real a[3], b[3], c[3];
+        for (int r = 0; r < 3; r++) { a[r] = a1[r] - a0[r]; b[r] = b1[r] - b0[r]; }
+        cross3(a, b, c);
+        return dot3(c, c);
+    };
+    if (maxPenIdx != 0) res[0] = area(pt.localA, m.p[1].localA, m.p[3].localA, m.p[2].localA);
+    if (maxPenIdx != 1) res[1] = area(pt.localA, m.p[0].localA, m.p[3].localA, m.p[2].localA);
+    if (maxPenIdx != 2) res[2] = area(pt.localA, m.p[0].localA, m.p[3].localA, m.p[1].localA);
+    if (maxPenIdx != 3) res[3] = area(pt.localA, m.p[0].localA, m.p[2].localA, m.p[1].localA);
+    int best = -1;
+    Real bv = -std::numeric_limits<Real>::infinity();
+    for (int i = 0; i < 4; i++) {
+        Real v = std::fabs(res[i]);
+        if (v > bv) { bv = v; best = i; }
+    }
+    return best;
+}
+
+template <class Emit>
+void pair_manifold_update(PairManifold& m, const Real* RA, const Real* oA, const Real* RB, const Real* oB, Real thr,
+                          const Contact* fresh, Emit emit) {
+    Real wa[4][3], wb[4][3];
+    for (int j = 0; j < m.n; j++) {
+        mat3_vec(RA, m.p[j].localA, wa[j]);
+        mat3_vec(RB, m.p[j].localB, wb[j]);
+        Real d = 0;
+        for (int r = 0; r < 3; r++) { wa[j][r] += oA[r]; wb[j][r] += oB[r]; d += (wa[j][r] - wb[j][r]) * m.p[j].nB[r]; }
+        m.p[j].dist = d;
+    }
+    for (int j = m.n - 1; j >= 0; j--) {
+        bool drop = !(m.p[j].dist <= thr);
+        if (!drop) {
+            Real dd = 0;
+            for (int r = 0; r < 3; r++) {
+                const Real proj = wa[j][r] - m.p[j].nB[r] * m.p[j].dist;
+                const Real df = wb[j][r] - proj;
+                dd += df * df;
+            }
+            drop = dd > thr * thr;
+        }
+        if (drop) {
+            const int last = m.n - 1;
+            if (j != last) {
+                m.p[j] = m.p[last];
+                for (int r = 0; r < 3; r++) { wa[j][r] = wa[last][r]; wb[j][r] = wb[last][r]; }
+            }
+            m.n--;
+        }
+    }
+    if (fresh && fresh->dist <= thr) {
+        PairPoint np;
+        Real da[3], db[3];
+        for (int r = 0; r < 3; r++) { da[r] = fresh->P[r] - oA[r]; db[r] = fresh->PB[r] - oB[r]; np.nB[r] = fresh->n[r]; }
+        mat3T_vec(RA, da, np.localA);
+        mat3T_vec(RB, db, np.localB);
+        np.dist = fresh->dist;
+        np.lambda = 0;
+        int nearest = -1;
+        Real shortest = thr * thr;
+        for (int j = 0; j < m.n; j++) {
+            Real d[3] = {m.p[j].localA[0] - np.localA[0], m.p[j].localA[1] - np.localA[1], m.p[j].localA[2] - np.localA[2]};
+            const Real dd = dot3(d, d);
+            if (dd < shortest) { shortest = dd; nearest = j; }
+        }
+        int where;
+        if (nearest >= 0) { np.lambda = m.p[nearest].lambda; where = nearest; }
+        else if (m.n < 4) where = m.n++;
+        else where = pair_sort_cached(m, np);
+        m.p[where] = np;
+        for (int r = 0; r < 3; r++) { wa[where][r] = fresh->P[r]; wb[where][r] = fresh->PB[r]; }
+    }
+    for (int j = 0; j < m.n; j++) emit(j, wa[j], wb[j], m.p[j]);
+}
+
 void find_self_contacts(orc_env* e) {
     const orc_params& P = e->P;
     std::vector<int> cyl;
@@ -1021,7 +1123,10 @@ void find_self_contacts(orc_env* e) {
             const size_t b = a + delta;
             Real d[3] = {cv[a].c[0] - cv[b].c[0], cv[a].c[1] - cv[b].c[1], cv[a].c[2] - cv[b].c[2]};
             Real reach = 2 * rb + thr;
-            if (dot3(d, d) > reach * reach) continue;         /* bounding spheres */
+            const long long pkey = (long long)cv[a].link * 4096 + cv[b].link;
+            /* (a pair out of reach has no manifold: Bullet drops it with the broad-phase pair) */
+            auto culled = [&]() { if (P.pair_manifold) e->pairs.erase(pkey); };
+            if (dot3(d, d) > reach * reach) { culled(); continue; }         /* bounding spheres */
             {
                 /* a separating axis: along the line of centres the two nominal cylinders (a hull lies inside its
                  * cylinder) are at least `bound` apart; when that, less both margins, is beyond the threshold the
@@ -1035,7 +1140,7 @@ void find_self_contacts(orc_env* e) {
                         const Real c = (R[2] * d[0] + R[5] * d[1] + R[8] * d[2]) / nn;      /* axis (local z) . u */
                         ext += e->cyl_len / 2 * std::fabs(c) + e->cyl_r * std::sqrt(std::max(Real(0), 1 - c * c));
                     }
-                    if (nn - ext - 2 * mg > thr + Real(1e-5)) continue;
+                    if (nn - ext - 2 * mg > thr + Real(1e-5)) { culled(); continue; }
                 }
             }
             Real pa[3], pb[3];
@@ -1061,7 +1166,20 @@ void find_self_contacts(orc_env* e) {
                 c.dist = dist - 2 * mgx;
                 for (int r = 0; r < 3; r++) { c.P[r] = pa[r] - mgx * c.n[r]; c.PB[r] = pb[r] + mgx * c.n[r]; }
             }
-            if (c.dist < thr) e->contacts.push_back(c);
+            if (P.pair_manifold) {
+                PairManifold& pm = e->pairs[pkey];        /* (value-initialised: empty) */
+                const int la = cv[a].link, lb = cv[b].link;
+                pair_manifold_update(pm, &e->Rw[9 * la], &e->ow[3 * la], &e->Rw[9 * lb], &e->ow[3 * lb], thr, &c,
+                                     [&](int j, const Real* wa, const Real* wb, const PairPoint& pt) {
+                                         Contact k = c;
+                                         k.mpoint = -1;      /* (index into the GROUND manifolds elsewhere) */
+                                         (void)j;
+                                         k.dist = pt.dist;
+                                         for (int r = 0; r < 3; r++) { k.P[r] = wa[r]; k.PB[r] = wb[r]; k.n[r] = pt.nB[r]; }
+                                         e->contacts.push_back(k);
+                                     });
+                if (pm.n == 0) e->pairs.erase(pkey);
+            } else if (c.dist < thr) e->contacts.push_back(c);
         }
 }
 
@@ -1091,7 +1209,8 @@ void find_obstacle_contacts(orc_env* e) {
         for (int r = 0; r < 3; r++) cy.c[r] = e->ow[3 * i + r] + w[r];
         Real d[3] = {cy.c[0] - box.c[0], cy.c[1] - box.c[1], cy.c[2] - box.c[2]};
         Real reach = rb + rbox + thr;
-        if (dot3(d, d) > reach * reach) continue;
+        const long long pkey = (long long)i * 4096 + 4095;
+        if (dot3(d, d) > reach * reach) { if (P.pair_manifold) e->pairs.erase(pkey); continue; }
         Real pa[3], pb[3];
         Real dist = gjk_distance(cy, box, pa, pb);
         Real mgx = mg;
@@ -1115,7 +1234,19 @@ void find_obstacle_contacts(orc_env* e) {
         }
         if (dist < 0)
             for (int r = 0; r < 3; r++) c.PB[r] = c.P[r];
-        if (c.dist < thr) e->contacts.push_back(c);
+        if (P.pair_manifold) {
+            PairManifold& pm = e->pairs[pkey];
+            pair_manifold_update(pm, &e->Rw[9 * i], &e->ow[3 * i], e->bR, e->bpos, thr, &c,
+                                 [&](int j, const Real* wa, const Real* wb, const PairPoint& pt) {
+                                     Contact k = c;
+                                     k.mpoint = -1;
+                                     (void)j;
+                                     k.dist = pt.dist;
+                                     for (int r = 0; r < 3; r++) { k.P[r] = wa[r]; k.PB[r] = wb[r]; k.n[r] = pt.nB[r]; }
+                                     e->contacts.push_back(k);
+                                 });
+            if (pm.n == 0) e->pairs.erase(pkey);
+        } else if (c.dist < thr) e->contacts.push_back(c);
     }
 }
 
@@ -1715,6 +1846,7 @@ void orc_default_params(orc_params* p) {
     p->self_collision = 1;   /* link-link contacts (URDF_USE_SELF_COLLISION, snake.py:93): the reference's load flag */
     p->max_self_contacts = 0;
     p->obstacle = 0;
+    p->pair_manifold = 0;    /* link-link / link-box pairs: one stateless point per step, as the kernels (1: Bullet's cache) */
     p->obstacle_pos[0] = 2.0; p->obstacle_pos[1] = 0.0; p->obstacle_pos[2] = 0.1;      /* snake.py:94 */
     p->obstacle_half[0] = 0.1; p->obstacle_half[1] = 0.4; p->obstacle_half[2] = 0.1;   /* snake/block.urdf:16 */
     p->mu_obstacle = 0.5;
@@ -1809,6 +1941,7 @@ void orc_hard_reset(orc_env* e) {
     e->contacts.clear();
     e->last_normal_impulse.clear();
     e->manifolds.clear();    /* resetSimulation + loadURDF: a new world (a soft reset keeps the contact cache [U]) */
+    e->pairs.clear();
     box_reset(e);
 }
 

@@ -58,6 +58,13 @@ typedef struct orc_params {
                                * the ground -- a btMultiBody without links [U]: gravity, link damping, its own
                                * persistent manifold with the plane (one support corner per step, <= 4 cached),
                                * two-body rows with the snake's links                                            */
+    int32_t pair_manifold;    /* 0 (default): link-link and link-box contacts are ONE stateless point per pair per step
+                               * (deviations 1-2, shared with the kernels).  1: Bullet's own bookkeeping
+                               * for those pairs too [U] -- a btPersistentManifold of <= 4 points per pair: refreshed
+                               * from both poses (distance along the stored normal; removed when separated or drifted
+                               * beyond the breaking threshold), then this step's GJK point merged in (getCacheEntry /
+                               * replaceContactPoint / addManifoldPoint with sortCachedPoints).  Oracle only: measures
+                               * what the deviation is worth (tests/test_oracle_pair_manifold.py)                */
     double  obstacle_pos[3];  /* centre [2, 0, 0.1]                                                            */
     double  obstacle_half[3]; /* half extents [0.1, 0.4, 0.1] (block.urdf:16)                                  */
     double  mu_obstacle;      /* 0.5 [U]                                                                       */

@@ -39,6 +39,16 @@ class OracleLocalEnv:
                 t.tensor(d, dtype=t.uint8))
 
 
+    def step_packed(self, actions, packed):
+        """The form ShardedVecEnv calls: rows [obs | reward | done (integer bits)] written by the local env itself."""
+        o, r, d = self.step(actions)
+        O = self.obs_dim
+        packed[:, :O] = o
+        packed[:, O] = r
+        packed.view(self.torch.int32)[:, O + 1] = d.to(self.torch.int32)
+        return packed
+
+
 def _actions(j, n):
     k = np.arange(8)
     a = (-np.sin((2 * k[None, :] + 1) * 4.0 + 0.2 * j + 0.7 * np.arange(n)[:, None])).astype(np.float32)

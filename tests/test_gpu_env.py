@@ -696,3 +696,36 @@ def test_test_mode_telemetry_follows_overridden_parameters(pkg):
     q = info['internal_observations'][-1][:16]
     assert np.abs(q[1::2]).max() < 1e-3 and np.abs(q[0::2]).max() > 0.05          # gait 0 drives the even slots
     env.close()
+
+
+@pytest.mark.parametrize("quantum", ["1", "0"])
+def test_step_packed_matches_step(pkg, monkeypatch, quantum):
+    """snk_step_packed (rows [obs | reward | done u32 | padding] written by the step kernel, what ShardedVecEnv gathers)
+    against snk_step from the same state: bit for bit, padding untouched; scheduled and unscheduled kernels."""
+    import torch
+    monkeypatch.setenv("SNK_QUANTUM", quantum)
+    B, O = 96, 56
+    env = pkg.DeviceVecEnv(B)
+    env.reset()
+    for j in range(3):
+        env.step(torch.tensor(gait(range(B), j)).cuda())
+    torch.cuda.synchronize()
+    S, X = env.stepper.get_state()
+    M = env.stepper.get_manifold()
+    a = torch.tensor(gait(range(B), 3) * np.float32(1.3)).cuda()       # (some components leave [-1, 1]: clipped in place)
+    a1 = a.clone()
+    o, r, d = env.step(a1)
+    torch.cuda.synchronize()
+    o, r, d, sub = o.clone(), r.clone(), d.clone(), env.substeps.clone()
+    env.stepper.set_state(S, X)
+    env.stepper.set_manifold(M)
+    packed = torch.full((B, O + 5), float("nan"), device="cuda")
+    a2 = a.clone()
+    env.step_packed(a2, packed)
+    torch.cuda.synchronize()
+    assert torch.equal(a1, a2) and float(a2.abs().max()) <= 1.0
+    assert torch.equal(packed[:, :O], o) and torch.equal(packed[:, O], r)
+    assert torch.equal(packed.view(torch.int32)[:, O + 1], d.to(torch.int32))
+    assert bool(torch.isnan(packed[:, O + 2:]).all()) and torch.equal(env.substeps, sub)
+    assert int(d.sum()) > 0 or int(sub.max()) > 0
+    env.close()
