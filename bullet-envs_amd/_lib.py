@@ -85,6 +85,7 @@ SYMBOLS = {
     "snk_timing_enable": (C.c_int, [_vp, C.c_int32]),
     "snk_timing_read": (C.c_int, [_vp, _D, _I32]),
     "snk_model_describe": (C.c_int, [_vp, _D, _D]),
+    "snk_params_derived": (C.c_int, [C.c_void_p, _D]),
     "snk_last_error": (C.c_char_p, []),
 }
 

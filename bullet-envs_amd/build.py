@@ -19,37 +19,71 @@ def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp", ".h")))
 
 
-def needs_build():
+# The flags every build of the translation unit uses (tools/dbg/loop_spills.sh asks for them: `build.py --print-flags`).
+# -greedy-regclass-priority-trumps-globalness: the register-resident solve keeps 192 row registers + 16 motor columns
+# alive across its loop; with the allocator's default priorities 4-12 of them ended up in scratch memory, reloaded
+# in EVERY Gauss-Seidel iteration, and which ones changed with every edit of unrelated code (round 3: 314 k ...
+# 341 k env-steps/s for the same arithmetic).  With this priority rule: two reloads per iteration, 342.8 k.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-mllvm",
+         "-greedy-regclass-priority-trumps-globalness=1"]
+
+
+def _hipcc():
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    return hipcc if os.path.exists(hipcc) else "hipcc"
+
+
+def _command(out, defines=(), extra=()):
+    return [_hipcc()] + FLAGS + ["-shared", "-fPIC", os.path.join(CSRC, "snk_api.hip"), "-o", out] + \
+        ["-D" + d for d in defines] + list(extra)
+
+
+def _stamp(out):
+    return out + ".cmd"
+
+
+def needs_build(cmd=None):
+    """Stale when a source is newer than the library -- or when the library was built by ANOTHER command line (other
+    flags or -D defines: mtimes cannot see that, and a libsnk.so from an experiment would travel to the GPU box as the
+    product).  The command of the last build is kept next to the library (libsnk.so.cmd, git-ignored with it)."""
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(d) > t for d in sources() + [HEADER, os.path.abspath(__file__)])
+    if any(os.path.getmtime(d) > t for d in sources() + [HEADER, os.path.abspath(__file__)]):
+        return True
+    try:
+        with open(_stamp(LIB)) as f:
+            return f.read() != " ".join(cmd if cmd is not None else _command(LIB))
+    except OSError:
+        return True
 
 
 def build(force=False, verbose=False, defines=(), out=None):
-    """defines/out: instrumented variants (e.g. -DSNK_PROFILE -> libsnk_prof.so, tools/profile_phases.py)."""
-    if out is None and not defines and not force and not needs_build():
+    """defines/out: instrumented variants (e.g. -DSNK_PROFILE -> libsnk_prof.so, tools/profile_phases.py).  The default
+    output (libsnk.so) is only ever built with the default command: variants and compiler experiments (SNK_EXTRA_FLAGS)
+    need an `out` of their own."""
+    extra = os.environ.get("SNK_EXTRA_FLAGS", "").split()        # compiler experiments
+    if out is None and (defines or extra):
+        raise RuntimeError("bullet-envs_amd/build.py: -D defines / SNK_EXTRA_FLAGS need an output of their own (out=...): "
+                           "libsnk.so is the product and is built with the default flags only")
+    target = out or LIB
+    cmd = _command(target, defines, extra)
+    if out is None and not force and not needs_build(cmd):
         return LIB
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    if not os.path.exists(hipcc):
-        hipcc = "hipcc"
-    # -greedy-regclass-priority-trumps-globalness: the register-resident solve keeps 192 row registers + 16 motor columns
-    # alive across its loop; with the allocator's default priorities 4-12 of them ended up in scratch memory, reloaded
-    # in EVERY Gauss-Seidel iteration, and which ones changed with every edit of unrelated code (round 3: 314 k ...
-    # 341 k env-steps/s for the same arithmetic).  With this priority rule: two reloads per iteration, 342.8 k.
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-mllvm",
-           "-greedy-regclass-priority-trumps-globalness=1", "-shared", "-fPIC",
-           os.path.join(CSRC, "snk_api.hip"), "-o", out or LIB] + ["-D" + d for d in defines]
-    cmd += os.environ.get("SNK_EXTRA_FLAGS", "").split()        # compiler experiments
+    run = list(cmd)
     if verbose:
-        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
-    return out or LIB
+        run.insert(1, "-Rpass-analysis=kernel-resource-usage")
+        print(" ".join(run))
+    subprocess.check_call(run)
+    with open(_stamp(target), "w") as f:
+        f.write(" ".join(cmd))
+    return target
 
 
 if __name__ == "__main__":
-    if "--profile" in sys.argv:
+    if "--print-flags" in sys.argv:
+        print(" ".join(FLAGS))
+    elif "--profile" in sys.argv:
         print(build(force=True, defines=("SNK_PROFILE",), out=os.path.join(HERE, "libsnk_prof.so")))
     elif "--sched-debug" in sys.argv:      # per-wave accounting of the step kernel's scheduler (tools/sched_stats.py)
         print(build(force=True, defines=("SNK_SCHED_DEBUG",), out=os.path.join(HERE, "libsnk_dbg.so")))

@@ -630,7 +630,7 @@ int snk_set_manifold(snk_handle* h, const float* in) {
     for (size_t c = 0; c < ncyl; c++) {
         float* d = &dev[snk::kMfFloats * c];
         const float* o = in + 29 * c;
-        d[0] = o[0];
+        d[0] = o[0] >= 0.f ? (o[0] <= 4.f ? floorf(o[0]) : 4.f) : 0.f;      // a manifold holds 0 .. 4 points, whatever the caller says
         for (int j = 0; j < 4; j++) {
             for (int r = 0; r < 3; r++) d[4 + 6 * j + r] = o[1 + 7 * j + r];
             d[7 + 6 * j] = o[4 + 7 * j];
@@ -680,7 +680,7 @@ int snk_set_box(snk_handle* h, const float* state, const float* manifold) {
         if (state) memcpy(x, state + 13 * e, 13 * sizeof(float));
         if (manifold) {
             const float* o = manifold + 29 * e;
-            x[13] = o[0];
+            x[13] = o[0] >= 0.f ? (o[0] <= 4.f ? floorf(o[0]) : 4.f) : 0.f;      // 0 .. 4 cached points
             for (int j = 0; j < 4; j++) {
                 for (int r = 0; r < 3; r++) x[14 + 6 * j + r] = o[1 + 7 * j + r];
                 x[17 + 6 * j] = o[4 + 7 * j];
@@ -821,6 +821,17 @@ int snk_selftest(int32_t device) {
                  o[0], s22, o[1], s64, o[2], o[3], s38);
         return fail(buf);
     }
+    return 0;
+}
+
+int snk_params_derived(const snk_params* p, double* out) {
+    if (!p || !out) return fail("snk_params_derived: null argument");
+    if (p->n_modules != 16 && p->n_modules != 32) return fail("snk_params_derived: n_modules must be 16 or 32");
+    snk::HostModel H;
+    snk::DevModel D;
+    snk::build_host_model(*p, H);
+    snk::build_dev_model(*p, H, D);
+    out[0] = D.break_thr; out[1] = D.cyl_r; out[2] = D.cyl_hl; out[3] = D.cyl_zoff; out[4] = D.margin; out[5] = D.obs_thr;
     return 0;
 }
 

@@ -224,18 +224,22 @@ inline void build_dev_model(const snk_params& P, const HostModel& H, DevModel& D
     for (int i = 0; i < 3; i++) D.aniso[i] = (float)P.aniso[i];
     D.contact_erp = (float)P.contact_erp; D.slop = (float)P.linear_slop;
     D.margin = (float)P.collision_margin;
+    // the link collider's cylinder (snake.urdf:806-811, 862-867): radius, half length, centre along the link's z.  ONE set
+    // of numbers for the model, the hull's vertices and the contact threshold (tests/test_urdf_and_live.py holds them
+    // against the URDF-derived golden values)
+    const double kCylR = 0.026, kCylHL = 0.033 / 2, kCylZ = 0.0183;
+    D.cyl_r = (float)kCylR; D.cyl_hl = (float)kCylHL; D.cyl_zoff = (float)kCylZ;
     {
         // [U] btCollisionDispatcher::getNewManifold with CD_USE_RELATIVE_CONTACT_BREAKING_THRESHOLD (the dispatcher's
         // default): gContactBreakingThreshold x the smaller shape's angular-motion disc = |centre| + bounding-sphere
         // radius of its AABB.  A link collider is a compound with the cylinder's hull (margin included) 0.0183 m from
         // the link's inertial frame (snake.urdf:807,813,863,869); the plane's and the box's discs are larger.
-        const double ax = 0.026 + P.collision_margin, az = 0.033 / 2 + P.collision_margin;
-        const double disc = 0.0183 + std::sqrt(ax * ax + ax * ax + az * az);
+        const double ax = kCylR + P.collision_margin, az = kCylHL + P.collision_margin;
+        const double disc = kCylZ + std::sqrt(ax * ax + ax * ax + az * az);
         D.break_thr = (float)(P.relative_breaking_threshold ? P.breaking_threshold * disc : P.breaking_threshold);
     }
     D.warm_start = (P.warm_start && P.contact_model == 1) ? 1 : 0;
     D.warm_factor = (float)P.warmstarting_factor;
-    D.cyl_r = 0.026f; D.cyl_hl = 0.0165f;                               // snake.urdf:809
     D.hull_sides = P.hull_sides; D.contact_model = P.contact_model;
     // (link-link rows are built by the streamed-row solve; a 16-link substep with a pair of links within reach of each
     //  other goes there: snk_pgs_v2.hpp, find_contacts_v2)
@@ -255,11 +259,10 @@ inline void build_dev_model(const snk_params& P, const HostModel& H, DevModel& D
         // its manifold with the plane: the box's own angular-motion disc (|half extents|), smaller than the plane's [U]
         D.obs_thr = (float)(P.relative_breaking_threshold ? P.breaking_threshold * hn : P.breaking_threshold);
     }
-    D.cyl_zoff = 0.0183f;                                               // snake.urdf:807,863
     for (int s = 0; s < P.hull_sides && s < 32; s++) {
         const double th = 2.0 * 3.14159265358979323846 * s / P.hull_sides;
-        D.hull_xy[s][0] = (float)(0.026 * sin(th));
-        D.hull_xy[s][1] = (float)(0.026 * cos(th));
+        D.hull_xy[s][0] = (float)(kCylR * sin(th));
+        D.hull_xy[s][1] = (float)(kCylR * cos(th));
     }
     D.resid_thr = (float)P.residual_threshold;
     D.n_iter = P.n_iterations; D.cone = P.cone_friction;

@@ -341,7 +341,8 @@ __device__ __forceinline__ int manifold_load_global(const float* __restrict__ mf
         p[j].lam = f[9 + 6 * j];
         p[j].d = 0.f;
     }
-    return (int)f[0];
+    const int n = (int)f[0];
+    return n < 0 ? 0 : (n > 4 ? 4 : n);      // (manifold_core clamps as well; the count indexes registers here)
 }
 __device__ __forceinline__ void manifold_store_global(float* __restrict__ mfc, int n, const MPt (&p)[4]) {
     mf_v4 v[7];

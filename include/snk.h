@@ -241,6 +241,12 @@ int snk_selftest(int32_t device);
 int snk_timing_enable(snk_handle* h, int32_t capacity);
 int snk_timing_read(snk_handle* h, double* mean_ms, int32_t* count);
 
+/* What the kernels derive from a parameter set, without a device (host arithmetic only), for tests: out[6] =
+ * [contact breaking threshold of a (ground | link | box, link) manifold in metres (relative_breaking_threshold 1:
+ *  breaking_threshold x the link collider's angular-motion disc), collision cylinder radius, half length, centre along
+ *  the link's z (snake.urdf:806-811), collision margin, breaking threshold of the (ground, box) manifold]. */
+int snk_params_derived(const snk_params* p, double* out);
+
 /* Merged-model introspection for tests: per composite body [mass, com3, I_origin6] and
  * rest-pose world origins.  out_bodies [(n+1) x 10], out_origins [(n+1) x 3] (host). */
 int snk_model_describe(const snk_handle* h, double* out_bodies, double* out_origins);

@@ -6,7 +6,8 @@
 # Compiles with build.py's flags into /tmp/snk_loop; extra arguments go to hipcc (compiler experiments).
 here=$(cd "$(dirname "$0")" && pwd)
 out=/tmp/snk_loop; mkdir -p $out
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -mllvm -greedy-regclass-priority-trumps-globalness=1 \
+flags=$(python3 "$here/../../bullet-envs_amd/build.py" --print-flags)     # the product's own flags, from one place
+/opt/rocm/bin/hipcc $flags \
     --cuda-device-only -S "$@" "$here/one_kernel.hip" -o $out/k.s -Rpass-analysis=kernel-resource-usage 2> $out/k.log
 grep -E "VGPRs Spill|SGPRs Spill|ScratchSize|  VGPRs:" $out/k.log | sed 's/.*remark: *//' | tr '\n' ' '; echo
 python3 "$here/loop_spills.py" $out/k.s
