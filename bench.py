@@ -214,8 +214,24 @@ def roofline_block(NL, E, K, local_sub, kernel_ms, kcount, cfg_key):
     }
 
 
+HIST_STEPS = 10      # env-steps of the (untimed) pass that counts contact points per substep
+
+
+def histogram_pass(env, torch, acts):
+    """Contact points per physics substep (snk_contact_histogram) over len(acts) more env-steps, AFTER and outside the
+    timed region: the counting costs one atomic per substep (0.7 % of the rate), so it is off while anything is timed."""
+    st = env.stepper
+    st.contact_histogram_enable(True)
+    st.contact_histogram(reset=True)
+    for a in acts:
+        env.step(a)
+    torch.cuda.synchronize()
+    out = histogram_summary(st)
+    st.contact_histogram_enable(False)
+    return out
+
+
 def histogram_summary(stepper):
-    """Contact points per physics substep since the last reset of the counters (snk_contact_histogram)."""
     h = stepper.contact_histogram(reset=True).astype(np.int64)
     n = int(h.sum())
     if n == 0:
@@ -237,15 +253,14 @@ def measure_variant(pkg, torch, dev, device_index, E, NL, K, W, friction_seed=No
     if friction_seed is not None:
         env.set_ground_friction(env_friction(np.arange(E), friction_seed).astype(np.float32))
     gids = np.arange(E)
-    acts = torch.empty((W + K, E, A), dtype=torch.float32, device=dev)
-    for j in range(W + K):
+    acts = torch.empty((W + K + HIST_STEPS, E, A), dtype=torch.float32, device=dev)
+    for j in range(W + K + HIST_STEPS):
         acts[j] = torch.from_numpy(gait_actions(gids, j, A).astype(np.float32)).to(dev)
     env.reset()
     sub = torch.zeros((), dtype=torch.int64, device=dev)
     for j in range(W):
         env.step(acts[j])
     torch.cuda.synchronize()
-    env.stepper.contact_histogram(reset=True)
     env.stepper.timing_enable(K)
     t0 = time.perf_counter()
     for j in range(W, W + K):
@@ -256,12 +271,13 @@ def measure_variant(pkg, torch, dev, device_index, E, NL, K, W, friction_seed=No
     kernel_ms, kcount = env.stepper.timing_read()
     nsub = float(sub.item())
     ov = env.stepper.contact_overflow()
+    hist = histogram_pass(env, torch, [acts[j] for j in range(W + K, W + K + HIST_STEPS)])
     out = {"value": E * K / el, "unit": "env-steps/s", "steps": K, "warmup": W, "ms_per_step": 1e3 * el / K,
            "n_links": NL, "friction_seed": friction_seed, "substeps_per_s": nsub / el,
            "mean_substeps_per_env_step": nsub / (E * K),
            "contact_overflow": {"substeps_on_streamed_rows": ov[0], "points_without_rows": ov[1],
                                 "link_link_or_obstacle_without_rows": ov[2]},
-           "contacts_per_substep": histogram_summary(env.stepper),
+           "contacts_per_substep": hist,
            "roofline": roofline_block(NL, E, K, nsub, kernel_ms, kcount, cfg_key) if cfg_key else None}
     out.update({k: v for k, v in params.items()})
     env.close()
@@ -459,7 +475,11 @@ def main():
     #   round1_contact_model: the stateless two-point manifold on implicit cylinders that rounds 1 and 2 measured
     #     (self_collision 0: those rounds built no link-link rows for 16 links), keeps the record comparable.
     variants = None
-    headline_hist = histogram_summary(local.stepper) if rank == 0 else None
+    headline_hist = None
+    if rank == 0 and world == 1 and not args.policy:
+        # (an untimed pass of its own, the gait stream carried on)
+        more = [torch.from_numpy(gait_actions(np.arange(E), W + K + j, A).astype(np.float32)).to(dev) for j in range(HIST_STEPS)]
+        headline_hist = histogram_pass(local, torch, more)
     if (world == 1 and not args.no_variants and not args.policy and NL == 16 and args.hull_sides == 32
             and args.contact_model == 1 and not args.warm_start and args.friction_seed is None
             and not args.streamed_rows and args.obstacle is None and args.self_collision == 1):
@@ -512,8 +532,8 @@ def main():
                 "warm_start": int(local.params.warm_start),
                 "contact_overflow": {"substeps_on_streamed_rows": overflow[0], "points_without_rows": overflow[1],
                                      "link_link_or_obstacle_without_rows": overflow[2]},
-                # contact points per physics substep over the timed steps of rank 0 (snk_contact_histogram): what sizes
-                # the register-resident solve's 64 slots
+                # contact points per physics substep (snk_contact_histogram) over HIST_STEPS further env-steps, counted after
+                # the timed region: what sizes the register-resident solve's 64 slots
                 "contacts_per_substep": headline_hist,
                 "self_collision": args.self_collision if NL == 32 else
                 ("flag on: a substep with a pair of links within the breaking threshold goes through the streamed-row solve "

@@ -254,6 +254,7 @@ int init_handle(snk_handle* h, const snk_params* p, int32_t n_envs, int32_t devi
     // whatever was there, so that a read of something never written shows in the outputs
     const bool poison = getenv("SNK_POISON") != nullptr;
     h->D.poison = poison ? 1 : 0;
+    h->D.hist = 0;
     h->rec = h->D.rec_floats;
     // 16 links: the register-resident solve (the obstacle's contacts take slots out of the ground's 64).
     // SNK_FORCE_STREAMED=1 (diagnostics, tests): the streamed-row kernels for a 16-link handle too
@@ -704,6 +705,17 @@ int snk_contact_overflow(snk_handle* h, uint64_t* out) {
 }
 
 int32_t snk_contact_histogram_bins(void) { return snk::kHistBins; }
+int snk_contact_histogram_enable(snk_handle* h, int32_t on) {
+    if (!h) return fail("snk_contact_histogram_enable: null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipDeviceSynchronize());
+    h->D.hist = on ? 1 : 0;
+    HIP_TRY(hipMemcpy(h->d_model, &h->D, sizeof(snk::DevModel), hipMemcpyHostToDevice));
+    if (h->model_slot >= 0)
+        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(snk::g_models), &h->D, sizeof(snk::DevModel),
+                                  (size_t)h->model_slot * sizeof(snk::DevModel), hipMemcpyHostToDevice));
+    return 0;
+}
 int snk_contact_histogram(snk_handle* h, uint64_t* out, int32_t reset) {
     if (!h || !out) return fail("snk_contact_histogram: null argument");
     HIP_TRY(hipSetDevice(h->device));

@@ -1730,6 +1730,12 @@ namespace snk {
 constexpr int kOvfCounters = 3;
 constexpr int kHistBins = 320;
 
+// (defined with the record <-> LDS movers below)
+template <class LT>
+__device__ __forceinline__ void load_mf(LT& L, const float* __restrict__ mf, int lane);
+template <class LT, bool THROUGH>
+__device__ __forceinline__ void store_mf(LT& L, float* __restrict__ mf, int lane);
+
 // One out-of-line copy of the streamed-row substep for the register-resident kernels' rare substeps (below): inlined
 // there it would double those kernels; the streamed-row kernels themselves inline it (as a called function its LDS
 // accesses go through flat addresses: -10 % on those kernels when the compiler chose that by itself, round 3).
@@ -1778,13 +1784,21 @@ __device__ __forceinline__ void substep(LT& L, const DevModel& M0, int lane_in, 
     // contact points of this substep, counted per value (snk_contact_histogram): what decides how many row slots a
     // register-resident solve needs.  One fire-and-forget atomic per substep (every lane with its own operand, folded
     // into one memory operation: see sched_pop for why there is no `if (lane == 0)`).
-#ifndef SNK_NO_HIST      /* (A/B builds only: what the one atomic per substep costs) */
+    // Off unless snk_contact_histogram_enable asked for it: always on it cost 0.7 % of the headline (A/B on one box, three
+    // runs each: 361.1-362.1 k against 363.8-364.0 k env-steps/s).
+#ifndef SNK_HIST_MODE
+#define SNK_HIST_MODE 2
+#endif
+#if SNK_HIST_MODE == 2
+    if (M.hist)
+#elif SNK_HIST_MODE == 0
+    if (false)
+#endif
     {
         int bin = __builtin_amdgcn_readfirstlane(ncontacts);
         bin = bin < 0 ? 0 : (bin > kHistBins - 1 ? kHistBins - 1 : bin);
         atomicAdd(ovf + kOvfCounters + bin, lane_id() == 0 ? 1ull : 0ull);
     }
-#endif
 }
 
 // ----------------------------------------------------------------------------------

@@ -58,6 +58,7 @@ struct DevModel {
     int hull_sides, contact_model, self_collision;
     int warm_start;                      // snk_params::warm_start; warm_factor = warmstarting_factor
     int poison;                          // SNK_POISON=1 at snk_create: LDS images start as NaNs (snk_device.hpp: poison)
+    int hist;                            // snk_contact_histogram_enable: count every substep's contact points (one atomic each)
     float warm_factor;
     int obstacle;                        // a static box on the ground (snake/block.urdf), contacts through the streamed-row solve
     float obs_c[3], obs_h[3], mu_obs;    // its centre, half extents, lateral friction

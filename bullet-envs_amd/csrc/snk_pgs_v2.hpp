@@ -1649,6 +1649,13 @@ __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane_in
     // tolerance); for the third, no sampled point can move further in one substep than
     // dt * (|v| + L_chain * (|omega| + sum |qd|)): rigid rotations about the base and the joints.
     const bool sensor = sensor_pass_needed(L, M, lane, dv, hint);
+    // delta-v crosses the sensor pass in LDS (a free column of the staging rows), not in a register: the pass is full of
+    // lane-dependent regions (lane < nc, lane <= N, lane == 0), and a register copy or a scratch reload the allocator places
+    // INSIDE such a region only moves the lanes that are active there.  Round 4 met exactly that: with one more scalar
+    // live across the substep, substep_kernel<16, true> came out with delta-v's lanes 16..21 (joints 10..15) lost on the
+    // way -- those joints simply stopped moving under the single-substep API, while the fused kernels were fine
+    // (tests/test_gpu_parity.py::test_substep_api_servo_converges keeps watch).
+    L.stM[lane][20] = dv;
     float fz = L.fz(), fz3 = L.fz3();
     if (sensor) {
         // lane = contact: its force and its moment about the body's joint origin (staging rows are
@@ -1720,6 +1727,8 @@ __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane_in
         SNK_STAMP(15)
     }
     // (7) apply the solver's delta-v (lower half's copy), motor torques, integrate positions
+    lds_sync();
+    dv = L.stM[lane][20];
     if (lane < 6) {
         float x = L.base()[7 + lane] + dv;
         L.base()[7 + lane] = fminf(fmaxf(x, -M.max_vel), M.max_vel);

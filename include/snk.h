@@ -218,10 +218,13 @@ int snk_contact_overflow(snk_handle* h, uint64_t* out);
 /* How many contact points the environments held, physics substep by physics substep, since snk_create (or the last
  * reset of these counters): out[k] = substeps that ran with k contact points (ground + link-link + obstacle), the last
  * bin collecting everything beyond it.  snk_contact_histogram_bins() values (host buffer).  This is the distribution
- * that sizes the register-resident solve's row slots; counted by the step and the substep kernels alike.
- * reset != 0 zeroes the counters after reading. */
+ * that sizes the register-resident solve's row slots; counted by the step and the substep kernels alike
+ * -- while enabled (snk_contact_histogram_enable).  reset != 0 zeroes the counters after reading. */
 int32_t snk_contact_histogram_bins(void);
 int snk_contact_histogram(snk_handle* h, uint64_t* out, int32_t reset);
+/* The counting is OFF after snk_create (it costs one atomic per physics substep: 0.7 % of the headline rate) and is
+ * switched with this call; the counters keep what they hold. */
+int snk_contact_histogram_enable(snk_handle* h, int32_t on);
 
 /* BASELINE config 5: per-env lateral friction of the ground plane (reference: plane.urdf = 1). */
 int snk_set_ground_friction(snk_handle* h, const float* mu /* host [n_envs] */);

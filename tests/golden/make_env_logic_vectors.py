@@ -73,6 +73,7 @@ class OracleClient(object):
         self.n = self.e.n
         self.targets = np.zeros(self.n)
         self.calls = {}
+        self.servo_err = []
         self.snake_id = None
 
     def _count(self, name):
@@ -137,6 +138,8 @@ class OracleClient(object):
     def stepSimulation(self):
         self._count("stepSimulation")
         self.e.substep(self.targets)
+        # (for the tests' boundary checks: the servo error the reference's checkFeedback sees after this substep)
+        self.servo_err.append(float(np.linalg.norm(self.targets - self.e.get_state()[13:13 + self.n])))
 
     # read-out (snake.py:130-146, 180-206, 237-245)
     def getJointState(self, body, joint):
@@ -180,8 +183,9 @@ class Recorder(object):
         prev_x = float(env._observation[3 * e.n]) if hasattr(env, "_observation") else 0.0
         return dict(state=e.get_state(), aux=np.concatenate([tau, [fz, prev_x]]), manifold=e.get_manifold())
 
-    def add(self, scen, pre, a_in, a_out, obs, rew, done, k, vec, gait, mode, telem=None, mmi=np.inf):
-        self.rows.append(dict(scen=scen, pre=pre, mmi=float(mmi), a_in=np.array(a_in, dtype=np.float64).reshape(-1),
+    def add(self, scen, pre, a_in, a_out, obs, rew, done, k, vec, gait, mode, telem=None, mmi=np.inf, err=()):
+        assert len(err) == k, (len(err), k)
+        self.rows.append(dict(scen=scen, pre=pre, mmi=float(mmi), err=np.pad(np.array(err, dtype=np.float64), (0, 41 - len(err))), a_in=np.array(a_in, dtype=np.float64).reshape(-1),
                               a_out=np.array(a_out, dtype=np.float64).reshape(-1), obs=np.array(obs, dtype=np.float64),
                               rew=float(rew), done=bool(done), k=int(k), vec=int(vec), gait=int(gait),
                               mode=1 if mode == "test" else 0, telem=telem))
@@ -210,6 +214,7 @@ def run_single(rec, scen, actions, gait=1, mode="train", setup=None, use_args=Fa
         a = np.array(a, dtype=np.float64)
         pre = rec.pre(client, env)
         a_in = a.copy()
+        client.servo_err = []
         obs, rew, done, info = env.step(a)
         telem = None
         if mode == "test":
@@ -219,7 +224,8 @@ def run_single(rec, scen, actions, gait=1, mode="train", setup=None, use_args=Fa
             telem = (io, lp)
         else:
             assert info == {}
-        rec.add(scen, pre, a_in, a, obs, rew, done, robot.counter, 0, gait, mode, telem, client.e.params.max_motor_impulse)
+        rec.add(scen, pre, a_in, a, obs, rew, done, robot.counter, 0, gait, mode, telem, client.e.params.max_motor_impulse,
+                err=list(client.servo_err))
     return client
 
 
@@ -262,9 +268,13 @@ def run_worker(rec, scen, actions, gait=1, setup=None, params=None):
     counters = []
     real_step = env.step
 
+    errs = []
+
     def step_and_count(a):
+        client.servo_err = []
         out = real_step(a)
         counters.append(robot.counter)
+        errs.append(list(client.servo_err))
         return out
     env.step = step_and_count
     ref_mp.worker(remote, FakeRemote([], None), types.SimpleNamespace(x=lambda: env))
@@ -272,9 +282,9 @@ def run_worker(rec, scen, actions, gait=1, setup=None, params=None):
     ospace, aspace = remote.sent[-1]
     assert ospace.shape == (3 * client.n + 8,) and aspace.shape == (len(acts[0]),)
     assert len(outs) == len(acts) == len(counters)
-    for a, a_in, pre, (obs, rew, done, info), k in zip(acts, a_ins, pres, outs, counters):
+    for a, a_in, pre, (obs, rew, done, info), k, er in zip(acts, a_ins, pres, outs, counters, errs):
         assert info == {}
-        rec.add(scen, pre, a_in, a, obs, rew, done, k, 1, gait, "train", None, client.e.params.max_motor_impulse)
+        rec.add(scen, pre, a_in, a, obs, rew, done, k, 1, gait, "train", None, client.e.params.max_motor_impulse, err=er)
     return client
 
 
@@ -341,6 +351,8 @@ def main():
         "reward": np.array([r["rew"] for r in R]),
         "done": np.array([r["done"] for r in R], dtype=np.bool_),
         "substeps": np.array([r["k"] for r in R], dtype=np.int32),
+        # servo error ||target - q|| after substep 1 .. k of the step (what checkFeedback compares with 0.05, snake.py:228-235)
+        "servo_err": np.stack([r["err"] for r in R]),
     }
     tel_rows = [i for i, r in enumerate(R) if r["telem"] is not None]
     io = np.zeros((len(tel_rows), T, O))

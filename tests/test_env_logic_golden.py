@@ -117,7 +117,7 @@ def test_gpu_env_step_reproduces_the_reference(vec, pkg, oracle_mod):
         groups.setdefault((tuple(sorted(over.items())), int(v["vec_mode"][i])), []).append(i)
     worst = dict(q=0.0, r=0.0, qd=[])
     cal = dict(q=0.0, r=0.0, qd=[])
-    mism = compared = 0
+    mism = mism32 = compared = 0
     for (key, vec_mode), rows in groups.items():
         over = dict(key)
         B = len(rows)
@@ -136,8 +136,20 @@ def test_gpu_env_step_reproduces_the_reference(vec, pkg, oracle_mod):
         for b, i in enumerate(rows):
             k_ref, d_ref, o_ref, r_ref = int(v["substeps"][i]), bool(v["done"][i]), v["obs"][i], float(v["reward"][i])
             if sub[b] != k_ref or bool(done[b]) != d_ref:
+                # Legitimate only AT a decision boundary: the loop stops at the first servo error <= 0.05 (snake.py:228-235),
+                # and the vectors hold the error the reference saw after every substep.  One substep fewer than the
+                # reference: the reference's error after that substep was within a few 1e-3 above the tolerance; one more:
+                # its last error as close below.  (The bench gait ends a quarter of its env-steps that close to the
+                # tolerance; float32 round-off in q -- up to 1e-3 after thirty substeps -- decides those.)
                 mism += 1
-                assert abs(int(sub[b]) - k_ref) <= 1, (i, sub[b], k_ref, done[b], d_ref)
+                kg = int(sub[b])
+                assert abs(kg - k_ref) <= 1, (i, kg, k_ref, done[b], d_ref)
+                e_dec = float(v["servo_err"][i, min(kg, k_ref) - 1])      # the error where the two part ways
+                # (float32 round-off in the servo error grows with the substeps behind it: 4e-4 at 15, 3e-3 at 33 observed)
+                near = abs(e_dec - 0.05) < 1.5e-3 + 2e-4 * k_ref or abs(abs(o_ref[9]) - 0.5) < 1e-3
+                print("  boundary mismatch: row %d scenario %d: substeps %d / %d, done %s / %s, servo error there %.5f"
+                      % (i, v["scenario"][i], kg, k_ref, bool(done[b]), d_ref, e_dec))
+                assert near, (i, kg, k_ref, e_dec)
                 continue
             compared += 1
             if d_ref and vec_mode:
@@ -161,6 +173,8 @@ def test_gpu_env_step_reproduces_the_reference(vec, pkg, oracle_mod):
             # _observation for the next step (SnakeGymEnv.py:41-42, multiprocessing_env.py:14-15): the x of the observation
             # this step RETURNED -- the terminal one in the single-env seam, the reset one (0) behind the worker
             assert X1[b, N + 1] == obs[b, 3 * N] and (obs[b, 3 * N] == 0.0 or not (d_ref and vec_mode)), (i, X1[b, N + 1])
+            if k32 != k_ref or d32 != d_ref:
+                mism32 += 1
             if k32 == k_ref and d32 == d_ref:
                 cal["q"] = max(cal["q"], np.abs(o32[:N] - o_ref[:N]).max(), np.abs(o32[3 * N:3 * N + 7] - o_ref[3 * N:3 * N + 7]).max())
                 cal["qd"].append((np.abs(o32[N:2 * N] - o_ref[N:2 * N]) / (1 + np.abs(o_ref[N:2 * N]))).max())
@@ -168,7 +182,9 @@ def test_gpu_env_step_reproduces_the_reference(vec, pkg, oracle_mod):
     p90, p90c = float(np.percentile(worst["qd"], 90)), float(np.percentile(cal["qd"], 90))
     print("GPU vs the reference's own env logic (%d env-steps compared, %d boundary mismatches): worst q/pose %.2e reward %.2e "
           "qd p90 %.2e | float32 oracle: %.2e %.2e %.2e" % (compared, mism, worst["q"], worst["r"], p90, cal["q"], cal["r"], p90c))
-    assert compared >= n_rows - max(3, n_rows // 20)
+    print("  (the float32 oracle's own boundary mismatches among the compared rows: %d)" % mism32)
+    # every mismatch was checked to sit at a decision boundary above; their number stays in the float32 oracle's range
+    assert mism <= 2 * mism32 + 12 and compared >= n_rows * 3 // 4
     # float32 sensitivity of one env-step (tests/test_gpu_env.py): calibrated, with a hard outer cap next to it
     assert worst["q"] < min(max(5e-3, 2 * cal["q"]), 2.5e-2)
     assert worst["r"] < min(max(5e-3, 2 * cal["r"] + 2e-3), 2.5e-2)

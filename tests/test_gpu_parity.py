@@ -217,3 +217,32 @@ def test_partial_contact_sets(pkg, oracle_mod, n, model):
     assert len(set(ncs.tolist())) >= 3 and any(c % 8 for c in ncs) and any(c % 4 for c in ncs)   # really partial sets
     assert np.abs(G[:, :7] - R[:, :7]).max() < 2e-4 and np.abs(G[:, 13:13 + n] - R[:, 13:13 + n]).max() < 2e-4
     assert (np.abs(G[:, 13 + n:] - R[:, 13 + n:]) / (1 + np.abs(R[:, 13 + n:]))).max() < 2e-2
+
+
+@pytest.mark.parametrize("n", [16, 32])
+def test_substep_api_servo_converges(pkg, oracle_mod, n):
+    """snk_substep_host from the rest pose with EVERY joint commanded, one substep per call: after ten substeps every joint
+    is where the oracle's is (the position motors close 10 % of the error per substep), and ten substeps in one call end
+    on the same bits.  (Round 4: a build of substep_kernel<16, true> lost delta-v's lanes 16..21 across the sensor pass --
+    joints 10..15 stood still under this API while the fused kernels and every random-state parity test were fine.)"""
+    st = pkg.Stepper(2, n_modules=n)
+    st.reset()
+    T = np.zeros((2, n), np.float32)
+    T[0, :] = 0.2
+    T[1, 1::2] = np.linspace(-0.5, 0.5, n // 2)
+    for _ in range(10):
+        st.substep(T, 1)
+    S, _ = st.get_state()
+    one = pkg.Stepper(2, n_modules=n)
+    one.reset()
+    one.substep(T, 10)
+    S1, _ = one.get_state()
+    assert np.array_equal(S, S1)
+    for i in range(2):
+        e = oracle_mod.OracleEnv(n_modules=n)
+        e.reset()
+        for _ in range(10):
+            e.substep(T[i].astype(np.float64))
+        q = e.get_state()[13:13 + n]
+        assert np.abs(S[i, 13:13 + n] - q).max() < 2e-3, (i, S[i, 13:13 + n], q)
+        assert np.abs(S[i, 13:13 + n] - T[i] * (1 - 0.9 ** 10)).max() < 2e-2      # every joint tracks, the last one too

@@ -19,6 +19,7 @@ ids = np.arange(E)
 rng = np.random.default_rng(0)
 for j in range(10):
     st.step(bench.gait_actions(ids, j, NL // 2).astype(np.float32))
+st.contact_histogram_enable(True)
 st.contact_histogram(reset=True)
 tot_sub = 0
 for j in range(10, 10 + K):
