@@ -209,9 +209,11 @@ int snk_set_box(snk_handle* h, const float* state, const float* manifold);
  *          solved by the streamed-row solve of the same chain instead, in the same launch, with every point -- a
  *          count of slower substeps, not of lost contacts.  Streamed-row handles: always 0,
  *   out[1] manifold points that got no rows: always 0 (kept as a tripwire: the finders still count against the slots),
- *   out[2] 32-link handles: link-link / obstacle contacts beyond the room for them (32 in all; obstacle contacts are
- *          kept before link-link ones).  16-link handles: always 0 (a substep with more than the register-resident
- *          solve's eight box contacts goes through the other solve as well, which has room for every cylinder).
+ *   out[2] link-link / obstacle contacts beyond the room for them (32 in all; obstacle contacts are kept before
+ *          link-link ones): a 32-link chain can reach it; a 16-link one only when tangled beyond its joint limits with
+ *          more than 32 pairs of links touching at once (states set from outside: tests/test_gpu_accuracy_distribution.py
+ *          meets 6 in 1024 random foldings) -- a substep with more than the register-resident solve's eight box contacts
+ *          goes through the other solve, which has room for every cylinder.
  * Host buffer of 3. */
 int snk_contact_overflow(snk_handle* h, uint64_t* out);
 

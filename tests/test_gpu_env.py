@@ -665,10 +665,17 @@ def test_bench_multi_rank_rehearsal():
     import json
     import subprocess
     import sys
+    import socket
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, SNK_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    s = socket.socket()                      # a free port, from a bound socket (as tests/test_dist_gloo.py does)
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    # two ranks: with the launcher and pytest that is four processes with the GPU open, inside the box's limit of six
+    # (rehearsals with more ranks belong to the CPU gloo tests: tests/test_dist_gloo.py runs 2 / 4 / 8)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
            "--envs-per-gpu", "512"]
     out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
