@@ -203,7 +203,7 @@ def test_env_step_through_the_client_is_the_fused_kernel(pkg):
             assert errs[-1] < 0.1, (j, errs[-1])             # (a stick-slip step can amplify that last bit to 5e-2 ...
             if errs[-1] < 1e-3:                              #  ... and its impulses beyond comparing)
                 assert (np.abs(obs[0, dyn] - o[dyn]) / (1.0 + np.abs(o[dyn]))).max() < 0.1, j
-            assert abs(float(rew[0]) - r) < 1e-3
+            assert abs(float(rew[0]) - r) < (1e-3 if errs[-1] < 1e-3 else 2e-2)
             same += 1
     print("client-driven env-steps matching the fused kernel:", same, "of", compared)
     assert same >= compared - 1 and np.median(errs) < 1e-3 and sum(e >= 1e-3 for e in errs) <= 3, (same, compared, errs)
