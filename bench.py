@@ -151,9 +151,9 @@ def cpu_baseline(steps=2000, warmup=20, n_links=16, friction_seed=None, hull_sid
 # configuration say (PMC counters need the profiler around the process: replayed, and labelled so)
 # --------------------------------------------------------------------------------------
 # tools/ubench_solve.hip (round 4, profiles/r04_ubench_solve.txt): the row steps of the register-resident solve -- the
-# instruction mix that is 82 % of this kernel's VALU instructions -- saturate a SIMD at this rate from two waves per
-# SIMD on (0.241 at two, 0.247 at four; one wave alone 0.20), although a plain v_fma stream issues every 2 clocks
-SOLVE_MIX_VALU_PER_CLK_PER_SIMD = 0.247
+# instruction mix that is 82 % of this kernel's VALU instructions -- sustain this rate at the kernel's own two waves per
+# SIMD (0.20 for one wave alone, 0.253 at three, 0.255 at four), although a plain v_fma stream issues every 2 clocks
+SOLVE_MIX_VALU_PER_CLK_PER_SIMD = 0.248
 N_SIMDS = 1024
 
 

@@ -87,7 +87,9 @@ void run(const float* d_in, float* d_out, long long* d_ticks, int n_iter, int n_
     // VALU instructions of one iteration (hand count of the asm blocks): 16 motors x 4, quads 44 + 6, cone2 52 + 1
     const double valu_per_iter = 16 * 4 + (NC / 4) * 50.0 + (NC / 2) * 53.0;
     for (int w = 1; w <= WAVES; w++) {
-        const size_t lds = (size_t)(160 * 1024 / (4 * w) / 1024) * 1024;       // 4 w one-wave workgroups per CU
+        // 4 w one-wave workgroups per CU: an LDS size that lets 4 w of them in and not 4 w + 4 (one KB of slack under the
+        // even share: at exactly 160 KB / 12 a CU held only 11 and the launch ran in two rounds)
+        const size_t lds = (size_t)(160 * 1024 / (4 * w) / 1024 - (w == 3 ? 1 : 0)) * 1024;
         const int grid = n_cu * 4 * w;
         hipEvent_t e0, e1;
         CHECK(hipEventCreate(&e0));
