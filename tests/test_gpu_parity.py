@@ -246,3 +246,51 @@ def test_substep_api_servo_converges(pkg, oracle_mod, n):
         q = e.get_state()[13:13 + n]
         assert np.abs(S[i, 13:13 + n] - q).max() < 2e-3, (i, S[i, 13:13 + n], q)
         assert np.abs(S[i, 13:13 + n] - T[i] * (1 - 0.9 ** 10)).max() < 2e-2      # every joint tracks, the last one too
+
+
+@pytest.mark.parametrize("n,streamed", [(16, False), (16, True), (32, False)])
+def test_three_kernels_one_substep(pkg, monkeypatch, n, streamed):
+    """The same physics substep through the three instantiations that contain it -- the scheduled fused kernel, the
+    unscheduled fused kernel (SNK_QUANTUM=0) and the single-substep API -- from 512 random ground states with every joint
+    commanded: bit-identical states.  With max_counter = 0 a fused env-step is exactly one substep (snake.py:303's cap).
+    Each instantiation is compiled on its own; a register copy placed inside a lane-dependent region of ONE of them loses
+    lanes there and nowhere else (round 4's frozen joints), which only a cross-check like this one sees."""
+    if streamed:
+        monkeypatch.setenv("SNK_FORCE_STREAMED", "1")
+    B = 512
+    rng = np.random.default_rng(99)
+    # snakes lying flat (pitch joints at zero and commanded to stay there, yaw joints bent and commanded at random): no
+    # env-step ends in a termination, which the substep API would not act on
+    S = np.stack([random_state(rng, n, z=0.026, qamp=0.3, vamp=0.3, flat=True) for _ in range(B)]).astype(np.float32)
+    S[:, 0:3] = [0, 0, 0]
+    S[:, 7:13] *= 0.1
+    S[:, 13:13 + n:2] = 0
+    S[:, 13 + n::2] = 0
+    act = rng.uniform(-0.9, 0.9, (B, n)).astype(np.float32)       # gait 2: one action per joint
+    act[:, 0::2] = 0
+    over = dict(n_modules=n, gait=2, max_counter=0)
+    outs = []
+    for quantum in ("1", "0"):
+        monkeypatch.setenv("SNK_QUANTUM", quantum)
+        st = pkg.Stepper(B, **over)
+        st.set_state(S)
+        obs, rew, done, sub = st.step(act.copy(), vec_mode=False)
+        assert np.all(sub == 1) and not done.any()
+        outs.append((st.get_state(), st.get_manifold()))
+        st.close()
+    monkeypatch.setenv("SNK_QUANTUM", "1")
+    st = pkg.Stepper(B, **over)
+    st.set_state(S)
+    st.substep(act * np.float32(st.params.scaling_factor), 1)
+    api = (st.get_state(), st.get_manifold())
+    st.close()
+    (s0, x0), m0 = outs[0]
+    for (s1, x1), m1 in (outs[1], api):
+        assert np.array_equal(s0, s1)
+        assert np.array_equal(x0[:, :n], x1[:, :n])               # the motor torques (prev_x is the env-step's business)
+        assert np.array_equal(m0, m1)
+    # ... and every joint moved towards its target (no lane of delta-v lost anywhere)
+    yaw = slice(13 + 1, 13 + n, 2)
+    moved = (s0[:, yaw] - S[:, yaw]) * np.sign(act[:, 1::2] * st.params.scaling_factor - S[:, yaw])
+    # (per joint position in the chain: the tail's joints as much as the head's)
+    assert (np.median(moved, axis=0) > 1e-3).all() and (moved > 0).mean() > 0.9, np.median(moved, axis=0)
