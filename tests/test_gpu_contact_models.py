@@ -134,7 +134,10 @@ def test_substep_parity_under_contact_switch(pkg, oracle_mod, name, n):
     assert bad <= (B // 6 if n == 16 else B // 3)      # (the 32-link chain: twice the contacts, twice the decisions)
     # (implicit cylinders on a two-point manifold are the sensitive ones here: the float32 oracle itself is 3e-3 / 0.17
     #  off on these states after three substeps; hulls 3e-5 / 1.5e-3)
-    assert worst_p < max(5e-4, 3 * cal_p) and worst_v < max(5e-2 if n == 16 else 0.2, 3 * cal_v)
+    # (hard outer caps beside the calibrated bounds; the 32-link states of this test start with links deep in the ground:
+    #  the float32 ORACLE is 6e-2 / 1.7 off the float64 one on them)
+    cap_p, cap_v = (5e-3, 1.0) if n == 16 else (0.25, 5.0)
+    assert worst_p < min(max(5e-4, 3 * cal_p), cap_p) and worst_v < min(max(5e-2 if n == 16 else 0.2, 3 * cal_v), cap_v)
     if manifold:
         counts = st.get_manifold()[:, :, 0]
         assert counts.max() <= 4 and counts.sum() > 0
@@ -205,8 +208,8 @@ def test_manifold_parity_from_gait_states(pkg, oracle_mod, n):
     assert bad <= B // 4
     # states in motion include stick-slip ones that amplify float32 round-off: no worse than 3x the float32 oracle
     # (the velocity error is heavy-tailed and this is the maximum of two dozen samples: factor 5 on it)
-    assert worst_p < max(5e-4, 3 * cal_p) and worst_v < max(5e-2, 5 * cal_v)
-    assert worst_f < max(0.05, 3 * cal_f)
+    assert worst_p < min(max(5e-4, 3 * cal_p), 5e-3) and worst_v < min(max(5e-2, 5 * cal_v), 1.0)
+    assert worst_f < min(max(0.05, 3 * cal_f), 0.5)
     st.close()
 
 
@@ -414,7 +417,7 @@ def test_env_steps_beyond_64_contacts_match_the_oracle(pkg, oracle_mod, monkeypa
                   "points cached at the end", st.get_manifold()[:, :, 0].sum(axis=1).max())
             assert st.contact_overflow()[0] > 0 and st.contact_overflow()[1] == 0
             assert st.get_manifold()[:, :, 0].sum(axis=1).max() > 64
-            assert worst < max(2e-3, 3 * cal) and mism <= B * J // 10
+            assert worst < min(max(2e-3, 3 * cal), 2e-2) and mism <= B * J // 10
         st.close()
     monkeypatch.delenv("SNK_POISON")
     for other in (0, "poison"):
@@ -471,5 +474,5 @@ def test_thirty_two_links_at_rest_keep_every_point(pkg, oracle_mod):
     assert most > 6 * n and rows_most > 6 * n          # well past the 128 slots of the earlier builds
     assert st.contact_overflow() == (0, 0, 0)
     assert flips <= 170 * B // 8 and compared > 100 * B
-    assert worst < max(1e-3, 3 * cal)      # (one substep of a 250-contact, 32-link resting snake: float32 against float64)
+    assert worst < min(max(1e-3, 3 * cal), 1e-2)      # (one substep of a 250-contact, 32-link resting snake: float32 against float64)
     st.close()

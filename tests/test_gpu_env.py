@@ -87,14 +87,16 @@ def test_env_step_parity_resynced(pkg, oracle_mod, n):
     # (hulls on a persistent manifold of one to four points roll more easily than round 1's two end-cap points per
     #  cylinder: the float32 ORACLE itself is 1e-2 off the float64 one on the worst of these steps, so the absolute caps
     #  give way to the calibration below)
-    assert worst["q"] < max(tq, kcal * cal["q"]) and worst["r"] < max(5e-3, kcal * cal["r"])
+    # (calibrated bounds, each with a hard outer cap beside it: a defect shared by the float32 and the float64 build of
+    #  the oracle must not widen the gate with it -- ADVICE r3; the calibration values go into the printed line above)
+    assert worst["q"] < min(max(tq, kcal * cal["q"]), 5 * tq) and worst["r"] < min(max(5e-3, kcal * cal["r"]), 2.5e-2)
     assert worst["fz"] < 1.0      # sanity only: bit-exactness of the sensor is test_sensor_pass_only_when_observable
     # joint velocities: the 90th percentile within twice the float32 oracle's (every rebuild
     # re-associates FMAs, so an absolute cap on a heavy-tailed error is a coin toss), hard cap tmax
     assert p90 < max(tp90, kcal * p90c) and worst["qd"] < tmax
     assert worst["q"] < kcal * cal["q"] + 1e-4 and worst["qd"] < kcal * cal["qd"] + 1e-3
     assert worst["r"] < kcal * cal["r"] + 2e-3     # the energy term (qd x motor torque) is noisy
-    assert mism <= max(1, B * J // 20, 2 * cal_mism + 2)
+    assert mism <= min(max(1, B * J // 20, 2 * cal_mism + 2), B * J // 6)
 
 
 def test_vec_env_semantics(pkg, oracle_mod):
@@ -355,7 +357,7 @@ def test_test_mode_telemetry(pkg, oracle_mod):
             o = ref.get_obs()
             o32 = ref32.get_obs()
             cal = max(np.abs(o32[:16] - o[:16]).max(), np.abs(o32[48:55] - o[48:55]).max())
-            tol = max(2e-4 * (i + 1), 3 * cal)           # float32 drift over the substeps of one env-step
+            tol = min(max(2e-4 * (i + 1), 3 * cal), 2e-3 * (i + 1))           # float32 drift over the substeps of one env-step
             assert np.abs(info["internal_observations"][i][:16] - o[:16]).max() < tol
             assert np.abs(info["internal_observations"][i][48:55] - o[48:55]).max() < tol
             lp = info["link_positions"][i].reshape(3, 17).T

@@ -95,7 +95,7 @@ def test_coil_self_contacts_match_oracle(pkg, oracle_mod, hull):
     assert flips <= 1
     # stiff pushing contact between unlimited-force motors: float32 round-off in the GJK witness points is
     # amplified; the GPU must be no worse than three times the float32 build of the oracle on the same steps
-    assert worst_p < max(5e-4, 3 * cal_p) and worst_v < max(5e-2, 3 * cal_v)
+    assert worst_p < min(max(5e-4, 3 * cal_p), 5e-3) and worst_v < min(max(5e-2, 3 * cal_v), 1.0)
     # and they matter: without them the oracle's coil closes further
     with_sc = np.array([r.get_state()[13:13 + N] for r in refs])
     without = np.array([p.get_state()[13:13 + N] for p in plain])
