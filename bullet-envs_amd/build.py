@@ -42,6 +42,12 @@ def _stamp(out):
     return out + ".cmd"
 
 
+def _stamp_text(cmd):
+    """The command line as it is kept next to the library: paths relative to this directory, so that the copy of the tree
+    on a GPU box (another absolute path) does not look like another build."""
+    return " ".join(os.path.relpath(a, HERE) if os.path.isabs(a) and a.startswith(os.path.dirname(HERE)) else a for a in cmd)
+
+
 def needs_build(cmd=None):
     """Stale when a source is newer than the library -- or when the library was built by ANOTHER command line (other
     flags or -D defines: mtimes cannot see that, and a libsnk.so from an experiment would travel to the GPU box as the
@@ -53,7 +59,7 @@ def needs_build(cmd=None):
         return True
     try:
         with open(_stamp(LIB)) as f:
-            return f.read() != " ".join(cmd if cmd is not None else _command(LIB))
+            return f.read() != _stamp_text(cmd if cmd is not None else _command(LIB))
     except OSError:
         return True
 
@@ -76,7 +82,7 @@ def build(force=False, verbose=False, defines=(), out=None):
         print(" ".join(run))
     subprocess.check_call(run)
     with open(_stamp(target), "w") as f:
-        f.write(" ".join(cmd))
+        f.write(_stamp_text(cmd))
     return target
 
 
