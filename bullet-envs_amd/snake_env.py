@@ -109,6 +109,67 @@ class Snake(object):
     def getBaseOrientation(self):
         return tuple(self.getObservation()[3 * self.numMotors + 3:3 * self.numMotors + 7])
 
+    # --- the rest of the robot-level surface (snake.py:138-146, 180-206, 219-235, 247-306): nothing on the trainers'
+    #     path calls these, scratch scripts do (test_script.py:19-25) ---
+    def getPosition(self):
+        return self.getObservation()[0:self.numMotors]
+
+    def getVelocity(self):
+        return self.getObservation()[self.numMotors:2 * self.numMotors]
+
+    def getTorque(self):
+        return self.getObservation()[2 * self.numMotors:3 * self.numMotors]
+
+    def getForceInfo(self):                              # snake.py:202-206: reaction Fz of joint 0 (obs[55])
+        return float(self.getObservation()[3 * self.numMotors + 7])
+
+    def getLinkPositions(self):                          # snake.py:138-146: [x.., y.., z..] of links 0, 3, ..., 3n
+        return self._need_env()._stepper.link_positions()[0].astype(np.float64)
+
+    def convertActionToJointCommand(self, action):       # snake.py:223-225
+        return [a * self.SCALING_FACTOR for a in action]
+
+    def createAction(self, action):                      # snake.py:247-269
+        n = self.numMotors
+        full = [0] * n
+        slots = range(0, n, 2) if self._gaitSelection == 0 else (range(1, n, 2) if self._gaitSelection == 1 else range(n))
+        for k, i in enumerate(slots):
+            full[i] = action[k]
+        return full
+
+    def checkFeedback(self, action, observation):        # snake.py:228-235
+        n = self.numMotors
+        err = np.asarray(action[:n], dtype=np.float64) * self.SCALING_FACTOR - np.asarray(observation[:n], dtype=np.float64)
+        return bool(np.sqrt(err.dot(err)) > 0.05)
+
+    def step(self, action):
+        """Snake.step by itself (snake.py:274-306; test_script.py:25): the servo loop WITHOUT SnakeGymEnv's reward,
+        termination and reset, one single-substep launch per pass.  Fills `counter` and `endDue2Height`; in test mode
+        also the per-substep lists.  (SnakeGymEnv.step does not come through here: it runs the fused kernel.)"""
+        env = self._need_env()
+        st = env._stepper
+        n = self.numMotors
+        if self.mode == 'test':
+            self.imgs, self.step_internal_observations, self.link_positions = [], [], []
+        full = self.createAction(action)
+        targets = (np.asarray(full, dtype=np.float32) * np.float32(env.params.scaling_factor)).reshape(1, n)
+        self.counter = 0
+        self.endDue2Height = False
+        observation = self.getObservation()
+        while bool(np.linalg.norm(targets[0].astype(np.float64) - observation[:n]) > env.params.servo_tol):
+            st.substep(targets, 1)
+            observation = self.getObservation()
+            if self.mode == 'test':
+                self.step_internal_observations.append(observation)
+                self.link_positions.append(self.getLinkPositions())
+            self.counter += 1
+            if self.checkSnakeHeight():
+                self.endDue2Height = True
+                break
+            if self.counter > env.params.max_counter:
+                break
+        return True
+
     def checkSnakeHeight(self):                          # snake.py:237-245
         return bool(self._need_env()._stepper.mean_height()[0] > 0.1)
 

@@ -738,3 +738,26 @@ def test_step_packed_matches_step(pkg, monkeypatch, quantum):
     assert bool(torch.isnan(packed[:, O + 2:]).all()) and torch.equal(env.substeps, sub)
     assert int(d.sum()) > 0 or int(sub.max()) > 0
     env.close()
+
+
+def test_robot_level_step_is_the_fused_kernels_servo_loop(pkg):
+    """Snake.step called by itself (test_script.py:25) -- createAction, checkFeedback, one substep per pass, height exit,
+    counter cap -- ends where the fused env-step kernel ends from the same state: same counter, same observation (the
+    fused kernel adds reward / termination / reset on top, which Snake.step does not have)."""
+    robot = pkg.Snake(None, "snake/snake.urdf", None)
+    env = pkg.SnakeGymEnv(robot, None)
+    env.reset()
+    twin = pkg.Stepper(1)
+    for j in range(5):
+        a = gait([2], j)[0].astype(np.float64) * 0.9            # (|q9| stays below 0.5: no termination in the twin)
+        S, X = env._stepper.get_state()
+        twin.set_state(S, X)
+        twin.set_manifold(env._stepper.get_manifold())
+        obs, rew, done, sub = twin.step(a.astype(np.float32).reshape(1, 8).copy(), vec_mode=False)
+        assert robot.step(list(a)) is True
+        assert robot.counter == int(sub[0]) and not robot.endDue2Height and not done[0]
+        assert np.array_equal(robot.getObservation().astype(np.float32), obs[0])
+        assert np.array_equal(robot.getPosition(), robot.getObservation()[:16]) and robot.getLinkPositions().shape == (51,)
+        assert robot.createAction(list(range(1, 9))) == [0, 1, 0, 2, 0, 3, 0, 4, 0, 5, 0, 6, 0, 7, 0, 8]
+    env.close()
+    twin.close()
