@@ -110,6 +110,35 @@ class BulletClient(object):
         elif body == self._BLOCK and lateralFriction is not None:
             self._set("mu_obstacle", float(lateralFriction))
 
+    # what snake_gait_test.py:20-26,54-55,73-74 calls besides: accepted, nothing to do on this engine (no GUI, no real-time
+    # clock); getCameraImage hands back PyBullet's 5-tuple with no pixels
+    def setRealTimeSimulation(self, enable):
+        if enable:
+            raise NotImplementedError("BulletClient: stepSimulation drives the clock (snake_gait_test.py:54)")
+
+    def resetDebugVisualizerCamera(self, *a, **k):
+        return None
+
+    def getCameraImage(self, width, height, *a, **k):
+        return (width, height, [], [], [])
+
+    def getJointInfo(self, body, joint):
+        """(index, name, type, ...) in PyBullet's layout, from the URDF's module pattern: joint 3k is
+        module k's revolute joint (type 0), the others are fixed (type 4)."""
+        if body != self._SNAKE or not (0 <= joint <= 3 * self._n):
+            raise NotImplementedError("BulletClient.getJointInfo: the snake's joints 0 .. 3n")
+        if joint == 0:
+            name, link, k = "base_joint", "base", 0
+        else:
+            k = (joint + 2) // 3
+            part = ("INPUT_INTERFACE", "COLLAR", "OUTPUT_BODY")[(joint - 1) % 3]
+            name, link = "SA%03d_%s_joint" % (k, part), "SA%03d_%s" % (k, part)
+        rev = joint >= 3 and joint % 3 == 0
+        lo, hi = (self._world.get("joint_lo", -1.57), self._world.get("joint_hi", 1.57)) if rev else (0.0, -1.0)
+        return (joint, name.encode(), 0 if rev else 4, (6 + k if rev else -1), (5 + k if rev else -1), 1,
+                0.1 if rev else 0.0, 0.2 if rev else 0.0, lo, hi, 7.0 if rev else 0.0, 2.208932 if rev else 0.0,
+                link.encode(), (0.0, 1.0, 0.0) if rev else (0.0, 0.0, 0.0), (0.0, 0.0, 0.0), (0.0, 0.0, 0.0, 1.0), joint - 1)
+
     def enableJointForceTorqueSensor(self, body, joint, enableSensor=1):
         return None                                      # joints 0 and 3 are always evaluated (obs[55]; snake_gait_test.py:126)
 
@@ -201,9 +230,12 @@ class BulletClient(object):
         if jointIndex == 0:                              # the head sensor: obs[55] = reaction Fz (snake.py:202-206)
             return (0.0, 0.0, (0.0, 0.0, float(x[n]), 0.0, 0.0, 0.0), 0.0)
         j = self._motor(jointIndex)
-        react = (0.0,) * 6
-        if jointIndex == 3:                              # snake_gait_test.py:126 reads joint 3's reaction Fz
-            react = (0.0, 0.0, float(self._stepper().joint3_reaction_fz()[0]), 0.0, 0.0, 0.0)
+        # the 6-D reaction is evaluated for joints 0 and 3 only (obs[55]; snake_gait_test.py:126 reads joint 3's Fz and
+        # records the others without using them): the rest come back as NaN, not as a made-up zero
+        nan = float("nan")
+        react = (nan,) * 6
+        if jointIndex == 3:
+            react = (nan, nan, float(self._stepper().joint3_reaction_fz()[0]), nan, nan, nan)
         return (float(s[13 + j]), float(s[13 + n + j]), react, float(x[j]))
 
     def getBasePositionAndOrientation(self, bodyUniqueId):

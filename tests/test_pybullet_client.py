@@ -109,7 +109,7 @@ def test_world_building_needs_no_device(pkg):
     with pytest.raises(NotImplementedError):
         p.setGravity(1, 0, -9.8)
     with pytest.raises(AttributeError):
-        p.getCameraImage(64, 64)
+        p.applyExternalForce(body, -1, [0, 0, 1], [0, 0, 0], 1)
     with pytest.raises(NotImplementedError):
         p.getLinkStates(body, [1, 2])
     p.disconnect()
