@@ -203,6 +203,20 @@ struct LdsCommon {
     __device__ __forceinline__ float& fz3() { return rec[15 + 3 * N]; }   // reaction Fz of the first motor joint (streamed-row solve)
 };
 
+// (occupancy experiments: tools/dbg/loop_spills.sh -DSNK_V1_RINGN=16 ...; the defaults are what ships)
+#ifndef SNK_V1_RESN
+#define SNK_V1_RESN 32
+#endif
+#ifndef SNK_V1_RINGN
+#define SNK_V1_RINGN 32
+#endif
+#ifndef SNK_V1_RINGF
+#define SNK_V1_RINGF 16
+#endif
+#ifndef SNK_LB
+#define SNK_LB 2
+#endif
+
 template <int N, bool V2>
 struct Lds;
 
@@ -230,9 +244,9 @@ struct Lds<N, false> : LdsCommon<N, 2 * N> {
     // to anything else; they live in a per-resident-wave block of global memory that the solve
     // streams once per iteration (see pgs_v1), one 320-byte record [J | M^-1 J^T] per row.
     static constexpr int kRing = 32;                       // padding entries behind the ground contacts' impulses (the link-link contacts' live there)
-    static constexpr int kResN = 32;                       // contacts whose normal rows stay in registers over the solve
-    static constexpr int kRingN = 32;                      // normal rows in flight behind them
-    static constexpr int kRingF = 16;                      // friction pairs in flight
+    static constexpr int kResN = SNK_V1_RESN;              // contacts whose normal rows stay in registers over the solve
+    static constexpr int kRingN = SNK_V1_RINGN;            // normal rows in flight behind them
+    static constexpr int kRingF = SNK_V1_RINGF;            // friction pairs in flight
     // link-link (self-collision) contacts follow the ground contacts in the compact list: at most kMaxSelf of them,
     // geometry slots NC .. NC + kMaxSelf - 1
     static constexpr int kMaxSelf = kRing;
@@ -2447,7 +2461,7 @@ __device__ __forceinline__ Sched load_sched(StepArgPtr p) {
 }
 
 template <int N, bool V2>
-__global__ __launch_bounds__(64, 2) void env_step_sched_kernel(StepArgs args_by_value) {
+__global__ __launch_bounds__(64, SNK_LB) void env_step_sched_kernel(StepArgs args_by_value) {
     (void)args_by_value;            // read through step_args() only
     extern __shared__ float4 smem_raw[];
     using LT = Lds<N, V2>;
