@@ -140,6 +140,8 @@ def test_gpu_client_runs_the_script_to_the_wall(vec, pkg, oracle_mod):
     hit = np.nonzero(fz > 20)[0]
     print("GPU: wall reported at step", hit[0] if len(hit) else None, "(reference run: 1344); head x %.3f (1.891); box x %.4f; "
           "max reaction %.1f" % (s[0, 0], box[0, 0], fz.max()))
-    assert len(hit) and abs(int(hit[0]) - 1344) <= 67                      # within 5 % of the reference's step
+    # (the step itself is a chaotic quantity: the float64 oracle reports 1341 with every command moved by 1e-9, 1357 with
+    #  the commands rounded to float32, the float32 oracle 1346 -- hence a window, 5 % of the reference's step)
+    assert len(hit) and abs(int(hit[0]) - 1344) <= 67
     assert abs(s[0, 0] - vec["head_xyz"][-1, 0]) < 0.03 and abs(box[0, 0] - 2.0) < 0.02
     p.close()
