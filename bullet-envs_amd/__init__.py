@@ -5,7 +5,7 @@ The directory name carries the reference's hyphen, so import it through importli
 or through the top-level shim:  import bullet_envs_amd as pkg
 """
 from ._lib import SnkParams, Stepper, default_params, load, LIB_PATH  # noqa: F401
-from .snake_env import (Snake, SnakeGymEnv, SnakeVecEnv, SubprocVecEnv, VecEnv,  # noqa: F401
+from .snake_env import (CloudpickleWrapper, Snake, SnakeGymEnv, SnakeVecEnv, SubprocVecEnv, VecEnv,  # noqa: F401
                         params_from_args)
 from .device_env import DeviceVecEnv, ShardedVecEnv  # noqa: F401
 from .pybullet_client import BulletClient  # noqa: F401  (the reference's inner seam: Snake(pybullet_client, ...))

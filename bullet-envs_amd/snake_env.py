@@ -336,9 +336,43 @@ class VecEnv(object):
         self.observation_space = observation_space
         self.action_space = action_space
 
+    # the four calls a subclass fills in (the reference's base class leaves them empty too: they return None)
+    def reset(self):
+        return None
+
+    def step_async(self, actions):
+        return None
+
+    def step_wait(self):
+        return None
+
+    def close(self):
+        return None
+
     def step(self, actions):
         self.step_async(actions)
         return self.step_wait()
+
+
+class CloudpickleWrapper(object):
+    """The holder the reference wraps each env thunk in before it crosses to a worker process
+    (ppo/multiprocessing_env.py:83-94): `.x` is the thunk; pickling goes through cloudpickle so that closures and lambdas
+    survive.  Nothing here forks -- SubprocVecEnv below accepts wrapped and plain thunks alike -- but callers that build
+    their thunk lists with it keep working."""
+
+    def __init__(self, x):
+        self.x = x
+
+    def __call__(self, *a, **kw):
+        return self.x(*a, **kw)
+
+    def __getstate__(self):
+        import cloudpickle
+        return cloudpickle.dumps(self.x)
+
+    def __setstate__(self, blob):
+        import pickle
+        self.x = pickle.loads(blob)
 
 
 def _as_action_matrix(actions, n_envs, act_dim):
@@ -420,7 +454,8 @@ class SubprocVecEnv(SnakeVecEnv):
     """
 
     def __init__(self, env_fns, spaces=None, device=0):
-        proto = env_fns[0]()
+        first = env_fns[0]
+        proto = (first.x if isinstance(first, CloudpickleWrapper) else first)()
         params = getattr(proto, "params", None)
         if params is None:
             raise TypeError("env_fns must build bullet-envs_amd SnakeGymEnv objects")

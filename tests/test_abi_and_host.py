@@ -163,3 +163,20 @@ def test_contact_threshold_follows_the_urdf_geometry(pkg):
         assert abs(bthr - 0.02 * np.sqrt(0.1 ** 2 + 0.4 ** 2 + 0.1 ** 2)) < 1e-8
         p2 = _lib.default_params(n_modules=n, relative_breaking_threshold=0)
         assert lib.snk_params_derived(C.byref(p2), out) == 0 and abs(out[0] - 0.02) < 1e-9
+
+
+def test_vec_env_module_surface(pkg):
+    """ppo/multiprocessing_env.py's module-level names a caller can import: VecEnv (its four calls left empty, step =
+    step_async + step_wait, :31-80), CloudpickleWrapper (:83-94: .x, pickled through cloudpickle), SubprocVecEnv."""
+    import pickle
+    v = pkg.VecEnv(3, "obs-space", "act-space")
+    assert (v.num_envs, v.observation_space, v.action_space) == (3, "obs-space", "act-space")
+    assert v.reset() is None and v.step_async([0]) is None and v.step_wait() is None and v.close() is None
+    assert v.step([0]) is None
+    k = 7
+    w = pkg.CloudpickleWrapper(lambda: k + 1)                 # a closure: plain pickle refuses it
+    with pytest.raises(Exception):
+        pickle.dumps(w.x)
+    w2 = pickle.loads(pickle.dumps(w))
+    assert w2.x() == 8 and w2() == 8 and w.x() == 8
+    assert issubclass(pkg.SubprocVecEnv, pkg.VecEnv)

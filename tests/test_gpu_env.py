@@ -171,6 +171,10 @@ def test_subproc_vec_env_dropin(pkg):
     ns, rw, dn, _ = envs.step(np.zeros((4, 8)))
     assert ns.shape == (4, 56) and sum(rw) == 0.0
     envs.close()
+    # thunks wrapped the way the reference's own SubprocVecEnv wraps them for its workers (multiprocessing_env.py:107)
+    envs = pkg.SubprocVecEnv([pkg.CloudpickleWrapper(make_env()) for _ in range(3)])
+    assert envs.num_envs == 3 and envs.reset().shape == (3, 56)
+    envs.close()
 
 
 def test_ground_friction_config(pkg, oracle_mod):
