@@ -203,12 +203,15 @@ struct LdsCommon {
     __device__ __forceinline__ float& fz3() { return rec[15 + 3 * N]; }   // reaction Fz of the first motor joint (streamed-row solve)
 };
 
-// (occupancy experiments: tools/dbg/loop_spills.sh -DSNK_V1_RINGN=16 ...; the defaults are what ships)
+// Register budget of the streamed-row solve (experiments: -DSNK_V1_RESN=.. etc. through build.py's `defines`; the defaults
+// are what ships).  Round 4's sweep on configs[3] (profiles/r04_c32_ring_sweep.txt): look-ahead beyond 16 normals / 16
+// friction pairs buys nothing, every resident normal saves its 320 bytes per iteration -- 40 / 16 / 16 runs at 91.7 k
+// env-steps/s against 89.9 k for round 2-3's 32 / 32 / 16; 48 resident or 24 pairs in flight spill into the loop.
 #ifndef SNK_V1_RESN
-#define SNK_V1_RESN 32
+#define SNK_V1_RESN 40
 #endif
 #ifndef SNK_V1_RINGN
-#define SNK_V1_RINGN 32
+#define SNK_V1_RINGN 16
 #endif
 #ifndef SNK_V1_RINGF
 #define SNK_V1_RINGF 16
@@ -235,6 +238,11 @@ struct Lds<N, false> : LdsCommon<N, 2 * N> {
     __device__ __forceinline__ float* ext(int b) { return ext_[b]; }
     __device__ __forceinline__ void poison(int lane) {
         this->poison_common(lane);
+        poison_own(lane);
+    }
+    // the members behind the common part only: what a register-resident kernel's rare streamed-row substep finds there is
+    // that kernel's own leftovers (finite numbers: the poison of the environment's load is long overwritten)
+    __device__ __forceinline__ void poison_own(int lane) {
         for (int i = lane; i < LdsCommon<N, 2 * N>::NB * 6; i += 64) (&ext_[0][0])[i] = __int_as_float(0x7fc00000);
         for (int i = lane; i < (NC + kRing + 3) * 4; i += 64) (&acc[0][0])[i] = __int_as_float(0x7fc00000);
     }
@@ -1753,8 +1761,13 @@ __device__ __forceinline__ void store_mf(LT& L, float* __restrict__ mf, int lane
 // One out-of-line copy of the streamed-row substep for the register-resident kernels' rare substeps (below): inlined
 // there it would double those kernels; the streamed-row kernels themselves inline it (as a called function its LDS
 // accesses go through flat addresses: -10 % on those kernels when the compiler chose that by itself, round 3).
+#ifdef SNK_V1_INLINE
+#define SNK_V1_CALL_ATTR __forceinline__
+#else
+#define SNK_V1_CALL_ATTR __noinline__
+#endif
 template <class LT>
-__device__ __noinline__ void substep_v1_call(LT& L, const DevModel& M, int lane, float mu, int& iters, int& ncontacts,
+__device__ SNK_V1_CALL_ATTR void substep_v1_call(LT& L, const DevModel& M, int lane, float mu, int& iters, int& ncontacts,
                                              float* __restrict__ rows, const SensorHint& hint, float* __restrict__ mf,
                                              unsigned long long* __restrict__ ovf) {
     substep_v1(L, M, lane, mu, iters, ncontacts, rows, hint, mf, ovf);
@@ -1786,11 +1799,39 @@ __device__ __forceinline__ void substep(LT& L, const DevModel& M0, int lane_in, 
             using L1 = Lds<LT::kN, false>;
             static_assert(sizeof(L1) <= sizeof(LT), "the streamed-row image must fit the register-resident one's allocation");
             L1& Lx = *reinterpret_cast<L1*>(&L);
+            // The cache goes out with plain stores and this CU's vector L1 is invalidated behind them (an agent-scope
+            // acquire: s_waitcnt vmcnt(0), buffer_inv sc1) before the streamed-row substep loads it, and again before it
+            // comes back.  Round 4: with write-through (sc1) stores and no invalidate, the loads that followed could hit
+            // lines this CU had cached when the environment was loaded -- an sc1 store does not refresh the storing CU's
+            // own L1 -- and a few cylinders' manifolds came back one substep old: 64 against 65 contacts among replicas of
+            // one state, whenever the line had survived (tools/dbg/replica_sub.py; it took other ring sizes in the
+            // streamed solve, i.e. other timing, to show in test_schedule_does_not_change_results).
+#ifndef SNK_FB_MODE
+#define SNK_FB_MODE 2
+#endif
+#if SNK_FB_MODE == 0
             store_mf<LT, true>(L, mf, lane);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             substep_v1_call(Lx, M, launder_lane(lane), mu, iters, ncontacts, rows, hint, mf, ovf);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             load_mf(L, mf, lane);
+#elif SNK_FB_MODE == 1
+            store_mf<LT, false>(L, mf, lane);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (M.poison) { lds_sync(); Lx.poison_own(lane); lds_sync(); }
+            substep_v1_call(Lx, M, launder_lane(lane), mu, iters, ncontacts, rows, hint, mf, ovf);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            load_mf(L, mf, lane);
+#else
+            store_mf<LT, false>(L, mf, lane);
+            asm volatile("s_waitcnt vmcnt(0)\n\tbuffer_inv sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
+            if (M.poison) { lds_sync(); Lx.poison_own(lane); lds_sync(); }
+            substep_v1_call(Lx, M, launder_lane(lane), mu, iters, ncontacts, rows, hint, mf, ovf);
+            asm volatile("s_waitcnt vmcnt(0)\n\tbuffer_inv sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
+            load_mf(L, mf, lane);
+#endif
         }
     } else {
         substep_v1(L, M, lane, mu, iters, ncontacts, rows, hint, mf, ovf);

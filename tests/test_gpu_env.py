@@ -765,3 +765,49 @@ def test_robot_level_step_is_the_fused_kernels_servo_loop(pkg):
         assert robot.createAction(list(range(1, 9))) == [0, 1, 0, 2, 0, 3, 0, 4, 0, 5, 0, 6, 0, 7, 0, 8]
     env.close()
     twin.close()
+
+
+@pytest.mark.gpu
+def test_overflow_substep_replicas_agree(pkg, monkeypatch):
+    """A substep whose contacts outgrow the register-resident solve's slots runs through the streamed-row substep in place,
+    its contact cache handed over through global memory.  385 replicas of such an environment, scattered among 4615
+    ordinary ones (their partner waves busy with the register-resident solve), must all end the env-step on the same bits,
+    pass after pass.  Round 4 found them in two camps (64 against 65 contacts in that substep, a quarter of the replicas
+    in the minority): the hand-over's write-through stores had not refreshed the storing CU's own L1, and the loads behind
+    them sometimes hit lines cached when the environment was loaded (snk_device.hpp: substep())."""
+    monkeypatch.setenv("SNK_QUANTUM", "0")
+    B, n, A = 5000, 16, 8
+    fr = (0.5 + np.arange(B) % 11 / 10.0).astype(np.float32)
+    st = pkg.Stepper(B, n_modules=n)
+    st.reset()
+    st.set_ground_friction(fr)
+    a = np.clip(gait(range(B), 0, A) * 1.2, -1, 1).astype(np.float32)
+    S, X = st.get_state()
+    Mf = st.get_manifold()
+    tg = np.zeros((B, n), np.float32)
+    tg[:, 1::2] = a * np.float32(np.pi / 6)
+    e = None
+    for k in range(28):                                  # the gait's first env-step: an env that overflows on the way
+        info = st.substep(tg, 1)
+        hit = np.nonzero(info[:, 1] > 64)[0]
+        if len(hit):
+            e = int(hit[0])
+            break
+    assert e is not None, "no substep beyond 64 contacts in the gait's first env-step"
+    idx = np.arange(7, B, 13)
+    S2, X2, M2, a2, f2 = S.copy(), X.copy(), Mf.copy(), a.copy(), fr.copy()
+    S2[idx], X2[idx], M2[idx], a2[idx], f2[idx] = S[e], X[e], Mf[e], a[e], fr[e]
+    first = None
+    for rep in range(3):
+        st.set_ground_friction(f2)
+        st.set_state(S2, X2)
+        st.set_manifold(M2)
+        c0 = st.contact_overflow()[0]
+        o, r, d, s = st.step(a2.copy())
+        assert st.contact_overflow()[0] - c0 >= len(idx)             # every replica took the in-place streamed substep
+        camps = np.unique(o[idx], axis=0)
+        assert len(camps) == 1, "pass %d: %d different outcomes among %d replicas of env %d" % (rep, len(camps), len(idx), e)
+        assert np.unique(s[idx]).size == 1 and np.unique(r[idx]).size == 1
+        first = o.copy() if first is None else first
+        assert np.array_equal(o, first)                              # ... and the whole handle repeats bit for bit
+    st.close()
