@@ -1211,7 +1211,11 @@ __device__ __forceinline__ void row_step_cone(float jA, float mA, float jB, floa
     accB = xB;
 }
 
-template <class LT>
+// INPLACE: the copy that runs inside the register-resident kernels for their rare substeps (substep()): it keeps rounds
+// 2-3's 32 / 32 / 16 registers' split.  With the standalone kernels' 40 / 16 / 16 (round 4: +2 % for 32 links, +7 % for the
+// 16-link streamed-row kernels) the register-resident kernel around it came out 3.6 % slower -- 352 k against 365 k
+// env-steps/s with 19 such substeps in 80 000 -- for the registers live across the call.
+template <class LT, bool INPLACE = false>
 __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, float mu, int& iters,
                         float* __restrict__ rows) {
     constexpr int N = LT::kN;
@@ -1241,7 +1245,7 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
     // kSpec + 1 the row's scalars (160 contiguous bytes per half row: coalesced); the other lanes sit the solve out.
     // The rows and impulses of the contacts between nc and the end of the last group are zeroed: resolving them
     // changes nothing (dI = 0 exactly).
-    constexpr int kRN = LT::kRingN;      // normals in flight
+    constexpr int kRN = INPLACE ? 32 : LT::kRingN;      // normals in flight
     // contacts are resolved in groups of 8 behind one scalar branch: the rows between nc and the next multiple of 8
     // are zeroed (inert), a ring trip ends at that multiple instead of running its full depth (round 1 padded
     // to a whole trip: 144 contacts -- 128 on the ground + 16 link-link -- cost 160)
@@ -1289,7 +1293,7 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
     for (int j = 0; j < N; j++) RMm[j] = ldJ((unsigned)(LT::kMmOff * 4) + (unsigned)(6 + j) * kHalfB);   // columns >= ND: zero
     // ... and so do the normal rows of the first kResN contacts: the registers the rings leave free hold an eighth of
     // the stream (the kernel is bound by that stream)
-    constexpr int kResN = LT::kResN;
+    constexpr int kResN = INPLACE ? 32 : LT::kResN;
     float RNJ[kResN], RNM[kResN];
 #pragma unroll
     for (int k = 0; k < kResN; k++) ldN((unsigned)k * kRecB, RNJ[k], RNM[k]);
@@ -1393,7 +1397,7 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
                 // six.  Its step is skipped and its record is not fetched: `live`, one bit per contact, is fixed for the
                 // whole phase (the normal impulses are this iteration's final ones, a pair's own impulses only change
                 // at its own step), built with four ballots and kept in SGPRs, so a step's test is scalar.
-                constexpr int kC = LT::kRingF;
+                constexpr int kC = INPLACE ? 16 : LT::kRingF;
                 // (the solve runs on lanes 0 .. kMO - 1: one ballot covers kMO contacts; kP ballots, kW 64-bit words)
                 constexpr int kP = (LT::NCT + LT::kMO - 1) / LT::kMO, kW = (kP * LT::kMO + 63) / 64;
                 unsigned long long mw[kW + 1];
@@ -1477,7 +1481,7 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
 // ----------------------------------------------------------------------------------
 // one physics substep
 // ----------------------------------------------------------------------------------
-template <class LT>
+template <class LT, bool INPLACE = false>
 __device__ __forceinline__ void substep_v1(LT& L, const DevModel& M, int lane, float mu, int& iters, int& ncontacts, float* __restrict__ rows,
                            const SensorHint& hint, float* __restrict__ mf, unsigned long long* __restrict__ ovf) {
     constexpr int N = LT::kN;
@@ -1556,7 +1560,7 @@ __device__ __forceinline__ void substep_v1(LT& L, const DevModel& M, int lane, f
     SNK_STAMP(5)
     // the solve runs at a higher wave priority than everything around it (snk_pgs_v2.hpp: substep_v2)
     __builtin_amdgcn_s_setprio(3);
-    float dv = pgs_v1(L, M, lane, nc, nn, mu, iters, rows);
+    float dv = pgs_v1<LT, INPLACE>(L, M, lane, nc, nn, mu, iters, rows);
     __builtin_amdgcn_s_setprio(0);
     SNK_STAMP(6)
     if (M.contact_model == 1 && lane < 2 * N) {
@@ -1770,7 +1774,7 @@ template <class LT>
 __device__ SNK_V1_CALL_ATTR void substep_v1_call(LT& L, const DevModel& M, int lane, float mu, int& iters, int& ncontacts,
                                              float* __restrict__ rows, const SensorHint& hint, float* __restrict__ mf,
                                              unsigned long long* __restrict__ ovf) {
-    substep_v1(L, M, lane, mu, iters, ncontacts, rows, hint, mf, ovf);
+    substep_v1<LT, true>(L, M, lane, mu, iters, ncontacts, rows, hint, mf, ovf);
 }
 
 template <class LT>
@@ -1799,39 +1803,19 @@ __device__ __forceinline__ void substep(LT& L, const DevModel& M0, int lane_in, 
             using L1 = Lds<LT::kN, false>;
             static_assert(sizeof(L1) <= sizeof(LT), "the streamed-row image must fit the register-resident one's allocation");
             L1& Lx = *reinterpret_cast<L1*>(&L);
-            // The cache goes out with plain stores and this CU's vector L1 is invalidated behind them (an agent-scope
-            // acquire: s_waitcnt vmcnt(0), buffer_inv sc1) before the streamed-row substep loads it, and again before it
+            // The cache goes out with plain stores and this CU's vector L1 is invalidated behind them (what an agent-scope
+            // acquire does: s_waitcnt vmcnt(0), buffer_inv sc1) before the streamed-row substep loads it, and again before it
             // comes back.  Round 4: with write-through (sc1) stores and no invalidate, the loads that followed could hit
             // lines this CU had cached when the environment was loaded -- an sc1 store does not refresh the storing CU's
             // own L1 -- and a few cylinders' manifolds came back one substep old: 64 against 65 contacts among replicas of
             // one state, whenever the line had survived (tools/dbg/replica_sub.py; it took other ring sizes in the
             // streamed solve, i.e. other timing, to show in test_schedule_does_not_change_results).
-#ifndef SNK_FB_MODE
-#define SNK_FB_MODE 2
-#endif
-#if SNK_FB_MODE == 0
-            store_mf<LT, true>(L, mf, lane);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            substep_v1_call(Lx, M, launder_lane(lane), mu, iters, ncontacts, rows, hint, mf, ovf);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            load_mf(L, mf, lane);
-#elif SNK_FB_MODE == 1
-            store_mf<LT, false>(L, mf, lane);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (M.poison) { lds_sync(); Lx.poison_own(lane); lds_sync(); }
-            substep_v1_call(Lx, M, launder_lane(lane), mu, iters, ncontacts, rows, hint, mf, ovf);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            load_mf(L, mf, lane);
-#else
             store_mf<LT, false>(L, mf, lane);
             asm volatile("s_waitcnt vmcnt(0)\n\tbuffer_inv sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
             if (M.poison) { lds_sync(); Lx.poison_own(lane); lds_sync(); }
             substep_v1_call(Lx, M, launder_lane(lane), mu, iters, ncontacts, rows, hint, mf, ovf);
             asm volatile("s_waitcnt vmcnt(0)\n\tbuffer_inv sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
             load_mf(L, mf, lane);
-#endif
         }
     } else {
         substep_v1(L, M, lane, mu, iters, ncontacts, rows, hint, mf, ovf);
