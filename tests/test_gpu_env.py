@@ -811,3 +811,51 @@ def test_overflow_substep_replicas_agree(pkg, monkeypatch):
         first = o.copy() if first is None else first
         assert np.array_equal(o, first)                              # ... and the whole handle repeats bit for bit
     st.close()
+
+
+REPLICA_CASES = [(16, 4000, {}), (16, 3000, dict(warm_start=1)), (32, 2600, {}),
+                 (16, 3000, dict(obstacle=1, obstacle_pos=[0.12, 0.0, 0.1])), (16, 3000, dict(obstacle=2, obstacle_pos=[0.12, 0.0, 0.1])),
+                 (16, 4000, dict(hull_sides=0, contact_model=0, relative_breaking_threshold=0)),
+                 (32, 2600, dict(obstacle=1, obstacle_pos=[0.12, 0.0, 0.1]))]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", range(len(REPLICA_CASES)))
+def test_replicas_agree_whatever_runs_beside_them(pkg, monkeypatch, case):
+    """The stronger form of the schedule test (round 4, after the stale contact cache of the in-place streamed substep):
+    replicas of one environment -- state, contact cache, free box, friction, action -- every 13th slot of a handle full of
+    ordinary environments.  Whatever wave runs a replica, whatever runs beside it on the SIMD and the CU, it must end the
+    env-step on the bits the source environment itself ended on; scheduled and unscheduled kernels."""
+    n, B, over = REPLICA_CASES[case]
+    A = n // 2
+    for quantum in (1, 0):
+        monkeypatch.setenv("SNK_QUANTUM", str(quantum))
+        st = pkg.Stepper(B, n_modules=n, **over)
+        st.reset()
+        fr = (0.5 + np.arange(B) % 11 / 10.0).astype(np.float32)
+        st.set_ground_friction(fr)
+        for j in range(2):
+            st.step((gait(range(B), j, A) * 1.2).astype(np.float32))
+        S, X = st.get_state()
+        Mf = st.get_manifold()
+        BX = st.get_box() if over.get("obstacle") == 2 else None
+        a = (gait(range(B), 2, A) * 1.2).astype(np.float32)
+        o0, r0, d0, s0 = st.step(a.copy())
+        idx = np.arange(7, B, 13)
+        for e in (int(np.argmax(s0)), int(np.argmin(s0 + 100 * (s0 == 0))), 1234 % B):
+            S2, X2, a2, f2 = S.copy(), X.copy(), a.copy(), fr.copy()
+            S2[idx], X2[idx], a2[idx], f2[idx] = S[e], X[e], a[e], fr[e]
+            st.set_ground_friction(f2)
+            st.set_state(S2, X2)
+            if Mf is not None:
+                M2 = Mf.copy()
+                M2[idx] = Mf[e]
+                st.set_manifold(M2)
+            if BX is not None:
+                b0, b1 = BX[0].copy(), BX[1].copy()
+                b0[idx], b1[idx] = BX[0][e], BX[1][e]
+                st.set_box(b0, b1)
+            o, r, d, s = st.step(a2.copy())
+            assert len(np.unique(o[idx], axis=0)) == 1, (n, over, quantum, e)
+            assert np.array_equal(o[idx[0]], o0[e]) and r[idx[0]] == r0[e] and s[idx[0]] == s0[e], (n, over, quantum, e)
+        st.close()
