@@ -859,3 +859,28 @@ def test_replicas_agree_whatever_runs_beside_them(pkg, monkeypatch, case):
             assert len(np.unique(o[idx], axis=0)) == 1, (n, over, quantum, e)
             assert np.array_equal(o[idx[0]], o0[e]) and r[idx[0]] == r0[e] and s[idx[0]] == s0[e], (n, over, quantum, e)
         st.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,B,over", [(16, 4096, {}), (32, 2048, {}), (16, 2048, dict(obstacle=2, obstacle_pos=[0.12, 0.0, 0.1]))])
+def test_twin_environments_stay_identical(pkg, n, B, over):
+    """env i and env i + B/2: same friction, same actions (gait, every seventh step random and out of range), same start --
+    other slots, other waves, other neighbours.  80 env-steps, auto-resets and in-place streamed substeps included; the
+    twins must agree bit for bit throughout (tools/dbg/twins_soak.py runs six configurations for 300 steps)."""
+    A, H = n // 2, B // 2
+    st = pkg.Stepper(B, n_modules=n, **over)
+    st.reset()
+    fr = (0.5 + np.arange(H) % 11 / 10.0).astype(np.float32)
+    st.set_ground_friction(np.concatenate([fr, fr]))
+    rng = np.random.default_rng(3)
+    for j in range(80):
+        a = (gait(range(H), j, A) * 1.2).astype(np.float32)
+        if j % 7 == 3:
+            a = rng.uniform(-2, 2, (H, A)).astype(np.float32)
+        o, r, d, s = st.step(np.concatenate([a, a]))
+        assert np.array_equal(o[:H], o[H:]) and np.array_equal(r[:H], r[H:]) and np.array_equal(s[:H], s[H:]), j
+    S, X = st.get_state()
+    assert np.array_equal(S[:H], S[H:]) and np.array_equal(X[:H], X[H:])
+    if n == 16 and not over:
+        assert st.contact_overflow()[0] > 0            # the run went through the in-place streamed substep as well
+    st.close()
