@@ -884,3 +884,47 @@ def test_twin_environments_stay_identical(pkg, n, B, over):
     if n == 16 and not over:
         assert st.contact_overflow()[0] > 0            # the run went through the in-place streamed substep as well
     st.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,B,over", [(16, 4096, {}), (32, 2048, {}), (16, 2048, dict(obstacle=2, obstacle_pos=[0.12, 0.0, 0.1])),
+                                      (16, 3000, dict(warm_start=1, obstacle=1, obstacle_pos=[0.12, 0.0, 0.1]))])
+def test_slot_permutation_invariance(pkg, n, B, over):
+    """An environment's outcome does not depend on the slot it sits in: the same handle stepped from the same states in
+    natural order and in a random permutation (state, contact cache, free box, friction, actions permuted alike) gives
+    the permuted outputs, bit for bit, over three env-steps in a row -- every environment of the handle, not a few
+    replicated ones."""
+    A = n // 2
+    st = pkg.Stepper(B, n_modules=n, **over)
+    st.reset()
+    fr = (0.5 + np.arange(B) % 11 / 10.0).astype(np.float32)
+    st.set_ground_friction(fr)
+    for j in range(2):
+        st.step((gait(range(B), j, A) * 1.2).astype(np.float32))
+    S, X = st.get_state()
+    Mf = st.get_manifold()
+    BX = st.get_box() if over.get("obstacle") == 2 else None
+    acts = [(gait(range(B), 2 + j, A) * 1.2).astype(np.float32) for j in range(3)]
+
+    def run(p):
+        st.set_ground_friction(fr[p])
+        st.set_state(S[p], X[p])
+        if Mf is not None:
+            st.set_manifold(Mf[p])
+        if BX is not None:
+            st.set_box(BX[0][p], BX[1][p])
+        outs = []
+        for a in acts:
+            o, r, d, s = st.step(a[p].copy())
+            outs.append((o.copy(), r.copy(), d.copy(), s.copy()))
+        return outs, st.get_state()[0]
+
+    ident = np.arange(B)
+    perm = np.random.default_rng(11).permutation(B)
+    ref, Sr = run(ident)
+    got, Sg = run(perm)
+    for (o, r, d, s), (O, R, D, Sx) in zip(got, ref):
+        assert np.array_equal(s, Sx[perm]) and np.array_equal(d, D[perm])
+        assert np.array_equal(o, O[perm]) and np.array_equal(r, R[perm])
+    assert np.array_equal(Sg, Sr[perm])
+    st.close()
