@@ -1,5 +1,5 @@
 """Which environments end a step on different bits under another slice length (tests/test_gpu_env.py::
-test_schedule_does_not_change_results)?   python tools/dbg/sched_diff.py [16|32] [B]"""
+test_schedule_does_not_change_results)?   [SD_OVER='{"self_collision": 0}'] python tools/dbg/sched_diff.py [16|32] [B]"""
 import importlib, os, sys
 import numpy as np
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
@@ -12,7 +12,7 @@ A = n // 2
 
 def run(quantum):
     os.environ["SNK_QUANTUM"] = str(quantum)
-    st = pkg.Stepper(B, n_modules=n, **eval(os.environ.get("SD_OVER", "{}")))
+    st = pkg.Stepper(B, n_modules=n, **__import__("json").loads(os.environ.get("SD_OVER", "{}")))
     st.reset()
     st.set_ground_friction((0.5 + np.arange(B) % 11 / 10.0).astype(np.float32))
     outs = []
