@@ -382,6 +382,15 @@ __device__ __forceinline__ bool sensor_pass_needed(LT& L, const DevModel& M, int
     return __builtin_amdgcn_readfirstlane(sensor ? 1 : 0) != 0;
 }
 
+// What this wave stored to its own block of global memory (constraint rows, contact geometry: written lane = row, read
+// lane = column) becomes visible to its own later loads: the stores have left the wave (vmcnt) and this CU's vector L1
+// holds no line from before them (buffer_inv sc1).  The XCD's L2 is the point of coherence for writer and reader alike --
+// the same wave -- so nothing has to be written back: __threadfence() here (rounds 1-4) also ran buffer_wbl2, a
+// write-back of every dirty line of the XCD's L2, two to three times per streamed-row substep.
+__device__ __forceinline__ void own_stores_visible() {
+    asm volatile("s_waitcnt vmcnt(0)\n\tbuffer_inv sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
+}
+
 // ----------------------------------------------------------------------------------
 // S1: forward kinematics + link velocities of the chain (serial recurrence, evaluated
 // uniformly by the wave; lane 0 stores)
@@ -1010,7 +1019,7 @@ __device__ void build_rows_v1(LT& L, const DevModel& M, int lane, int nc, int& n
             if (boxlane && i >= 3) yf = mk3(i == 3 ? M.obs_minv : 0.f, i == 4 ? M.obs_minv : 0.f, i == 5 ? M.obs_minv : 0.f);
             y[0] = yt.x; y[kMO] = yt.y; y[2 * kMO] = yt.z; y[3 * kMO] = yf.x; y[4 * kMO] = yf.y; y[5 * kMO] = yf.z;
         }
-        __threadfence();
+        own_stores_visible();
         lds_sync();
         for (int ci = nplane; ci < nc; ci++) {
             const Geo G = load_geo(ci);
@@ -1258,7 +1267,7 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
         for (int i = lane; i < 2 * nz; i += 64) zf[i] = 0.f;
         for (int i = lane; i < 4 * (nc_pad - nc); i += 64) L.acc[nc][i] = 0.f;
     }
-    __threadfence();          // the rows were written lane = row, they are read lane = column
+    own_stores_visible();     // the rows were written lane = row, they are read lane = column
     lds_sync();
     constexpr int kRS = LT::kRS;
     // Addressing: a record's address is a wave-uniform base (scalar arithmetic) plus the lane's column, 4 * lane bytes,
@@ -1502,7 +1511,7 @@ __device__ __forceinline__ void substep_v1(LT& L, const DevModel& M, int lane, f
         nc += find_self_contacts_v1(L, M, lane, mu, rows, ovf);   // link-link and obstacle contacts follow the ground's
     if (fbox) nc += find_box_ground_v1(L, M, lane, mu, nc - nplane, rows, ovf);     // ... and the box's own with the ground
     ncontacts = nc;
-    __threadfence();      // contact geometry: written lane = slot, read lane = row
+    own_stores_visible(); // contact geometry: written lane = slot, read lane = row
     lds_sync();
     SNK_STAMP(2)
     if (lane < N) {
