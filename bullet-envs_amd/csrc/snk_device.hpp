@@ -219,6 +219,9 @@ struct LdsCommon {
 #ifndef SNK_LB
 #define SNK_LB 2
 #endif
+#ifndef SNK_V1_LDAUX
+#define SNK_V1_LDAUX 0      // cache policy bits of the streamed rows' buffer loads (experiments: 1 sc0, 2 nt, 16 sc1)
+#endif
 
 template <int N, bool V2>
 struct Lds;
@@ -1286,11 +1289,11 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     auto ldN = [&](unsigned rec_bytes, float& j, float& m) {       // {J, M^-1 J^T} of a normal's record
-        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, 2 * vcol, (int)rec_bytes, 0);
+        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, 2 * vcol, (int)rec_bytes, SNK_V1_LDAUX);
         j = __uint_as_float(v.x); m = __uint_as_float(v.y);
     };
     auto ldF = [&](unsigned rec_bytes, float& ja, float& jb, float& ma, float& mb) {    // a friction pair's record
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, 4 * vcol, (int)rec_bytes, 0);
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, 4 * vcol, (int)rec_bytes, SNK_V1_LDAUX);
         ja = __uint_as_float(v.x); jb = __uint_as_float(v.y); ma = __uint_as_float(v.z); mb = __uint_as_float(v.w);
     };
     float dv = lane == kSpec ? 1.0f : 0.f;        // lane kSpec: the constant that multiplies the rows' -rhs column
