@@ -219,9 +219,6 @@ struct LdsCommon {
 #ifndef SNK_LB
 #define SNK_LB 2
 #endif
-#ifndef SNK_V1_JPREFIX
-#define SNK_V1_JPREFIX 0     // 1: records de-interleaved, J's zero suffix not fetched (see pgs_v1)
-#endif
 #ifndef SNK_V1_LDAUX
 #define SNK_V1_LDAUX 0      // cache policy bits of the streamed rows' buffer loads (experiments: 1 sc0, 2 nt, 16 sc1)
 #endif
@@ -304,9 +301,6 @@ struct Lds<N, false> : LdsCommon<N, 2 * N> {
     alignas(16) float acc[NC + kRing + 3][4];        // (+ the entries the solve reads ahead of the last pair)
     static_assert(NCT <= NC + kRing, "the impulses of the link-link contacts live in the ring's padding entries");
     int nplane;                  // ground contacts of this substep (the link-link contacts follow them)
-#if SNK_V1_JPREFIX
-    int gL[(NCT + 7) / 8 + 1];   // per group of eight contacts: positions of the J half that hold non-zeros (pgs_v1)
-#endif
     // obstacle 2: the free box while this wave holds the environment -- state [pos3, quat4, omega3, vel3], its world
     // rotation and world inverse inertia (sym6) for this substep, its manifold with the plane (4 x (a3, b.x, b.y,
     // lambda)) and the point count; travels with the state record (d_box)
@@ -988,21 +982,8 @@ __device__ void build_rows_v1(LT& L, const DevModel& M, int lane, int nc, int& n
         }
         prevMn = Mo[0];
         if (colv) {
-#if SNK_V1_JPREFIX
-            // de-interleaved: [M^-1 J^T (kMO columns) | J (kMO positions: the two scalar columns first, then the velocity
-            // components in order)], so that the zero suffix of J -- the joints beyond the contact's body -- is the
-            // record's tail and the solve can leave it unfetched
-            const int pj = d >= LT::kSpec ? d - LT::kSpec : d + 2;
-            float* rn = rows + (size_t)ci * LT::kRS;
-            rn[d] = Mo[0];
-            rn[kMO + pj] = Jo[0];
-            float* rf = rows + (size_t)(LT::kFric + 2 * ci) * LT::kRS;
-            *reinterpret_cast<float2*>(rf + 2 * d) = make_float2(Mo[1], Mo[2]);
-            *reinterpret_cast<float2*>(rf + 2 * kMO + 2 * pj) = make_float2(Jo[1], Jo[2]);
-#else
             *reinterpret_cast<float2*>(rows + (size_t)ci * LT::kRS + 2 * d) = make_float2(Jo[0], Mo[0]);
             *reinterpret_cast<float4*>(rows + (size_t)(LT::kFric + 2 * ci) * LT::kRS + 4 * d) = make_float4(Jo[1], Jo[2], Mo[1], Mo[2]);
-#endif
         }
         if (lane == 0) *reinterpret_cast<float4*>(L.acc[ci]) = make_float4(lam0, 0.f, 0.f, cpl);
     };
@@ -1289,21 +1270,6 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
         for (int i = lane; i < 2 * nz; i += 64) zf[i] = 0.f;
         for (int i = lane; i < 4 * (nc_pad - nc); i += 64) L.acc[nc][i] = 0.f;
     }
-#if SNK_V1_JPREFIX
-    // J of a ground contact on body k is zero beyond velocity component 5 + k (the joints further down the chain do not
-    // move it), i.e. beyond position 7 + k of the record's J half.  Ground contacts come in the order of their bodies,
-    // so the last contact of a group of eight has the group's longest prefix; a group with link-link / obstacle contacts
-    // or padding in it is read whole.  One table entry per group: the positions worth fetching.
-    if (lane * 8 < nc_pad) {
-        int lp = LT::kMO;
-        const int last = 8 * lane + 7;
-        if (last < L.nplane) {
-            const int slot = L.clist[last];
-            lp = 8 + (int)rows[LT::kGeoOff + (size_t)slot * LT::kGeo + 16];
-        }
-        L.gL[lane] = lp < LT::kMO ? lp : LT::kMO;
-    }
-#endif
     own_stores_visible();     // the rows were written lane = row, they are read lane = column
     lds_sync();
     constexpr int kRS = LT::kRS;
@@ -1322,27 +1288,6 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
     };
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-#if SNK_V1_JPREFIX
-    // this lane's position in a record's J half, in bytes (normals; friction pairs: twice that), and the same with the
-    // lanes beyond a group's prefix sent out of range: a buffer load returns 0 for them and fetches nothing
-    const int posJ4 = 4 * (lane >= kSpec ? lane - kSpec : lane + 2);
-    constexpr int kOOB = 0x7ffffff0;
-    auto vsel = [&](int contact, int scale) {        // contact: any contact of the group (wave-uniform)
-        const int lp4 = 4 * __builtin_amdgcn_readfirstlane(L.gL[contact >> 3]);
-        return posJ4 < lp4 ? posJ4 * scale : kOOB;
-    };
-    auto ldNv = [&](unsigned rec_bytes, int vj, float& j, float& m) {       // {J, M^-1 J^T} of a normal's record
-        m = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, vcol, (int)rec_bytes, SNK_V1_LDAUX));
-        j = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, vj, (int)(rec_bytes + kHalfB), SNK_V1_LDAUX));
-    };
-    auto ldFv = [&](unsigned rec_bytes, int vj2, float& ja, float& jb, float& ma, float& mb) {    // a friction pair's record
-        const u32x2 vm = __builtin_amdgcn_raw_buffer_load_b64(rsrc, 2 * vcol, (int)rec_bytes, SNK_V1_LDAUX);
-        const u32x2 vv = __builtin_amdgcn_raw_buffer_load_b64(rsrc, vj2, (int)(rec_bytes + 2 * kHalfB), SNK_V1_LDAUX);
-        ja = __uint_as_float(vv.x); jb = __uint_as_float(vv.y); ma = __uint_as_float(vm.x); mb = __uint_as_float(vm.y);
-    };
-    auto ldN = [&](unsigned rec_bytes, float& j, float& m) { ldNv(rec_bytes, posJ4, j, m); };            // a whole record
-    auto ldF = [&](unsigned rec_bytes, float& ja, float& jb, float& ma, float& mb) { ldFv(rec_bytes, 2 * posJ4, ja, jb, ma, mb); };
-#else
     auto ldN = [&](unsigned rec_bytes, float& j, float& m) {       // {J, M^-1 J^T} of a normal's record
         const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, 2 * vcol, (int)rec_bytes, SNK_V1_LDAUX);
         j = __uint_as_float(v.x); m = __uint_as_float(v.y);
@@ -1351,10 +1296,6 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
         const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, 4 * vcol, (int)rec_bytes, SNK_V1_LDAUX);
         ja = __uint_as_float(v.x); jb = __uint_as_float(v.y); ma = __uint_as_float(v.z); mb = __uint_as_float(v.w);
     };
-    auto vsel = [&](int, int) { return 0; };
-    auto ldNv = [&](unsigned rec_bytes, int, float& j, float& m) { ldN(rec_bytes, j, m); };
-    auto ldFv = [&](unsigned rec_bytes, int, float& ja, float& jb, float& ma, float& mb) { ldF(rec_bytes, ja, jb, ma, mb); };
-#endif
     float dv = lane == kSpec ? 1.0f : 0.f;        // lane kSpec: the constant that multiplies the rows' -rhs column
     int it = 0;
     if (lane < LT::kMO) {
@@ -1424,12 +1365,8 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
             // worth of rows nobody used, 14 % of the stream this kernel is bound by; the contact's
             // accumulated impulse comes from LDS one step ahead.
             float jr[kRN], mr[kRN];
-            int vjn = 0;            // the J-half offsets of the group the next refills belong to (SNK_V1_JPREFIX)
 #pragma unroll
-            for (int k = 0; k < kRN; k++) {
-                if ((k & 7) == 0) vjn = vsel(kResN + k, 1);
-                ldNv((unsigned)(kResN + k) * kRecB, vjn, jr[k], mr[k]);
-            }
+            for (int k = 0; k < kRN; k++) ldN((unsigned)(kResN + k) * kRecB, jr[k], mr[k]);
             // two contacts per step (row_step_normal2): {impulse of the even one, impulse and coupling of the odd one} come
             // from LDS one step ahead
             float a0n = L.acc[0][0];
@@ -1460,13 +1397,9 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
                     // the refill: the contacts kRN further on if there are any, else this trip's once more
                     // (a cache hit instead of a fetch of rows nobody uses; no branch, the load is issued either way).
                     // Issued after the step: the register pairs are free then and take the new records as they are
-                    if ((k & 7) == 0) {
-                        const int rc = (base + kRN + k < nc_pad) ? base + kRN : base;
-                        rb = (unsigned)rc * kRecB;
-                        vjn = vsel(rc + k, 1);
-                    }
-                    ldNv(rb + (unsigned)k * kRecB, vjn, jr[k], mr[k]);
-                    ldNv(rb + (unsigned)(k + 1) * kRecB, vjn, jr[k + 1], mr[k + 1]);
+                    if ((k & 7) == 0) rb = (unsigned)((base + kRN + k < nc_pad) ? base + kRN : base) * kRecB;
+                    ldN(rb + (unsigned)k * kRecB, jr[k], mr[k]);
+                    ldN(rb + (unsigned)(k + 1) * kRecB, jr[k + 1], mr[k + 1]);
                 }
             }
             if (cone) {
@@ -1498,14 +1431,11 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
                 // (the register is shifted down by kC contacts per trip)
                 constexpr unsigned kZeroB = (unsigned)(LT::kRows - 3) * kRecB;   // 960 bytes of zeros: the refill of a skipped pair
                 float jA[kC], jB[kC], mA[kC], mB[kC];
-                int vjf = 0;            // as vjn, for the friction pairs' refills
                 {
                     const unsigned long long l0 = mw[0];
 #pragma unroll
-                    for (int k = 0; k < kC; k++) {
-                        if ((k & 7) == 0) vjf = vsel(k, 2);
-                        ldFv((l0 >> k) & 1ull ? kFricB + (unsigned)k * 2u * kRecB : kZeroB, vjf, jA[k], jB[k], mA[k], mB[k]);
-                    }
+                    for (int k = 0; k < kC; k++)
+                        ldF((l0 >> k) & 1ull ? kFricB + (unsigned)k * 2u * kRecB : kZeroB, jA[k], jB[k], mA[k], mB[k]);
                 }
                 float4 fn = *reinterpret_cast<const float4*>(L.acc[0]);
                 for (int base = 0; base < nc_pad; base += kC) {
@@ -1525,8 +1455,7 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
                             *reinterpret_cast<float2*>(&L.acc[base + k][1]) = make_float2(aA, aB);
                         }
                         // the refill, issued after the step (the four registers are free then): the pair kC further on
-                        if ((k & 7) == 0) vjf = vsel(base + kC + k < nc_pad ? base + kC + k : base + k, 2);     // (past the end: nothing live to fetch)
-                        ldFv((lv >> (kC + k)) & 1ull ? kFricB + (unsigned)(base + kC + k) * 2u * kRecB : kZeroB, vjf, jA[k], jB[k], mA[k], mB[k]);
+                        ldF((lv >> (kC + k)) & 1ull ? kFricB + (unsigned)(base + kC + k) * 2u * kRecB : kZeroB, jA[k], jB[k], mA[k], mB[k]);
                     }
                 }
             } else {
