@@ -265,9 +265,10 @@ struct Lds<N, false> : LdsCommon<N, 2 * N> {
     // record order: the NCT normal rows, then the NCT friction pairs (A, B) -- each phase of the solve streams its own
     // rows back to back, every fetched cache line used whole (interleaved by contact, a phase used 320 of every 960
     // bytes and paid for the neighbours' half lines), then 3 rows that stay zero.  Inside a record the vectors are
-    // interleaved by column -- a normal's 320 bytes are [J0 M0 J1 M1 ...], a friction pair's 640 bytes
-    // [JA0 JB0 MA0 MB0 JA1 ...] -- so that lane d fetches everything it needs of a contact with ONE 8- or 16-byte
-    // load (one 320- / 640-byte request per contact instead of two / four of 160 bytes)
+    // interleaved by column -- a friction pair's 640 bytes are [JA0 JB0 MA0 MB0 JA1 ...], and the normals of contacts 2p,
+    // 2p + 1, which the solve resolves in one step, share 640 bytes [J(2p)0 M(2p)0 J(2p+1)0 M(2p+1)0 J(2p)1 ...] (since the end of
+    // round 4; 320 bytes per contact before: +1.5 %) -- so that lane d fetches everything it needs for a step with ONE
+    // 16-byte load
     static constexpr int kRows = 3 * NCT + 3;
     static constexpr int kFric = NCT;                      // first friction record
     // a row of the block: [J (ND floats), pad, M^-1 J^T (ND floats), pad], 320 B = five aligned 64-B
@@ -982,7 +983,9 @@ __device__ void build_rows_v1(LT& L, const DevModel& M, int lane, int nc, int& n
         }
         prevMn = Mo[0];
         if (colv) {
-            *reinterpret_cast<float2*>(rows + (size_t)ci * LT::kRS + 2 * d) = make_float2(Jo[0], Mo[0]);
+            // contacts 2p and 2p + 1 share a 640-byte record [J0 M0 J1 M1] per column: the solve resolves them in one
+            // step (row_step_normal2) and fetches them with one 16-byte load per lane
+            *reinterpret_cast<float2*>(rows + (size_t)(ci >> 1) * 2 * LT::kRS + 4 * d + 2 * (ci & 1)) = make_float2(Jo[0], Mo[0]);
             *reinterpret_cast<float4*>(rows + (size_t)(LT::kFric + 2 * ci) * LT::kRS + 4 * d) = make_float4(Jo[1], Jo[2], Mo[1], Mo[2]);
         }
         if (lane == 0) *reinterpret_cast<float4*>(L.acc[ci]) = make_float4(lam0, 0.f, 0.f, cpl);
@@ -1263,10 +1266,15 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
     // to a whole trip: 144 contacts -- 128 on the ground + 16 link-link -- cost 160)
     const int nc_pad = __builtin_amdgcn_readfirstlane((nc + 7) / 8 * 8);
     {
-        float* z = rows + (size_t)nc * LT::kRS;
+        // (normals in pairs: an odd count leaves the last contact's partner inside its record -- its two floats per column --,
+        //  then whole records)
+        const int nce = (nc + 1) & ~1;
+        if ((nc & 1) && lane < LT::kMO)
+            *reinterpret_cast<float2*>(rows + (size_t)(nc >> 1) * 2 * LT::kRS + 4 * lane + 2) = make_float2(0.f, 0.f);
+        float* z = rows + (size_t)nce * LT::kRS;
         float* zf = rows + (size_t)(LT::kFric + 2 * nc) * LT::kRS;
         const int nz = (nc_pad - nc) * LT::kRS;
-        for (int i = lane; i < nz; i += 64) z[i] = 0.f;
+        for (int i = lane; i < (nc_pad - nce) * LT::kRS; i += 64) z[i] = 0.f;
         for (int i = lane; i < 2 * nz; i += 64) zf[i] = 0.f;
         for (int i = lane; i < 4 * (nc_pad - nc); i += 64) L.acc[nc][i] = 0.f;
     }
@@ -1289,8 +1297,14 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     auto ldN = [&](unsigned rec_bytes, float& j, float& m) {       // {J, M^-1 J^T} of a normal's record
-        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, 2 * vcol, (int)rec_bytes, SNK_V1_LDAUX);
+        // (rec_bytes = contact x kRecB as before; inside its pair's record the contact's two floats sit at 16 d + 8 (ci & 1))
+        const unsigned odd = (rec_bytes / kRecB) & 1u;
+        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, 4 * vcol, (int)(rec_bytes - odd * kRecB + odd * 8u), SNK_V1_LDAUX);
         j = __uint_as_float(v.x); m = __uint_as_float(v.y);
+    };
+    auto ldN2 = [&](unsigned rec_bytes, float& j0, float& m0, float& j1, float& m1) {      // rec_bytes: of the EVEN contact
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, 4 * vcol, (int)rec_bytes, SNK_V1_LDAUX);
+        j0 = __uint_as_float(v.x); m0 = __uint_as_float(v.y); j1 = __uint_as_float(v.z); m1 = __uint_as_float(v.w);
     };
     auto ldF = [&](unsigned rec_bytes, float& ja, float& jb, float& ma, float& mb) {    // a friction pair's record
         const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, 4 * vcol, (int)rec_bytes, SNK_V1_LDAUX);
@@ -1308,7 +1322,7 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
     constexpr int kResN = INPLACE ? 32 : LT::kResN;
     float RNJ[kResN], RNM[kResN];
 #pragma unroll
-    for (int k = 0; k < kResN; k++) ldN((unsigned)k * kRecB, RNJ[k], RNM[k]);
+    for (int k = 0; k < kResN; k += 2) ldN2((unsigned)k * kRecB, RNJ[k], RNM[k], RNJ[k + 1], RNM[k + 1]);
     if (__builtin_amdgcn_readfirstlane(M.warm_start)) {
         // warm starting: the normal rows start at the impulses build_rows_v1 took from the contact cache, delta-v at the
         // sum of M^-1 J^T of those (the scalar columns' part of that sum is dropped again: lane kSpec stays 1, and
@@ -1366,7 +1380,7 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
             // accumulated impulse comes from LDS one step ahead.
             float jr[kRN], mr[kRN];
 #pragma unroll
-            for (int k = 0; k < kRN; k++) ldN((unsigned)(kResN + k) * kRecB, jr[k], mr[k]);
+            for (int k = 0; k < kRN; k += 2) ldN2((unsigned)(kResN + k) * kRecB, jr[k], mr[k], jr[k + 1], mr[k + 1]);
             // two contacts per step (row_step_normal2): {impulse of the even one, impulse and coupling of the odd one} come
             // from LDS one step ahead
             float a0n = L.acc[0][0];
@@ -1398,8 +1412,7 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
                     // (a cache hit instead of a fetch of rows nobody uses; no branch, the load is issued either way).
                     // Issued after the step: the register pairs are free then and take the new records as they are
                     if ((k & 7) == 0) rb = (unsigned)((base + kRN + k < nc_pad) ? base + kRN : base) * kRecB;
-                    ldN(rb + (unsigned)k * kRecB, jr[k], mr[k]);
-                    ldN(rb + (unsigned)(k + 1) * kRecB, jr[k + 1], mr[k + 1]);
+                    ldN2(rb + (unsigned)k * kRecB, jr[k], mr[k], jr[k + 1], mr[k + 1]);
                 }
             }
             if (cone) {
