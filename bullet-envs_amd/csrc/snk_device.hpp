@@ -219,6 +219,16 @@ struct LdsCommon {
 #ifndef SNK_LB
 #define SNK_LB 2
 #endif
+// (the same three numbers for the copy that runs inside the register-resident kernels, pgs_v1<LT, INPLACE = true>)
+#ifndef SNK_IP_RESN
+#define SNK_IP_RESN 32
+#endif
+#ifndef SNK_IP_RINGN
+#define SNK_IP_RINGN 32
+#endif
+#ifndef SNK_IP_RINGF
+#define SNK_IP_RINGF 16
+#endif
 #ifndef SNK_V1_LDAUX
 #define SNK_V1_LDAUX 0      // cache policy bits of the streamed rows' buffer loads (experiments: 1 sc0, 2 nt, 16 sc1)
 #endif
@@ -1260,7 +1270,7 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
     // kSpec + 1 the row's scalars (160 contiguous bytes per half row: coalesced); the other lanes sit the solve out.
     // The rows and impulses of the contacts between nc and the end of the last group are zeroed: resolving them
     // changes nothing (dI = 0 exactly).
-    constexpr int kRN = INPLACE ? 32 : LT::kRingN;      // normals in flight
+    constexpr int kRN = INPLACE ? SNK_IP_RINGN : LT::kRingN;      // normals in flight
     // contacts are resolved in groups of 8 behind one scalar branch: the rows between nc and the next multiple of 8
     // are zeroed (inert), a ring trip ends at that multiple instead of running its full depth (round 1 padded
     // to a whole trip: 144 contacts -- 128 on the ground + 16 link-link -- cost 160)
@@ -1319,7 +1329,7 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
     for (int j = 0; j < N; j++) RMm[j] = ldJ((unsigned)(LT::kMmOff * 4) + (unsigned)(6 + j) * kHalfB);   // columns >= ND: zero
     // ... and so do the normal rows of the first kResN contacts: the registers the rings leave free hold an eighth of
     // the stream (the kernel is bound by that stream)
-    constexpr int kResN = INPLACE ? 32 : LT::kResN;
+    constexpr int kResN = INPLACE ? SNK_IP_RESN : LT::kResN;
     float RNJ[kResN], RNM[kResN];
 #pragma unroll
     for (int k = 0; k < kResN; k += 2) ldN2((unsigned)k * kRecB, RNJ[k], RNM[k], RNJ[k + 1], RNM[k + 1]);
@@ -1422,7 +1432,7 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
                 // six.  Its step is skipped and its record is not fetched: `live`, one bit per contact, is fixed for the
                 // whole phase (the normal impulses are this iteration's final ones, a pair's own impulses only change
                 // at its own step), built with four ballots and kept in SGPRs, so a step's test is scalar.
-                constexpr int kC = INPLACE ? 16 : LT::kRingF;
+                constexpr int kC = INPLACE ? SNK_IP_RINGF : LT::kRingF;
                 // (the solve runs on lanes 0 .. kMO - 1: one ballot covers kMO contacts; kP ballots, kW 64-bit words)
                 constexpr int kP = (LT::NCT + LT::kMO - 1) / LT::kMO, kW = (kP * LT::kMO + 63) / 64;
                 unsigned long long mw[kW + 1];
