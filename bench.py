@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """bench.py -- env-steps/s of the batched snake stepper on N MI355X (one process per GPU).
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W            (any N: for N > 1 and no WORLD_SIZE in the environment
+                                                               the ranks are launched from here, as a child process)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -289,6 +290,39 @@ def measure_variant(pkg, torch, dev, device_index, E, NL, K, W, friction_seed=No
     return out
 
 
+def self_launch(n, argv):
+    """`python bench.py --gpus N` from a plain shell, N > 1: the reference's SubprocVecEnv fans out by itself when it is
+    constructed (ppo/multiprocessing_env.py:97-117); so does this.  One rank per GPU is started through
+    torch.distributed.run as a CHILD process (never an exec: this parent has not touched the GPU and never will), on a
+    port taken from a bound socket; rank 0's JSON line is relayed as this process's only stdout line, everything else
+    the ranks print goes to stderr, and the exit code is the child's."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", SNK_BENCH_SELF_LAUNCHED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: what RCCL needs on this pool's hosts
+    env.setdefault("OMP_NUM_THREADS", "1")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True, cwd=ROOT)
+    line = None
+    for ln in proc.stdout:
+        if ln.startswith("{") and line is None:
+            line = ln.rstrip("\n")
+        else:
+            sys.stderr.write(ln)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        sys.stderr.write("bench.py: the ranks exited 0 but rank 0 printed no JSON line\n")
+        rc = 1
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -329,10 +363,11 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # a plain shell: launch the ranks ourselves, BEFORE torch or any HIP call in this process
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with torch.distributed.run (one process per GPU)")
         args.gpus = world
 
     cpu = None
@@ -351,8 +386,13 @@ def main():
     E, K, W = args.envs_per_gpu, args.steps, args.warmup
     NL = args.links
     A = NL // 2
+    n_dev = torch.cuda.device_count()                 # (counting devices does not initialise the GPU)
     if os.environ.get("SNK_BENCH_BACKEND", "nccl") != "nccl":
-        local_rank = local_rank % max(1, torch.cuda.device_count())   # rehearsal: the ranks share the GPUs there are
+        local_rank = local_rank % max(1, n_dev)       # rehearsal: the ranks share the GPUs there are
+    elif world > n_dev:
+        # one process per GPU: refuse rather than put two RCCL ranks on one device
+        raise SystemExit("bench.py: --gpus %d but this node shows %d GPU(s) (torch.cuda.device_count()); "
+                         "SNK_BENCH_BACKEND=gloo rehearses N ranks on fewer GPUs" % (world, n_dev))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -402,9 +442,15 @@ def main():
         for j in range(total):
             acts_all[j] = torch.from_numpy(gait_actions(gids, j, A).astype(np.float32)).to(dev)
         O = local.obs_dim
-        h_obs = torch.empty((world * E, O), dtype=torch.float32).pin_memory()
-        h_rew = torch.empty((world * E,), dtype=torch.float32).pin_memory()
-        h_done = torch.empty((world * E,), dtype=torch.bool).pin_memory()
+        if world > 1:
+            # the gathered [world * E, O + 2] block comes to the host as it is, in ONE contiguous copy; obs / reward /
+            # done are host-side views of the pinned buffer (no strided-copy kernel on the root)
+            h_all = torch.empty((world * E, O + 2), dtype=torch.float32).pin_memory()
+            h_obs, h_rew, h_done = h_all[:, :O], h_all[:, O], h_all.view(torch.int32)[:, O + 1]
+        else:
+            h_obs = torch.empty((E, O), dtype=torch.float32).pin_memory()
+            h_rew = torch.empty((E,), dtype=torch.float32).pin_memory()
+            h_done = torch.empty((E,), dtype=torch.uint8).pin_memory()      # the kernel's own done bytes (0 / 1)
     sub_total = torch.zeros((), dtype=torch.int64, device=dev)
 
     if world > 1:
@@ -428,17 +474,20 @@ def main():
             sub_total.add_(local.substeps.sum())
             h_obs.copy_(obs, non_blocking=True)
             h_rew.copy_(rew, non_blocking=True)
-            h_done.copy_(done.to(torch.bool), non_blocking=True)
+            h_done.copy_(done, non_blocking=True)
             return
         if world > 1:
-            obs, rew, done, _ = env.step(acts_all[j] if rank == 0 else None)
-        else:
-            obs, rew, done = local.step(acts_all[j])
+            blk = env.step_block(acts_all[j] if rank == 0 else None)
+            sub_total.add_(local.substeps.sum())
+            if rank == 0:     # trainer side: the whole block to pinned host memory, one contiguous D2H copy
+                h_all.copy_(blk, non_blocking=True)
+            return
+        obs, rew, done = local.step(acts_all[j])
         sub_total.add_(local.substeps.sum())
-        if rank == 0:     # trainer side: results to pinned host memory
-            h_obs.copy_(obs, non_blocking=True)
-            h_rew.copy_(rew, non_blocking=True)
-            h_done.copy_(done.to(torch.bool) if done.dtype != torch.bool else done, non_blocking=True)
+        # trainer side: results to pinned host memory (three contiguous tensors, three copies, no kernel)
+        h_obs.copy_(obs, non_blocking=True)
+        h_rew.copy_(rew, non_blocking=True)
+        h_done.copy_(done, non_blocking=True)
 
     for j in range(W):
         one_step(j)
@@ -541,6 +590,7 @@ def main():
                 "world_size": (dist.get_world_size() if dist is not None else 1),
                 "backend": (dist.get_backend() if dist is not None else None),
                 "ranks": ranks,
+                "self_launched": bool(os.environ.get("SNK_BENCH_SELF_LAUNCHED")),
                 "parallelism": "envs sharded over %d GPU(s), no data-path collective; "
                                "RCCL actions scatter + obs/reward/done gather to rank 0" % world
                                if world > 1 else "1 GPU, one wavefront per env",

@@ -13,12 +13,10 @@ ShardedVecEnv  one process per GPU (torch.distributed, backend "nccl" = RCCL ove
 Replaces the Pipe fan-out/fan-in of SubprocVecEnv (ppo/multiprocessing_env.py:119-128).
 torch is plumbing here (device memory, streams, process groups); it computes nothing.
 """
-import types
-
 import numpy as np
 
 from . import _lib
-from .snake_env import params_from_args
+from .snake_env import FrozenInfo, params_from_args
 
 
 class DeviceVecEnv(object):
@@ -77,13 +75,18 @@ class DeviceVecEnv(object):
 class ShardedVecEnv(object):
     """Envs sharded over the ranks of a process group; SubprocVecEnv API on the root rank.
 
-    local_env: object with num_envs, obs_dim, act_dim, reset() -> obs tensor [E,O] and
-               step(actions tensor [E,A]) -> (obs [E,O], rew [E], done [E]) on `device`.
+    local_env: object with num_envs, obs_dim, act_dim, reset() -> obs tensor [E,O], and either
+               step_packed(actions tensor [E,A], packed tensor [E,O+2]) writing rows [obs | reward | done] into
+               `packed` itself (DeviceVecEnv: the step kernel does; the done cell holds the INTEGER 0 / 1, i.e. its
+               int32 bits inside the float32 block) -- or, without that method, the plain
+               step(actions) -> (obs [E,O], rew [E], done [E]) on `device`, whose results are then copied into the block.
     Every rank must call reset()/step() collectively; non-root ranks pass actions=None and get
     (None, None, None, ()) back.
+    fresh_infos: True = a fresh dict per env per step, as the reference's workers send (32 768 dicts cost the root of 8
+    ranks about 1 ms of every step); False (default) = one read-only, picklable FrozenInfo repeated.
     """
 
-    def __init__(self, local_env, root=0, group=None, device=None):
+    def __init__(self, local_env, root=0, group=None, device=None, fresh_infos=False):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
@@ -111,7 +114,8 @@ class ShardedVecEnv(object):
             self._act_all = torch.zeros((self.num_envs, self.A), dtype=torch.float32, device=self._xdev)
         else:
             self._gather_list = None
-        self._infos = None
+        self._infos = None if fresh_infos else (FrozenInfo(),) * self.num_envs
+        self._packed_step = hasattr(local_env, "step_packed")
 
     def __len__(self):
         return self.num_envs
@@ -141,7 +145,21 @@ class ShardedVecEnv(object):
     def step(self, actions=None):
         """The root's `actions` (tensor or ndarray [world * E, A] or [.., A, 1]) are NOT modified: SubprocVecEnv pickles
         them to its workers (ppo/multiprocessing_env.py:119-122), so checkBound (SnakeGymEnv.py:82-88) only ever clips
-        the workers' copies -- here the scattered copies, which the step kernels clip."""
+        the workers' copies -- here the scattered copies, which the step kernels clip.
+        Returns VIEWS of the gathered block (obs [:, :O], reward [:, O], done from the integer cell [:, O + 1]); a
+        caller that moves the results on (to the host, into a rollout buffer) should take step_block() and move the
+        contiguous block in one copy."""
+        t = self.torch
+        allp = self.step_block(actions)
+        if allp is None:
+            return None, None, None, ()
+        infos = self._infos if self._infos is not None else tuple({} for _ in range(self.num_envs))
+        # the done cell holds the integer 0 / 1 (its bits travel in the float32 block)
+        return allp[:, :self.O], allp[:, self.O], allp.view(t.int32)[:, self.O + 1] != 0, infos
+
+    def step_block(self, actions=None):
+        """One collective env-step; on the root returns the contiguous [world * E, O + 2] float32 block on `device`
+        (rows [obs | reward | done as int32 bits], env g in row g), None elsewhere.  Valid until the next call."""
         t = self.torch
         if self.rank == self.root:
             a = t.as_tensor(actions, dtype=t.float32)       # shares memory with a float32 ndarray / tensor
@@ -155,17 +173,16 @@ class ShardedVecEnv(object):
         self.dist.scatter(self._act, chunks, src=self.root, group=self.group)
         # the local env writes its rows [obs | reward | done] into the block itself (DeviceVecEnv: the step kernel does,
         # snk_step_packed): nothing is copied between the physics and the gather
-        self.env.step_packed(self._act if self._xdev == self.device else self._act.to(self.device), self._pack)
-        allp = self._gather()
-        if allp is None:
-            return None, None, None, ()
-        if self._infos is None:
-            # train mode: empty dicts (SnakeGymEnv.py:46-47).  Made once -- 32 768 fresh dicts per step at 8 ranks would
-            # cost the root 2 ms of every step -- and READ-ONLY, so that a wrapper writing into infos[i] fails loudly
-            # instead of leaking its entries into every later step's infos
-            self._infos = (types.MappingProxyType({}),) * self.num_envs
-        # the done cell holds the integer 0 / 1 (its bits travel in the float32 block)
-        return allp[:, :self.O], allp[:, self.O], allp.view(t.int32)[:, self.O + 1] != 0, self._infos
+        a_loc = self._act if self._xdev == self.device else self._act.to(self.device)
+        if self._packed_step:
+            self.env.step_packed(a_loc, self._pack)
+        else:
+            # a local env with the plain contract: its results copied into the block (three small copies per step)
+            obs, rew, done = self.env.step(a_loc)
+            self._pack[:, :self.O] = obs
+            self._pack[:, self.O] = rew
+            self._pack.view(t.int32)[:, self.O + 1] = (t.as_tensor(done) != 0).to(t.int32)
+        return self._gather()
 
     def close(self):
         if hasattr(self.env, "close"):

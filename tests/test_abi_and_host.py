@@ -180,3 +180,19 @@ def test_vec_env_module_surface(pkg):
     w2 = pickle.loads(pickle.dumps(w))
     assert w2.x() == 8 and w2() == 8 and w.x() == 8
     assert issubclass(pkg.SubprocVecEnv, pkg.VecEnv)
+
+
+def test_bench_plain_multi_gpu_invocation_refuses_cleanly_without_the_gpus():
+    """The same plain invocation where the GPUs are not there (this container: none; a 1-GPU box: one): the ranks
+    refuse with a message naming the counts, the parent relays the launcher's non-zero exit code and prints no JSON."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs here: the invocation would run")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "SNK_BENCH_BACKEND")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and out.stdout.strip() == ""
+    assert "--gpus 2 but this node shows" in out.stderr

@@ -14,8 +14,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 E, STEPS = 2, 3
 
 
-class OracleLocalEnv:
-    """DeviceVecEnv look-alike on the CPU: E oracle envs, torch CPU tensors."""
+class PlainOracleLocalEnv:
+    """DeviceVecEnv look-alike on the CPU: E oracle envs, torch CPU tensors; the PLAIN local-env contract
+    (reset / step only: ShardedVecEnv copies the results into its block itself)."""
 
     def __init__(self, ids):
         import torch
@@ -39,6 +40,9 @@ class OracleLocalEnv:
                 t.tensor(d, dtype=t.uint8))
 
 
+
+
+class OracleLocalEnv(PlainOracleLocalEnv):
     def step_packed(self, actions, packed):
         """The form ShardedVecEnv calls: rows [obs | reward | done (integer bits)] written by the local env itself."""
         o, r, d = self.step(actions)
@@ -55,7 +59,7 @@ def _actions(j, n):
     return a * np.float32(1.5) if j == 1 else a       # step 1 leaves the [-1, 1] box: checkBound must clip it
 
 
-def _worker(rank, world, port, out_path, root):
+def _worker(rank, world, port, out_path, root, plain=False):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
@@ -64,8 +68,8 @@ def _worker(rank, world, port, out_path, root):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     pkg = importlib.import_module("bullet-envs_amd")
-    local = OracleLocalEnv(list(range(rank * E, (rank + 1) * E)))
-    env = pkg.ShardedVecEnv(local, root=root)
+    local = (PlainOracleLocalEnv if plain else OracleLocalEnv)(list(range(rank * E, (rank + 1) * E)))
+    env = pkg.ShardedVecEnv(local, root=root, fresh_infos=plain)
     assert env.num_envs == world * E and len(env) == world * E
     assert env.shard_slice() == slice(rank * E, (rank + 1) * E)
     res = {}
@@ -83,6 +87,14 @@ def _worker(rank, world, port, out_path, root):
             assert np.array_equal(acts, _actions(j, world * E))
             obs, rew, done, infos = out
             assert len(infos) == world * E and obs.shape == (world * E, 56)
+            import pickle
+            assert isinstance(infos[0], dict) and infos[0] == {} and pickle.loads(pickle.dumps(infos))[1] == {}
+            if plain:        # fresh dicts, writable, as the reference's workers send them
+                infos[0]["episode"] = j
+                assert infos[1] == {}
+            else:            # one shared dict: writing must fail loudly rather than leak into every env and step
+                with pytest.raises(TypeError):
+                    infos[0]["episode"] = j
             res["obs%d" % j] = obs.numpy().copy()
             res["rew%d" % j] = rew.numpy().copy()
             res["done%d" % j] = done.numpy().copy()
@@ -94,15 +106,16 @@ def _worker(rank, world, port, out_path, root):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,root", [(2, 0), (4, 3), (8, 5)])
-def test_sharded_env_gloo(tmp_path, oracle_mod, world, root):
+@pytest.mark.parametrize("world,root,plain", [(2, 0, False), (4, 3, False), (8, 5, False), (2, 1, True)])
+def test_sharded_env_gloo(tmp_path, oracle_mod, world, root, plain):
+    """plain: a local env with reset() / step() only (no step_packed) and fresh_infos=True."""
     import torch.multiprocessing as mp
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     out_path = str(tmp_path / "sharded.npz")
-    mp.spawn(_worker, args=(world, port, out_path, root), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, out_path, root, plain), nprocs=world, join=True)
     got = np.load(out_path)
     # the same world * E envs stepped directly, unsharded: global env g lives on rank g // E whoever the trainer rank is
     ref = [oracle_mod.OracleEnv() for _ in range(world * E)]

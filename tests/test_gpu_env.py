@@ -118,6 +118,11 @@ def test_vec_env_semantics(pkg, oracle_mod):
         assert np.array_equal(a, a_before)
         assert isinstance(obs, np.ndarray) and rews.shape == (B,) and dones.dtype == bool
         assert isinstance(infos, tuple) and len(infos) == B and infos[0] == {}
+        # a fresh, writable, picklable dict per env per step, as the reference's workers send: a wrapper
+        # may annotate one env's info without touching another's or a later step's
+        assert type(infos[0]) is dict and infos[0] is not infos[1]
+        infos[0]["episode"] = j
+        assert infos[1] == {}
         assert (1 - dones).sum() + dones.sum() == B                        # ppo/train.py:134
         if dones.any():
             seen_done = True
@@ -128,6 +133,15 @@ def test_vec_env_semantics(pkg, oracle_mod):
     assert seen_done
     env.close()
     env.close()   # idempotent like SubprocVecEnv.close
+    # the opt-in form: ONE read-only dict for every env and step; still a dict, still picklable, writing fails loudly
+    import pickle
+    env = pkg.SnakeVecEnv(4, shared_infos=True)
+    env.reset()
+    infos = env.step(gait(range(4), 0))[3]
+    assert isinstance(infos[0], dict) and infos[0] == {} and pickle.loads(pickle.dumps(infos)) == ({},) * 4
+    with pytest.raises(TypeError):
+        infos[0]["episode"] = 1
+    env.close()
 
 
 def test_single_env_api(pkg):
@@ -664,32 +678,33 @@ def test_free_running_gait_aggregates(pkg, oracle_mod):
 
 @pytest.mark.gpu
 def test_bench_multi_rank_rehearsal():
-    """bench.py's N > 1 path (one process per rank, ShardedVecEnv scatter/gather, max-over-ranks timing, rank 0
-    prints the one JSON line), rehearsed with two ranks that share this box's GPU over the gloo backend
-    (SNK_BENCH_BACKEND=gloo: host-staged collectives; the RCCL form of the same calls is covered by
+    """`python bench.py --gpus 2` from a PLAIN shell (no torchrun around it, no WORLD_SIZE): bench.py launches its own
+    ranks as a child process (the reference's SubprocVecEnv fans out by itself,
+    ppo/multiprocessing_env.py:97-128), ShardedVecEnv scatter / gather, max-over-ranks timing, and rank 0's one JSON
+    line comes back as the parent's only stdout line.  Rehearsed with two ranks that share this box's GPU over the
+    gloo backend (SNK_BENCH_BACKEND=gloo: host-staged collectives; the RCCL form of the same calls is covered by
     test_sharded_env_over_rccl_world1 and runs on the driver's 8-GPU node)."""
     import json
     import subprocess
     import sys
-    import socket
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, SNK_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
-    s = socket.socket()                      # a free port, from a bound socket (as tests/test_dist_gloo.py does)
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    # two ranks: with the launcher and pytest that is four processes with the GPU open, inside the box's limit of six
-    # (rehearsals with more ranks belong to the CPU gloo tests: tests/test_dist_gloo.py runs 2 / 4 / 8)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["SNK_BENCH_BACKEND"] = "gloo"
+    # two ranks: with the launcher, the parent bench.py (which never opens the GPU) and pytest that is at most four
+    # processes with the GPU open, inside the box's limit of six (more ranks: tests/test_dist_gloo.py runs 2 / 4 / 8)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
            "--envs-per-gpu", "512"]
     out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
-    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, out.stdout[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), out.stdout[-2000:]      # the ONE line, nothing else on stdout
     r = json.loads(lines[0])
     assert r["n_gpus"] == 2 and r["steps"] == 2 and r["scaling"] == "weak" and r["value"] > 0
     assert r["config"]["envs_per_gpu"] == 512 and r.get("cpu_baseline") is None      # the CPU baseline is an N = 1 leg
+    assert r["config"]["world_size"] == 2 and r["config"]["backend"] == "gloo" and r["config"]["self_launched"] is True
+    pids = {k["pid"] for k in r["config"]["ranks"]}
+    assert len(pids) == 2 and os.getpid() not in pids, r["config"]["ranks"]
+    assert sorted(k["rank"] for k in r["config"]["ranks"]) == [0, 1]
 
 
 @pytest.mark.gpu
