@@ -1,0 +1,266 @@
+"""The reference's OUTER seam and its callers, pinned by vectors from RUNNING them (tests/golden/make_vecenv_vectors.py):
+/root/reference/ppo/multiprocessing_env.py's SubprocVecEnv with 16 forked workers (Pipes, np.stack order, auto-reset
+inside the workers), driven by /root/reference/ars/train.py (ARS.__init__, test_envs twice: (16, 8, 1) float64 actions,
+`total_reward += reward`) and by /root/reference/ppo/train.py::train for 40 frames ((16, 8) float32 actions,
+`total_reward += sum(reward)`, `1 - done`, and utils.test_env on the trainer's single env at frame 40) -- each env a
+reference Snake + SnakeGymEnv on an oracle-backed client.  As everywhere, what stepSimulation computes is the oracle's
+restatement of Bullet (parity unpinned); what is pinned here is the seam: env order, shapes, dtypes, the
+workers' auto-reset, the trainers' arithmetic on what the seam returns.
+
+CPU (`-m "not gpu"`): 16 oracle envs, free-running from the reset on (no re-synchronisation over 100 / 40 vector steps),
+reproduce every stacked observation / reward / done / substep count of the reference's SubprocVecEnv, and the
+trainers' own numbers follow from them.
+GPU (`-m gpu`): the product's SubprocVecEnv (one HIP handle behind the reference's API), given the same action arrays
+-- shape and dtype as the trainers pass them -- from the same pre-step states: counts and dones exact off the servo
+boundary, observations and rewards within the float32 tolerance (calibrated against the float32 build of the oracle,
+hard outer caps), env order and the returned types as the reference's."""
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+VEC = os.path.join(HERE, "golden", "vecenv_vectors.npz")
+NENV, N, O = 16, 16, 56
+
+
+@pytest.fixture(scope="module")
+def vec():
+    d = np.load(VEC, allow_pickle=False)
+    return {k: d[k] for k in d.files}
+
+
+def test_what_the_reference_seam_returns(vec):
+    v = vec
+    # ARS passes (16, 8, 1) float64 (ars/train.py:95-99), PPO (16, 8) float32 (ppo/train.py:122)
+    assert v["ars_actions"].shape == (100, NENV, 8, 1) and v["ars_actions"].dtype == np.float64
+    assert v["ppo_actions"].shape == (40, NENV, 8) and v["ppo_actions"].dtype == np.float32
+    for t in ("ars_", "ppo_"):
+        assert v[t + "obs"].shape[1:] == (NENV, O) and v[t + "rews"].shape[1:] == (NENV,) and v[t + "dones"].shape[1:] == (NENV,)
+        assert list(v[t + "dtypes"]) == ["float64", "float64", "bool"]           # np.stack of the workers' tuples
+        assert v[t + "resets"].shape[1:] == (NENV, O)
+    assert list(v["ars_reset_before_step"]) == [0, 50] and list(v["ppo_reset_before_step"]) == [0]
+    assert tuple(v["ars_obs_space_shape"]) == (O,) and tuple(v["ars_act_space_shape"]) == (8,)
+    assert v["ppo_dones"].sum() >= 50 and v["ars_dones"].sum() >= 1 and (np.abs(v["ppo_actions"]) > 1).any()
+    assert (v["ars_substeps"] == 0).any() and v["ppo_substeps"].max() >= 30
+
+
+def _free_run(v, t, oracle_mod, on_step=None):
+    """16 oracle envs through trainer t's whole call sequence; returns nothing, asserts everything."""
+    envs = [oracle_mod.OracleEnv() for _ in range(NENV)]
+    T = len(v[t + "obs"])
+    resets = {int(s): i for i, s in enumerate(v[t + "reset_before_step"])}
+    done_row = 0
+    for j in range(T):
+        if j in resets:
+            got = np.stack([e.reset() for e in envs])
+            assert np.array_equal(got, v[t + "resets"][resets[j]]), (t, j)
+        if t == "ppo_" or j % 5 == 0:
+            S = v["ppo_state"][j] if t == "ppo_" else v["ars_state_every5"][j // 5]
+            for i, e in enumerate(envs):
+                assert np.array_equal(e.get_state(), S[i]), (t, j, i)            # the workers' own pre-step states
+        if on_step is not None:
+            on_step(j, envs)
+        a = v[t + "actions"][j].reshape(NENV, -1).astype(np.float64)
+        for i, e in enumerate(envs):                                             # env i <- row i, result i -> row i
+            o, r, d, k, _ = e.env_step(a[i].copy(), vec_mode=True)
+            assert k == v[t + "substeps"][j, i] and d == bool(v[t + "dones"][j, i]), (t, j, i, k, d)
+            assert abs(r - v[t + "rews"][j, i]) < 1e-9 and np.abs(o - v[t + "obs"][j, i]).max() < 1e-9, (t, j, i)
+            if d:
+                done_row += 1
+    assert done_row == len(v[t + "terminal_obs"])
+
+
+@pytest.mark.parametrize("t", ["ars_", "ppo_"])
+def test_sixteen_oracle_envs_reproduce_the_reference_subprocvecenv(vec, oracle_mod, t):
+    _free_run(vec, t, oracle_mod)
+
+
+def test_the_trainers_arithmetic_on_what_the_seam_returns(vec):
+    v = vec
+    # ARS (ars/train.py:82, 107): `total_reward = [0.0]*16`, then `total_reward += reward` with reward an ndarray: the
+    # list is coerced, the result is the per-env running sum (an ndarray of 16), one per call of test_envs
+    for name, rows in (("ars_reward_p", range(0, 50)), ("ars_reward_n", range(50, 100))):
+        total = [0.0] * NENV
+        for j in rows:
+            total += v["ars_rews"][j]
+        assert isinstance(total, np.ndarray) and np.array_equal(total, v[name])
+    # PPO (ppo/train.py:123, 176): total_reward += sum(reward) over an epoch's 20 steps -> writer 'reward/episode'
+    tags, vals, frames = v["ppo_scalar_tags"], v["ppo_scalar_values"], v["ppo_scalar_frames"]
+    ep = [(int(f), float(x)) for g, x, f in zip(tags, vals, frames) if g == "reward/episode"]
+    assert [f for f, _ in ep] == [20, 40]
+    for e, (f, x) in enumerate(ep):
+        total = 0.0
+        for j in range(20 * e, 20 * e + 20):
+            total += sum(v["ppo_rews"][j])
+        assert total == x
+    # masks (ppo/train.py:134): 1 - done on the stacked bool array
+    assert (1 - v["ppo_dones"][3]).dtype.kind == "i" and set(np.unique(1 - v["ppo_dones"])) == {0, 1}
+    # the policy test at frame 40 (ppo/train.py:145, utils.py:70-90): mean over two episodes of <= 10 steps on the
+    # trainer's single env; SnakeGymEnv.step's own returns are in the eval records
+    r, d = v["ppo_eval_env_reward"], v["ppo_eval_done"]
+    eps, cur, steps = [], 0, 0
+    for i in range(len(r)):
+        cur += r[i]
+        steps += 1
+        if d[i] or steps == 10:
+            eps.append(cur)
+            cur, steps = 0, 0
+    assert len(eps) == 2 and steps == 0
+    tr = [float(x) for g, x in zip(tags, vals) if g == "test_reward"]
+    assert len(tr) == 1 and tr[0] == np.mean(eps)
+
+
+def _eval_free_run(v, oracle_mod, on_step=None):
+    """utils.test_env's two episodes (ppo/utils.py:70-90) on one oracle env, free-running: reset, then SnakeGymEnv.step
+    directly until done or 10 steps."""
+    e = oracle_mod.OracleEnv()
+    steps, fresh, episodes = 0, True, 0
+    for i in range(len(v["ppo_eval_substeps"])):
+        if fresh:
+            e.reset()
+            episodes += 1
+            fresh = False
+        assert np.array_equal(e.get_state(), v["ppo_eval_state"][i]), i
+        assert np.array_equal(np.concatenate([e.get_aux()[0], e.get_aux()[1:]]), v["ppo_eval_aux"][i]), i
+        if on_step is not None:
+            on_step(i, e)
+        o, r, d, k, a = e.env_step(v["ppo_eval_action_in"][i, :8].copy(), vec_mode=False)
+        assert k == v["ppo_eval_substeps"][i] and d == bool(v["ppo_eval_done"][i]), i
+        assert abs(r - v["ppo_eval_env_reward"][i]) < 1e-9 and np.abs(o - v["ppo_eval_env_obs"][i]).max() < 1e-9, i
+        steps += 1
+        if d or steps == 10:
+            fresh, steps = True, 0
+    assert episodes == 2 and fresh
+
+
+def test_oracle_reproduces_the_trainers_eval_env(vec, oracle_mod):
+    """utils.test_env drives SnakeGymEnv.step directly (float32 (8,) actions): the terminal observation comes back on done
+    (no auto-reset), the caller resets -- and the soft reset keeps the contact cache (the second episode starts with
+    the first one's points: manifold_points > 0 on its first row)."""
+    _eval_free_run(vec, oracle_mod)
+    assert vec["ppo_eval_done"].any() and (np.abs(vec["ppo_eval_action_in"]) > 1).any()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("t", ["ars_", "ppo_"])
+def test_gpu_subprocvecenv_reproduces_the_reference_seam(vec, pkg, oracle_mod, t):
+    v = vec
+
+    def make_env():
+        def _thunk():                                       # ars/train.py:27-33, ppo/utils.py:63-68
+            robot = pkg.Snake(None, "snake/snake.urdf", None)
+            return pkg.SnakeGymEnv(robot, None)
+        return _thunk
+    envs = pkg.SubprocVecEnv([make_env() for _ in range(NENV)])
+    assert envs.num_envs == NENV and envs.observation_space.shape == (O,) and envs.action_space.shape == (8,)
+    e32 = oracle_mod.OracleEnv(f32=True)
+    stats = dict(mism=0, mism32=0, compared=0, q=0.0, r=0.0, qd=[], cq=0.0, cr=0.0, cqd=[], resets=0)
+    totals = {"list": [0.0] * NENV, "sum": 0.0}
+    done_index = np.cumsum(v[t + "dones"].reshape(-1)) - 1          # row of terminal_obs for a done at (step, env)
+
+    def on_step(j, oracles):
+        if j in [int(s) for s in v[t + "reset_before_step"]]:
+            got = envs.reset()
+            assert isinstance(got, np.ndarray) and got.shape == (NENV, O)
+            assert np.array_equal(got, v[t + "resets"][stats["resets"]].astype(np.float32))
+            stats["resets"] += 1
+        # the product's envs start the step where the reference's workers did (the oracle envs hold those states)
+        S = np.stack([e.get_state() for e in oracles])
+        X = np.stack([np.concatenate([e.get_aux()[0], e.get_aux()[1:]]) for e in oracles])
+        M = np.stack([e.get_manifold() for e in oracles])
+        envs._stepper.set_state(S, X)
+        envs._stepper.set_manifold(M)
+        a = v[t + "actions"][j]                              # as the trainer passes it: (16, 8, 1) f64 / (16, 8) f32
+        a_before = a.copy()
+        obs, rews, dones, infos = envs.step(a)
+        assert np.array_equal(a, a_before)                  # the reference pickles the actions to its workers
+        assert isinstance(obs, np.ndarray) and obs.shape == (NENV, O) and rews.shape == (NENV,) and dones.shape == (NENV,)
+        assert dones.dtype == np.bool_ and isinstance(infos, tuple) and len(infos) == NENV and infos[3] == {}
+        # float32 where the reference's np.stack gives float64: the GPU computes in float32
+        assert obs.dtype == np.float32 and rews.dtype == np.float32
+        # the trainers' own expressions on what came back
+        totals["list"] += rews                              # ars/train.py:107 (a list at first: numpy coerces it)
+        totals["sum"] += sum(rews)                          # ppo/train.py:123
+        assert (1 - dones).sum() + dones.sum() == NENV
+        sub = envs.last_substeps
+        for i in range(NENV):
+            k_ref, d_ref = int(v[t + "substeps"][j, i]), bool(v[t + "dones"][j, i])
+            o_ref, r_ref = v[t + "obs"][j, i], float(v[t + "rews"][j, i])
+            if sub[i] != k_ref or bool(dones[i]) != d_ref:
+                # legitimate only AT a decision boundary (tests/test_env_logic_golden.py has the reasoning): the servo
+                # error where the two part ways is within float32 round-off of the 0.05 tolerance, or |q9| of 0.5
+                stats["mism"] += 1
+                kg = int(sub[i])
+                assert abs(kg - k_ref) <= 1, (t, j, i, kg, k_ref)
+                if kg != k_ref:
+                    e_dec = float(v[t + "servo_err"][j, i, min(kg, k_ref) - 1])      # the error where the two part ways
+                    assert abs(e_dec - 0.05) < 1.5e-3 + 2e-4 * k_ref, (t, j, i, kg, k_ref, e_dec)
+                else:
+                    # equal counts, another done: |q9| of the observation the step ended on within round-off of 0.5
+                    q9 = v[t + "terminal_obs"][done_index[j * NENV + i]][9] if d_ref else o_ref[9]
+                    assert abs(abs(q9) - 0.5) < 2e-3, (t, j, i, q9)
+                continue
+            stats["compared"] += 1
+            if d_ref:       # the worker's auto-reset: the POST-reset observation comes back, the reward carries the -5
+                assert np.all(obs[i, :2 * N] == 0) and np.all(obs[i, 3 * N:3 * N + 3] == 0) and np.all(obs[i, 3 * N + 3:3 * N + 7] == [0, 0, 0, 1])
+            e32.hard_reset()
+            e32.sync(S[i], X[i], M[i])
+            o32, r32, d32, k32, _ = e32.env_step(a.reshape(NENV, -1)[i].astype(np.float64), vec_mode=True)
+            stats["q"] = max(stats["q"], np.abs(obs[i, :N] - o_ref[:N]).max(), np.abs(obs[i, 3 * N:3 * N + 7] - o_ref[3 * N:3 * N + 7]).max())
+            stats["qd"].append((np.abs(obs[i, N:2 * N] - o_ref[N:2 * N]) / (1 + np.abs(o_ref[N:2 * N]))).max())
+            stats["r"] = max(stats["r"], abs(float(rews[i]) - r_ref))
+            if k32 != k_ref or d32 != d_ref:
+                stats["mism32"] += 1
+            else:
+                stats["cq"] = max(stats["cq"], np.abs(o32[:N] - o_ref[:N]).max(), np.abs(o32[3 * N:3 * N + 7] - o_ref[3 * N:3 * N + 7]).max())
+                stats["cqd"].append((np.abs(o32[N:2 * N] - o_ref[N:2 * N]) / (1 + np.abs(o_ref[N:2 * N]))).max())
+                stats["cr"] = max(stats["cr"], abs(r32 - r_ref))
+
+    _free_run(v, t, oracle_mod, on_step=on_step)
+    envs.close()
+    T = len(v[t + "obs"])
+    p90, p90c = float(np.percentile(stats["qd"], 90)), float(np.percentile(stats["cqd"], 90))
+    print("%s GPU SubprocVecEnv vs the reference's (%d of %d env-steps compared, %d boundary mismatches; float32 oracle %d): "
+          "worst q/pose %.2e reward %.2e qd p90 %.2e | float32 oracle %.2e %.2e %.2e"
+          % (t, stats["compared"], T * NENV, stats["mism"], stats["mism32"], stats["q"], stats["r"], p90, stats["cq"], stats["cr"], p90c))
+    assert isinstance(totals["list"], np.ndarray) and totals["list"].shape == (NENV,)
+    assert stats["compared"] >= T * NENV * 3 // 4
+    assert stats["mism"] <= 2 * stats["mism32"] + max(8, T * NENV // 25)
+    assert stats["q"] < min(max(5e-3, 2 * stats["cq"]), 2.5e-2)
+    assert stats["r"] < min(max(5e-3, 2 * stats["cr"] + 2e-3), 2.5e-2)
+    assert p90 < min(max(5e-2, 2 * p90c), 0.25)
+
+
+@pytest.mark.gpu
+def test_gpu_single_env_reproduces_the_trainers_eval_env(vec, pkg, oracle_mod):
+    """utils.test_env's calls on the product's SnakeGymEnv (the single-env seam: terminal observation on done, the
+    caller's float32 action array clipped in place), each from the state the reference's env started the step in."""
+    v = vec
+    robot = pkg.Snake(None, "snake/snake.urdf", None)
+    env = pkg.SnakeGymEnv(robot, None)
+    env.reset()
+    seen = dict(n=0, q=0.0, r=0.0)
+
+    def on_step(i, e):
+        env._stepper.set_state(e.get_state()[None], np.concatenate([e.get_aux()[0], e.get_aux()[1:]])[None])
+        env._stepper.set_manifold(e.get_manifold()[None])
+        a = v["ppo_eval_action_in"][i, :8].astype(np.float32)
+        o, r, d, info = env.step(a)
+        assert info == {} and np.array_equal(a, np.clip(v["ppo_eval_action_in"][i, :8], -1, 1).astype(np.float32))
+        k_ref, d_ref = int(v["ppo_eval_substeps"][i]), bool(v["ppo_eval_done"][i])
+        if robot.counter != k_ref or bool(d) != d_ref:
+            assert abs(robot.counter - k_ref) <= 1, (i, robot.counter, k_ref)
+            return
+        seen["n"] += 1
+        o_ref = v["ppo_eval_env_obs"][i]
+        seen["q"] = max(seen["q"], np.abs(o[:N] - o_ref[:N]).max(), np.abs(o[3 * N:3 * N + 7] - o_ref[3 * N:3 * N + 7]).max())
+        seen["r"] = max(seen["r"], abs(float(r) - float(v["ppo_eval_env_reward"][i])))
+        if d_ref:       # the TERMINAL observation, not the reset one (SnakeGymEnv.py:39-42)
+            assert np.abs(o[:N]).max() > 0.05
+
+    _eval_free_run(v, oracle_mod, on_step=on_step)
+    env.close()
+    print("eval env on the GPU: %d of %d env-steps compared, worst q/pose %.2e reward %.2e" % (seen["n"], len(v["ppo_eval_substeps"]), seen["q"], seen["r"]))
+    assert seen["n"] >= len(v["ppo_eval_substeps"]) * 3 // 4 and seen["q"] < 1e-2 and seen["r"] < 1e-2
