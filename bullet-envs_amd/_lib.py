@@ -82,6 +82,7 @@ SYMBOLS = {
     "snk_set_ground_friction": (C.c_int, [_vp, _F]),
     "snk_get_ground_friction": (C.c_int, [_vp, _F]),
     "snk_debug_set_tickets": (C.c_int, [_vp, C.c_uint32]),
+    "snk_debug_raise_alarm": (C.c_int, [_vp]),
     "snk_selftest": (C.c_int, [C.c_int32]),
     "snk_timing_enable": (C.c_int, [_vp, C.c_int32]),
     "snk_timing_read": (C.c_int, [_vp, _D, _I32]),
@@ -311,6 +312,10 @@ class Stepper:
 
     def debug_set_tickets(self, base):
         check(self.lib.snk_debug_set_tickets(self.h, int(base) & 0xFFFFFFFF), "snk_debug_set_tickets")
+
+    def debug_raise_alarm(self):
+        """Test hook: the scheduler's alarm raised from the host (include/snk.h); the handle is poisoned afterwards."""
+        check(self.lib.snk_debug_raise_alarm(self.h), "snk_debug_raise_alarm")
 
     def model_describe(self):
         bodies = np.zeros((self.n + 1, 10))

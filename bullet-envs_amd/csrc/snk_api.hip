@@ -169,12 +169,22 @@ void release_model_slot(int i) {
     g_slot_used[i] = false;
 }
 
-// the step kernel's bounded waits (snk_device.hpp: sched_pop) raise this word when one runs out
+// the step kernel's bounded waits (snk_device.hpp: sched_pop) raise this word when one runs out.  From then on the
+// handle is poisoned: an env-step was abandoned half-way, so records, contact caches and queue no longer describe a
+// simulator state.  Every call that launches on, reads or writes that state refuses; snk_destroy, snk_last_error, the
+// dimension getters, the counters (snk_contact_overflow / _histogram) and the timing calls still work.
 int check_alarm(const snk_handle* h) {
     if (h->h_alarm && *(volatile int32_t*)h->h_alarm)
-        return fail("env-step scheduler: a bounded wait ran out (state of this handle is no longer valid)");
+        return fail("env-step scheduler: a bounded wait ran out (state of this handle is no longer valid; snk_destroy it)");
     return 0;
 }
+// the state accessors: the device idle (a step enqueued on a non-blocking stream may still be running), then the alarm
+#define SNK_SYNC_ALIVE(h)                           \
+    do {                                            \
+        HIP_TRY(hipSetDevice((h)->device));         \
+        HIP_TRY(hipDeviceSynchronize());            \
+        if (check_alarm(h)) return 1;               \
+    } while (0)
 
 int check_launch() {
     hipError_t e = hipGetLastError();
@@ -446,6 +456,7 @@ int32_t snk_record_floats(const snk_handle* h) { return h->rec; }
 
 int snk_reset(snk_handle* h, const uint8_t* mask_dev, float* obs_dev, void* stream) {
     if (!h) return fail("snk_reset: null handle");
+    if (check_alarm(h)) return 1;
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t st = (hipStream_t)stream;
     SNK_DISPATCH(h, launch_reset, h, mask_dev, obs_dev, 0, st);
@@ -551,6 +562,7 @@ int snk_step_host(snk_handle* h, float* actions, float* obs, float* rew, uint8_t
 int snk_substep_host(snk_handle* h, const float* targets, int32_t k, int32_t* info) {
     if (!h || !targets) return fail("snk_substep_host: null argument");
     if (k < 0) return fail("snk_substep_host: k < 0");
+    if (check_alarm(h)) return 1;
     HIP_TRY(hipSetDevice(h->device));
     const size_t ne = (size_t)h->n_envs;
     HIP_TRY(hipMemcpy(h->d_tgt, targets, ne * h->n * sizeof(float), hipMemcpyHostToDevice));
@@ -563,8 +575,7 @@ int snk_substep_host(snk_handle* h, const float* targets, int32_t k, int32_t* in
 
 int snk_get_state(snk_handle* h, float* state, float* aux) {
     if (!h) return fail("snk_get_state: null handle");
-    HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(hipDeviceSynchronize());      // a step enqueued on a non-blocking stream may still be running
+    SNK_SYNC_ALIVE(h);
     const size_t ne = (size_t)h->n_envs;
     std::vector<float> recs(ne * h->rec);
     HIP_TRY(hipMemcpy(recs.data(), h->d_recs, recs.size() * sizeof(float), hipMemcpyDeviceToHost));
@@ -578,8 +589,7 @@ int snk_get_state(snk_handle* h, float* state, float* aux) {
 
 int snk_set_state(snk_handle* h, const float* state, const float* aux) {
     if (!h) return fail("snk_set_state: null handle");
-    HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(hipDeviceSynchronize());      // a step enqueued on a non-blocking stream may still be running
+    SNK_SYNC_ALIVE(h);
     const size_t ne = (size_t)h->n_envs;
     std::vector<float> recs(ne * h->rec);
     HIP_TRY(hipMemcpy(recs.data(), h->d_recs, recs.size() * sizeof(float), hipMemcpyDeviceToHost));
@@ -600,8 +610,7 @@ int32_t snk_manifold_floats(const snk_handle* h) { return (h && h->d_mf) ? 2 * h
 int snk_get_manifold(snk_handle* h, float* out) {
     if (!h || !out) return fail("snk_get_manifold: null argument");
     if (!h->d_mf) return fail("snk_get_manifold: this handle has contact_model 0 (no contact cache)");
-    HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(hipDeviceSynchronize());
+    SNK_SYNC_ALIVE(h);
     const size_t ncyl = (size_t)h->n_envs * 2 * h->n;
     std::vector<float> dev(ncyl * snk::kMfFloats);
     HIP_TRY(hipMemcpy(dev.data(), h->d_mf, dev.size() * sizeof(float), hipMemcpyDeviceToHost));
@@ -624,8 +633,7 @@ int snk_get_manifold(snk_handle* h, float* out) {
 int snk_set_manifold(snk_handle* h, const float* in) {
     if (!h || !in) return fail("snk_set_manifold: null argument");
     if (!h->d_mf) return fail("snk_set_manifold: this handle has contact_model 0 (no contact cache)");
-    HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(hipDeviceSynchronize());
+    SNK_SYNC_ALIVE(h);
     const size_t ncyl = (size_t)h->n_envs * 2 * h->n;
     std::vector<float> dev(ncyl * snk::kMfFloats, 0.f);
     for (size_t c = 0; c < ncyl; c++) {
@@ -646,8 +654,7 @@ int snk_set_manifold(snk_handle* h, const float* in) {
 int snk_get_box(snk_handle* h, float* state, float* manifold) {
     if (!h) return fail("snk_get_box: null handle");
     if (!h->d_box) return fail("snk_get_box: this handle has no free box (obstacle != 2)");
-    HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(hipDeviceSynchronize());
+    SNK_SYNC_ALIVE(h);
     std::vector<float> b((size_t)h->n_envs * snk::kBoxFloats);
     HIP_TRY(hipMemcpy(b.data(), h->d_box, b.size() * sizeof(float), hipMemcpyDeviceToHost));
     for (size_t e = 0; e < (size_t)h->n_envs; e++) {
@@ -672,8 +679,7 @@ int snk_get_box(snk_handle* h, float* state, float* manifold) {
 int snk_set_box(snk_handle* h, const float* state, const float* manifold) {
     if (!h) return fail("snk_set_box: null handle");
     if (!h->d_box) return fail("snk_set_box: this handle has no free box (obstacle != 2)");
-    HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(hipDeviceSynchronize());
+    SNK_SYNC_ALIVE(h);
     std::vector<float> b((size_t)h->n_envs * snk::kBoxFloats);
     HIP_TRY(hipMemcpy(b.data(), h->d_box, b.size() * sizeof(float), hipMemcpyDeviceToHost));
     for (size_t e = 0; e < (size_t)h->n_envs; e++) {
@@ -729,8 +735,7 @@ int snk_contact_histogram(snk_handle* h, uint64_t* out, int32_t reset) {
 
 int snk_get_obs(snk_handle* h, float* obs) {
     if (!h || !obs) return fail("snk_get_obs: null argument");
-    HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(hipDeviceSynchronize());      // a step enqueued on a non-blocking stream may still be running
+    SNK_SYNC_ALIVE(h);
     SNK_DISPATCH(h, launch_obs, h, h->d_obs, nullptr, nullptr, nullptr);
     if (check_launch()) return 1;
     HIP_TRY(hipDeviceSynchronize());
@@ -740,8 +745,7 @@ int snk_get_obs(snk_handle* h, float* obs) {
 
 int snk_mean_height(snk_handle* h, float* out) {
     if (!h || !out) return fail("snk_mean_height: null argument");
-    HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(hipDeviceSynchronize());      // a step enqueued on a non-blocking stream may still be running
+    SNK_SYNC_ALIVE(h);
     SNK_DISPATCH(h, launch_obs, h, nullptr, h->d_h, nullptr, nullptr);
     if (check_launch()) return 1;
     HIP_TRY(hipDeviceSynchronize());
@@ -751,8 +755,7 @@ int snk_mean_height(snk_handle* h, float* out) {
 
 int snk_link_positions(snk_handle* h, float* out) {
     if (!h || !out) return fail("snk_link_positions: null argument");
-    HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(hipDeviceSynchronize());      // a step enqueued on a non-blocking stream may still be running
+    SNK_SYNC_ALIVE(h);
     const size_t bytes = (size_t)h->n_envs * 3 * (h->n + 1) * sizeof(float);
     if (!h->d_linkpos) HIP_TRY(hipMalloc(&h->d_linkpos, bytes));
     SNK_DISPATCH(h, launch_obs, h, nullptr, nullptr, nullptr, h->d_linkpos);
@@ -764,16 +767,14 @@ int snk_link_positions(snk_handle* h, float* out) {
 
 int snk_set_ground_friction(snk_handle* h, const float* mu) {
     if (!h || !mu) return fail("snk_set_ground_friction: null argument");
-    HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(hipDeviceSynchronize());      // a step enqueued on a non-blocking stream may still be running
+    SNK_SYNC_ALIVE(h);
     HIP_TRY(hipMemcpy(h->d_mu, mu, (size_t)h->n_envs * sizeof(float), hipMemcpyHostToDevice));
     return 0;
 }
 
 int snk_joint3_reaction_fz(snk_handle* h, float* out) {
     if (!h || !out) return fail("snk_joint3_reaction_fz: null argument");
-    HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(hipDeviceSynchronize());
+    SNK_SYNC_ALIVE(h);
     const size_t ne = (size_t)h->n_envs;
     std::vector<float> recs(ne * h->rec);
     HIP_TRY(hipMemcpy(recs.data(), h->d_recs, recs.size() * sizeof(float), hipMemcpyDeviceToHost));
@@ -791,10 +792,18 @@ int snk_get_ground_friction(snk_handle* h, float* mu) {
 
 int snk_debug_set_tickets(snk_handle* h, uint32_t base) {
     if (!h) return fail("snk_debug_set_tickets: null handle");
-    HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(hipDeviceSynchronize());
+    SNK_SYNC_ALIVE(h);
     HIP_TRY(hipMemcpy(h->sched.head, &base, sizeof(base), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->sched.tail, &base, sizeof(base), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int snk_debug_raise_alarm(snk_handle* h) {
+    if (!h) return fail("snk_debug_raise_alarm: null handle");
+    if (!h->h_alarm) return fail("snk_debug_raise_alarm: this handle has no alarm word");
+    // the word is host-mapped memory: the host stores what a wave whose bounded wait ran out would (sched_alarm);
+    // a step still running sees it at its next bounded wait and drains
+    __atomic_store_n(h->h_alarm, 1, __ATOMIC_SEQ_CST);
     return 0;
 }
 

@@ -401,6 +401,18 @@ __device__ __forceinline__ bool sensor_pass_needed(LT& L, const DevModel& M, int
 // holds no line from before them (buffer_inv sc1).  The XCD's L2 is the point of coherence for writer and reader alike --
 // the same wave -- so nothing has to be written back: __threadfence() here (rounds 1-4) also ran buffer_wbl2, a
 // write-back of every dirty line of the XCD's L2, two to three times per streamed-row substep.
+//
+// THE INVARIANT THIS RELIES ON (load-bearing since round 4; DESIGN.md 4 has the full producer -> consumer table): nothing
+// a wave stores with PLAIN stores is ever read by ANOTHER wave inside the same launch.  Every byte that crosses waves
+// in a launch -- the state record, the contact cache block, the free box's record, the substep counter at a hand-off;
+// the queue entry, tickets, counters -- is stored write-through (sc1 / dwordx4 sc1) or by an agent-scope atomic, and
+// ordered by s_waitcnt vmcnt(0) in front of the queue entry (sched_push).  The L2 write-back that __threadfence() did
+// here as a side effect is therefore not needed by any reader; a new cross-wave datum must come with its own
+// write-through stores, not lean on this function.
+// gfx942 / gfx950 ISA only: `vmcnt` counts stores there, and `buffer_inv sc1` is this family's L1 invalidate.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx942__) && !defined(__gfx950__)
+#error "own_stores_visible(): written for gfx942 / gfx950 (vmcnt covers stores, buffer_inv sc1); other targets need __threadfence()"
+#endif
 __device__ __forceinline__ void own_stores_visible() {
     asm volatile("s_waitcnt vmcnt(0)\n\tbuffer_inv sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
 }
@@ -1330,6 +1342,14 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
     // ... and so do the normal rows of the first kResN contacts: the registers the rings leave free hold an eighth of
     // the stream (the kernel is bound by that stream)
     constexpr int kResN = INPLACE ? SNK_IP_RESN : LT::kResN;
+    // What the build-time knobs (SNK_V1_* / SNK_IP_*) must satisfy for the loops below to stay inside the records: rows
+    // come in pairs (ldN2), the early exits and the ring's refill address are evaluated at every eighth row only, the
+    // first ring trip starts behind the resident rows.  A sweep value such as 36 or 44 would compile and read beyond
+    // nc_pad.
+    static_assert(kResN % 8 == 0 && kResN > 0, "resident normal rows: a multiple of 8 (groups of 8 behind one scalar branch)");
+    static_assert(kRN % 8 == 0 && kRN > 0, "normal rows in flight: a multiple of 8 (refill address taken at k % 8 == 0)");
+    static_assert(kResN + kRN <= LT::NCT, "resident + in-flight normal rows exceed the contact slots of this layout");
+    static_assert((INPLACE ? SNK_IP_RINGF : LT::kRingF) % 8 == 0, "friction pairs in flight: a multiple of 8");
     float RNJ[kResN], RNM[kResN];
 #pragma unroll
     for (int k = 0; k < kResN; k += 2) ldN2((unsigned)k * kRecB, RNJ[k], RNM[k], RNJ[k + 1], RNM[k + 1]);

@@ -1317,6 +1317,98 @@ __device__ __forceinline__ void contact_rows(float (&RJ)[kSlots], float (&RM)[kS
     }
 }
 
+// (6) constraint pass for the joint-0 sensor [U], as a FUNCTION OF ITS OWN (never inlined).  The pass is full of
+// lane-dependent regions (lane < nc, lane <= N, lane == 0); inlined into the substep, every value the substep keeps in a
+// vector register across it -- delta-v above all -- is exposed to the register allocator placing a copy or a reload of
+// it INSIDE one of those regions, which then moves the active lanes only.  Round 4 met a build with that signature
+// (substep_kernel<16, true>: joints 10..15 stood still under the single-substep API) and parked delta-v in LDS; ADVICE r4's
+// point was that this protects one variable.  Behind a call boundary the whole class is closed: whatever the caller has
+// live is preserved either by the callee's prologue / epilogue or by the caller around the call -- in both cases under
+// the call site's exec mask (every lane), never inside the pass.  The pass takes wave-uniform scalars only, re-derives
+// its lane index, and leaves its two results in the record (lane 0): no all-lane value crosses it in either direction.
+// (The one build of that time that can be rebuilt from history -- commit 89723cb without the LDS detour -- was
+// disassembled in round 5: delta-v crosses the pass untouched in v203, and that library passes
+// test_substep_api_servo_converges on the GPU; the failing object was an uncommitted intermediate.  The cause above is
+// therefore the best-supported reading, not a proven one: DESIGN.md 4.)
+template <class LT>
+__device__ __noinline__ void sensor_pass_v2(LT& L, const DevModel& M, const int nc, const int nlim
+#ifdef SNK_PROFILE
+                                            , unsigned long long* prof_t
+#endif
+) {
+    constexpr int N = LT::kN;
+    const int lane = lane_id();
+    // lane = contact: its force and its moment about the body's joint origin (staging rows are
+    // free now); then lane = body sums the contacts of its cylinders (2b-1 and 2b; body 0: cylinder 0) in
+    // contact order
+    if (lane < nc) {
+        const int ci = lane, k = L.ccbody[ci];
+        const f3 nrm = ci < L.nplane ? mk3(0.f, 0.f, 1.f) : ld3(L.obn[ci - L.nplane]);
+        f3 F = (nrm * L.app[kAppNormal + ci] +
+                ld3(L.cdir[L.ccds[ci]][0]) * L.app[kAppFric + 2 * ci] +
+                ld3(L.cdir[L.ccds[ci]][1]) * L.app[kAppFric + 2 * ci + 1]) * M.inv_dt;
+        st3(&L.stM[ci][0], cross(ld3(L.ccP[ci]) - ld3(L.o[k]), F));
+        st3(&L.stM[ci][3], F);
+    }
+    lds_sync();
+    if (lane <= N) {
+        const int b = lane;
+        f3 eN = mk3(0, 0, 0), eF = mk3(0, 0, 0);
+        const int c0 = b == 0 ? 0 : 2 * b - 1;
+        const int ncyl = (b == 0 || b == N) ? 1 : 2;
+        for (int cc = c0; cc < c0 + ncyl; cc++) {
+            const int cb = L.cylbase[cc], cn = L.cyln[cc];
+            for (int ci = cb; ci < cb + cn; ci++) {
+                eN = eN + ld3(&L.stM[ci][0]);
+                eF = eF + ld3(&L.stM[ci][3]);
+            }
+        }
+        for (int ci = L.nplane; ci < nc; ci++)               // the obstacle's contacts, behind the ground's
+            if (L.ccbody[ci] == b) {
+                eN = eN + ld3(&L.stM[ci][0]);
+                eF = eF + ld3(&L.stM[ci][3]);
+            }
+        st3(L.ext(b), eN);
+        st3(L.ext(b) + 3, eF);
+    }
+    if (lane < N) L.tauj[lane] = -M.joint_damp * L.qd_old[lane] + L.app[lane] * M.inv_dt;
+    lds_sync();
+    if (lane == 0) {
+        for (int i = 0; i < nlim; i++) L.tauj[L.nc_joint[i]] += L.nc_sign[i] * L.nc_app[i] * M.inv_dt;
+    }
+    lds_sync();
+    {
+        f3 wp = ld3(L.base() + 7), vp = ld3(L.base() + 10);
+        if (lane == 0) { st3(L.w[0], wp); st3(L.v[0], vp); }
+        for (int b = 1; b <= N; b++) {
+            f3 ax = ld3(L.ax[b]), rb = ld3(L.r[b]);
+            float qdb = L.qd()[b - 1];
+            f3 w = wp + ax * qdb, v = vp + cross(wp, rb);
+            f3 za = cross(wp, ax) * qdb, zl = cross(wp, cross(wp, rb));
+            if (lane == 0) { st3(L.w[b], w); st3(L.v[b], v); st3(&L.zeta[b][0], za); st3(&L.zeta[b][3], zl); }
+            wp = w; vp = v;
+        }
+    }
+    lds_sync();
+    SNK_STAMP(14)
+    body_bias<LT, false>(L, M, lane);
+    lds_sync();
+    aba_main<LT, false>(L, M, lane);
+    {
+        f3 zb = mulRv(L.R[0], ld3(M.zbase));
+        f3 v1 = ld3(L.base() + 10);
+        float nv1 = sqrtf(dot(v1, v1));
+        f3 a2 = ld3(&L.acc0[3]);
+        const float fz = L.fz_park - dot(zb, a2 * M.m_root + v1 * (M.m_root * (M.lin_damp + M.lin_damp * nv1)));
+        const f3 al2 = ld3(&L.acc0[0]);
+        const f3 F3 = -((a2 + cross(al2, ld3(L.cw[0]))) * M.mass[0] + ld3(&L.p[0][3]));
+        const float fz3 = L.fz3_park + F3.x * L.R[1][2] + F3.y * L.R[1][5] + F3.z * L.R[1][8];
+        // both results straight into the record (the caller's lds_sync in front of the integration follows)
+        if (lane == 0) { L.fz() = fz; L.fz3() = fz3; }
+    }
+    SNK_STAMP(15)
+}
+
 template <class LT>
 __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane_in, float mu, int& iters, int& ncontacts,
                                            const SensorHint& hint, unsigned long long* __restrict__ ovf) {
@@ -1649,82 +1741,17 @@ __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane_in
     // tolerance); for the third, no sampled point can move further in one substep than
     // dt * (|v| + L_chain * (|omega| + sum |qd|)): rigid rotations about the base and the joints.
     const bool sensor = sensor_pass_needed(L, M, lane, dv, hint);
-    // delta-v crosses the sensor pass in LDS (a free column of the staging rows), not in a register: the pass is full of
-    // lane-dependent regions (lane < nc, lane <= N, lane == 0), and a register copy or a scratch reload the allocator places
-    // INSIDE such a region only moves the lanes that are active there.  Round 4 met exactly that: with one more scalar
-    // live across the substep, substep_kernel<16, true> came out with delta-v's lanes 16..21 (joints 10..15) lost on the
-    // way -- those joints simply stopped moving under the single-substep API, while the fused kernels were fine
-    // (tests/test_gpu_parity.py::test_substep_api_servo_converges keeps watch).
+    // delta-v crosses the sensor pass in LDS (a free column of the staging rows), not in a register -- round 4's first
+    // answer to a build that lost its lanes 16..21 on the way; round 5 put the pass itself behind a call boundary
+    // (sensor_pass_v2 above), which protects every such value.  The detour stays: it costs one LDS write and read per
+    // substep and takes a register out of the callee-saved set around the call.
     L.stM[lane][20] = dv;
-    float fz = L.fz(), fz3 = L.fz3();
     if (sensor) {
-        // lane = contact: its force and its moment about the body's joint origin (staging rows are
-        // free now); then lane = body sums the contacts of its cylinders (2b-1 and 2b; body 0: cylinder 0) in
-        // contact order
-        if (lane < nc) {
-            const int ci = lane, k = L.ccbody[ci];
-            const f3 nrm = ci < L.nplane ? mk3(0.f, 0.f, 1.f) : ld3(L.obn[ci - L.nplane]);
-            f3 F = (nrm * L.app[kAppNormal + ci] +
-                    ld3(L.cdir[L.ccds[ci]][0]) * L.app[kAppFric + 2 * ci] +
-                    ld3(L.cdir[L.ccds[ci]][1]) * L.app[kAppFric + 2 * ci + 1]) * M.inv_dt;
-            st3(&L.stM[ci][0], cross(ld3(L.ccP[ci]) - ld3(L.o[k]), F));
-            st3(&L.stM[ci][3], F);
-        }
-        lds_sync();
-        if (lane <= N) {
-            const int b = lane;
-            f3 eN = mk3(0, 0, 0), eF = mk3(0, 0, 0);
-            const int c0 = b == 0 ? 0 : 2 * b - 1;
-            const int ncyl = (b == 0 || b == N) ? 1 : 2;
-            for (int cc = c0; cc < c0 + ncyl; cc++) {
-                const int cb = L.cylbase[cc], cn = L.cyln[cc];
-                for (int ci = cb; ci < cb + cn; ci++) {
-                    eN = eN + ld3(&L.stM[ci][0]);
-                    eF = eF + ld3(&L.stM[ci][3]);
-                }
-            }
-            for (int ci = L.nplane; ci < nc; ci++)               // the obstacle's contacts, behind the ground's
-                if (L.ccbody[ci] == b) {
-                    eN = eN + ld3(&L.stM[ci][0]);
-                    eF = eF + ld3(&L.stM[ci][3]);
-                }
-            st3(L.ext(b), eN);
-            st3(L.ext(b) + 3, eF);
-        }
-        if (lane < N) L.tauj[lane] = -M.joint_damp * L.qd_old[lane] + L.app[lane] * M.inv_dt;
-        lds_sync();
-        if (lane == 0) {
-            for (int i = 0; i < nlim; i++) L.tauj[L.nc_joint[i]] += L.nc_sign[i] * L.nc_app[i] * M.inv_dt;
-        }
-        lds_sync();
-        {
-            f3 wp = ld3(L.base() + 7), vp = ld3(L.base() + 10);
-            if (lane == 0) { st3(L.w[0], wp); st3(L.v[0], vp); }
-            for (int b = 1; b <= N; b++) {
-                f3 ax = ld3(L.ax[b]), rb = ld3(L.r[b]);
-                float qdb = L.qd()[b - 1];
-                f3 w = wp + ax * qdb, v = vp + cross(wp, rb);
-                f3 za = cross(wp, ax) * qdb, zl = cross(wp, cross(wp, rb));
-                if (lane == 0) { st3(L.w[b], w); st3(L.v[b], v); st3(&L.zeta[b][0], za); st3(&L.zeta[b][3], zl); }
-                wp = w; vp = v;
-            }
-        }
-        lds_sync();
-        SNK_STAMP(14)
-        body_bias<LT, false>(L, M, lane);
-        lds_sync();
-        aba_main<LT, false>(L, M, lane);
-        {
-            f3 zb = mulRv(L.R[0], ld3(M.zbase));
-            f3 v1 = ld3(L.base() + 10);
-            float nv1 = sqrtf(dot(v1, v1));
-            f3 a2 = ld3(&L.acc0[3]);
-            fz = L.fz_park - dot(zb, a2 * M.m_root + v1 * (M.m_root * (M.lin_damp + M.lin_damp * nv1)));
-            const f3 al2 = ld3(&L.acc0[0]);
-            const f3 F3 = -((a2 + cross(al2, ld3(L.cw[0]))) * M.mass[0] + ld3(&L.p[0][3]));
-            fz3 = L.fz3_park + F3.x * L.R[1][2] + F3.y * L.R[1][5] + F3.z * L.R[1][8];
-        }
-        SNK_STAMP(15)
+#ifdef SNK_PROFILE
+        sensor_pass_v2(L, M, nc, nlim, prof_t);
+#else
+        sensor_pass_v2(L, M, nc, nlim);
+#endif
     }
     // (7) apply the solver's delta-v (lower half's copy), motor torques, integrate positions
     lds_sync();
@@ -1760,8 +1787,6 @@ __device__ __forceinline__ void substep_v2(LT& L, const DevModel& M, int lane_in
         if (lane == 0) {
             bs[0] += dt * vl.x; bs[1] += dt * vl.y; bs[2] += dt * vl.z;
             bs[3] = nx * inv; bs[4] = ny * inv; bs[5] = nz * inv; bs[6] = nw * inv;
-            L.fz() = fz;
-            L.fz3() = fz3;
         }
     }
     lds_sync();

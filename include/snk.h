@@ -236,6 +236,15 @@ int snk_get_ground_friction(snk_handle* h, float* mu /* host [n_envs] */);
  * can put the wrap-around of the 32-bit tickets inside its next step.  Results never depend on it. */
 int snk_debug_set_tickets(snk_handle* h, uint32_t base);
 
+/* Test hook for the failure path: raises this handle's alarm from the HOST -- the host-mapped word a wave of the step
+ * kernel sets when one of its bounded waits runs out (nothing waits, nothing hangs).  Afterwards the handle behaves as
+ * after a real alarm: snk_step / snk_step_packed / snk_step_host / snk_reset(_host) / snk_substep_host and the state
+ * accessors (get/set state, manifold, box, obs, mean height, link positions, joint-3 force, set_ground_friction) return
+ * non-zero with snk_last_error() = "env-step scheduler: a bounded wait ran out ..."; snk_destroy succeeds.  The
+ * reference's failure story is SubprocVecEnv.close() draining and joining its workers
+ * (ppo/multiprocessing_env.py:140-150): here too the only way on is to destroy the handle and create a new one. */
+int snk_debug_raise_alarm(snk_handle* h);
+
 /* Device-side self test of the wave primitives (DPP reductions); 0 = pass. */
 int snk_selftest(int32_t device);
 

@@ -32,6 +32,7 @@ class OrcParams(C.Structure):
         ("breaking_threshold", C.c_double), ("relative_breaking_threshold", C.c_int32), ("cone_friction", C.c_int32),
         ("n_iterations", C.c_int32), ("residual_threshold", C.c_double),
         ("warm_start", C.c_int32), ("warmstarting_factor", C.c_double),
+        ("friction_directions", C.c_int32), ("contact_erp_rule", C.c_int32),
         ("scaling_factor", C.c_double), ("gait", C.c_int32),
         ("servo_tol", C.c_double), ("max_counter", C.c_int32),
         ("height_threshold", C.c_double), ("energy_dt", C.c_double),

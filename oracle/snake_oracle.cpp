@@ -1592,7 +1592,12 @@ void substep(orc_env* e, const Real* targets) {
         Real pen = c.dist + (Real)P.linear_slop;
         Real velerr = -rel_vel, poserr = 0;   /* restitution 0 */
         if (pen > 0) velerr -= pen / dt;
-        else poserr = -pen * (Real)P.contact_erp / dt;
+        else {
+            /* contact_erp_rule 1 [U]: erp = m_erp2; if (!m_splitImpulse || penetration > m_splitImpulsePenetrationThreshold)
+             * erp = m_erp -- split impulse on, threshold -0.04: every contact shallower than 4 cm takes m_erp */
+            const Real erp = (P.contact_erp_rule && pen > Real(-0.04)) ? (Real)P.limit_erp : (Real)P.contact_erp;
+            poserr = -pen * erp / dt;
+        }
         finish_row(row, velerr + poserr);
         row.lo = 0; row.hi = Real(1e10);
         /* warm starting (SOLVER_USE_WARMSTARTING as btSequentialImpulseConstraintSolver does it; disabled in Bullet's
@@ -1639,6 +1644,11 @@ void substep(orc_env* e, const Real* targets) {
             for (int i = 0; i < nd; i++) rv += fr.J[i] * g[i];
             finish_row(fr, -rv);
             fr.lo = 0; fr.hi = 0;   /* set from the normal impulse every iteration */
+            if (P.friction_directions == 1 && f == 1) {
+                /* no SOLVER_USE_2_FRICTION_DIRECTIONS [U]: the second tangent gets no row (kept as an inert entry
+                 * so that the pair indexing below stays) */
+                fr.J.assign(nd, 0); fr.M.assign(nd, 0); fr.dinv = 0; fr.rhs = 0;
+            }
             frictions.push_back(fr);
         }
     }
@@ -1666,7 +1676,14 @@ void substep(orc_env* e, const Real* targets) {
             Real lim = e->contacts[ci].mu * normals[ci].applied;
             Row& A = frictions[2 * ci];
             Row& B = frictions[2 * ci + 1];
-            if (P.cone_friction) {
+            if (P.friction_directions == 1) {
+                /* one friction row per contact, box bounds (the cone branch needs the second direction) */
+                if (lim > 0) {
+                    A.lo = -lim; A.hi = lim;
+                    Real r = resolve_row(A, dv, nd);
+                    if (r * r > lsq) lsq = r * r;
+                }
+            } else if (P.cone_friction) {
                 /* resolveConeFrictionConstraintRows [U]: both rows from the same velocity,
                  * accumulated pair projected radially onto the disc of radius mu*lambda_n */
                 Real ua = 0, ub = 0;
@@ -1876,6 +1893,8 @@ void orc_default_params(orc_params* p) {
     p->residual_threshold = 1e-7;
     p->warm_start = 0;
     p->warmstarting_factor = 0.85;
+    p->friction_directions = 2;
+    p->contact_erp_rule = 0;
     p->scaling_factor = kPi / 6.0;
     p->gait = 1;
     p->servo_tol = 0.05;

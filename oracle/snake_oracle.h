@@ -102,7 +102,20 @@ typedef struct orc_params {
                                * as the rigid-body solver does it -- a cached point's normal row starts at
                                * warmstarting_factor x the impulse it carried last step, delta-v starts at
                                * sum M^-1 J^T of those; friction rows start at zero.  contact_model 1 only             */
-    double  warmstarting_factor; /* btContactSolverInfo m_warmstartingFactor 0.85 [U]     */
+    double  warmstarting_factor; /* btContactSolverInfo m_warmstartingFactor 0.85 [U] (the struct's default; PyBullet's
+                               * world constructor is read as setting 0.1 [U]: an error-bar row, profiles/r05_u_rows.json) */
+    int32_t friction_directions; /* 2 (default): SOLVER_USE_2_FRICTION_DIRECTIONS [U] -- both btPlaneSpace1 tangents get a
+                               * row (and, with cone_friction, the implicit cone over the pair).  1: Bullet's multibody
+                               * solver WITHOUT that flag [U]: one row per contact along the first btPlaneSpace1 tangent
+                               * ((0,-1,0) for the ground), box bounds +-mu lambda_n, no cone branch.  Oracle only
+                               * (VERDICT r4 item 6): on flat ground that leaves world x without any friction -- a body
+                               * pushed along x would never stop -- which PyBullet visibly does not do             */
+    int32_t contact_erp_rule; /* 0 (default): contact rows use contact_erp (m_erp2 0.08) whatever the depth.  1: the
+                               * choice as setupMultiBodyContactConstraint is read to make it [U]: m_erp (= limit_erp,
+                               * 0.2) unless split impulse is on AND the penetration is deeper than
+                               * m_splitImpulsePenetrationThreshold (-0.04 m), only then m_erp2.  (Joint-limit rows:
+                               * fillMultiBodyConstraint has the same test commented out and always takes m_erp: that is
+                               * limit_erp already.)  Oracle only, an error-bar row                                   */
     /* task (snake.py / SnakeGymEnv.py) */
     double  scaling_factor;   /* snake.py:63  pi/6                                       */
     int32_t gait;             /* snake.py:62  1 -> odd slots                             */

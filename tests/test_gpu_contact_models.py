@@ -34,6 +34,7 @@ SWITCHES = {
     "hull+manifold@0.02": dict(hull_sides=32, contact_model=1, relative_breaking_threshold=0),
     "default": dict(),                                                   # hull + manifold, relative threshold (1.2 mm)
     "default+warm": dict(warm_start=1),
+    "default+pyramid": dict(cone_friction=0),                            # two friction rows, box bounds, no implicit cone
 }
 
 

@@ -943,3 +943,60 @@ def test_slot_permutation_invariance(pkg, n, B, over):
         assert np.array_equal(o, O[perm]) and np.array_equal(r, R[perm])
     assert np.array_equal(Sg, Sr[perm])
     st.close()
+
+
+def test_alarm_poisons_the_handle(pkg):
+    """The scheduler's failure path: every wait inside the step kernel is bounded, and a wave whose
+    wait runs out sets a host-mapped word.  Here the HOST sets that word (snk_debug_raise_alarm: nothing waits, nothing
+    hangs).  From then on the handle refuses: the step calls (device-pointer, packed and host-buffer forms), reset,
+    substep and the state accessors all fail with the scheduler's message in snk_last_error; the counters and
+    snk_destroy still work; a fresh handle is unaffected.  The reference's whole failure story is close() draining and
+    joining the workers (ppo/multiprocessing_env.py:140-150): destroy and create again is this build's."""
+    import torch
+    B = 64
+    st = pkg.Stepper(B)
+    st.reset()
+    a = gait(range(B), 0)
+    obs, rew, done, sub = st.step(a.copy())
+    assert np.isfinite(obs).all()
+    S0, X0 = st.get_state()
+    st.debug_raise_alarm()
+    msg = "env-step scheduler: a bounded wait ran out"
+    calls = {
+        "snk_step_host": lambda: st.step(a.copy()),
+        "snk_reset_host": lambda: st.reset(),
+        "snk_substep_host": lambda: st.substep(np.zeros((B, 16), dtype=np.float32), 1),
+        "snk_get_state": lambda: st.get_state(),
+        "snk_set_state": lambda: st.set_state(S0, X0),
+        "snk_get_manifold": lambda: st.get_manifold(),
+        "snk_get_obs": lambda: st.get_obs(),
+        "snk_mean_height": lambda: st.mean_height(),
+    }
+    for name, fn in calls.items():
+        with pytest.raises(RuntimeError) as ei:
+            fn()
+        assert msg in str(ei.value), (name, str(ei.value))
+    # the device-pointer forms refuse BEFORE launching anything
+    t_a = torch.tensor(a).cuda()
+    t_o = torch.zeros((B, 56), device="cuda")
+    t_r = torch.zeros((B,), device="cuda")
+    t_d = torch.zeros((B,), dtype=torch.uint8, device="cuda")
+    with pytest.raises(RuntimeError) as ei:
+        st.step_device(t_a.data_ptr(), t_o.data_ptr(), t_r.data_ptr(), t_d.data_ptr())
+    assert msg in str(ei.value)
+    t_p = torch.zeros((B, 58), device="cuda")
+    with pytest.raises(RuntimeError) as ei:
+        st.step_packed_device(t_a.data_ptr(), t_p.data_ptr(), 58)
+    assert msg in str(ei.value)
+    torch.cuda.synchronize()
+    assert float(t_o.abs().sum()) == 0.0 and float(t_p.abs().sum()) == 0.0          # nothing ran
+    assert msg in pkg.load().snk_last_error().decode()
+    # what still works: the counters, the dimensions, and destroying the handle
+    assert len(st.contact_overflow()) == 3 and st.obs_dim == 56
+    st.close()
+    # a new handle is healthy, and the poisoned one's alarm did not leak into it
+    st2 = pkg.Stepper(B)
+    st2.reset()
+    obs2, _, _, _ = st2.step(a.copy())
+    assert np.array_equal(obs2, obs)
+    st2.close()

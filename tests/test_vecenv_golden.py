@@ -143,6 +143,29 @@ def test_oracle_reproduces_the_trainers_eval_env(vec, oracle_mod):
 
 
 # ------------------------------------------------------------------------------------------------------------------
+def _count_spread(oracle_mod, S, X, M, a, vec_mode, seed):
+    """Substep counts the FLOAT64 oracle gives for one env-step when its inputs are moved by float32-sized amounts: the
+    state / contact cache / action rounded to float32 (what the GPU is handed), and four random relative perturbations
+    of 6e-8.  More than one value = the step sits at a bifurcation (a contact about to stick or slip decides how fast the
+    servo error decays): no float32 computation can be expected to land on the reference's count there.  Observed, e.g.,
+    ARS step 26 env 4: 18 from the exact state, 20 from the rounded one, 21 from perturbed ones."""
+    rng = np.random.default_rng(seed)
+    ks = []
+    e = oracle_mod.OracleEnv()
+    for trial in range(5):
+        if trial == 0:
+            S2, M2, a2 = (x.astype(np.float32).astype(np.float64) for x in (S, M, a))
+        else:
+            S2 = S * (1 + rng.uniform(-1, 1, S.shape) * 6e-8)
+            M2 = M * (1 + rng.uniform(-1, 1, M.shape) * 6e-8)
+            M2[:, 0] = M[:, 0]
+            a2 = a * (1 + rng.uniform(-1, 1, a.shape) * 6e-8)
+        e.hard_reset()
+        e.sync(S2, X, M2)
+        ks.append(e.env_step(a2.copy(), vec_mode=vec_mode)[3])
+    return ks
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("t", ["ars_", "ppo_"])
 def test_gpu_subprocvecenv_reproduces_the_reference_seam(vec, pkg, oracle_mod, t):
@@ -156,7 +179,7 @@ def test_gpu_subprocvecenv_reproduces_the_reference_seam(vec, pkg, oracle_mod, t
     envs = pkg.SubprocVecEnv([make_env() for _ in range(NENV)])
     assert envs.num_envs == NENV and envs.observation_space.shape == (O,) and envs.action_space.shape == (8,)
     e32 = oracle_mod.OracleEnv(f32=True)
-    stats = dict(mism=0, mism32=0, compared=0, q=0.0, r=0.0, qd=[], cq=0.0, cr=0.0, cqd=[], resets=0)
+    stats = dict(last_obs=None, mism=0, mism32=0, undecidable=0, compared=0, q=0.0, r=0.0, qd=[], cq=0.0, cr=0.0, cqd=[], resets=0)
     totals = {"list": [0.0] * NENV, "sum": 0.0}
     done_index = np.cumsum(v[t + "dones"].reshape(-1)) - 1          # row of terminal_obs for a done at (step, env)
 
@@ -164,7 +187,19 @@ def test_gpu_subprocvecenv_reproduces_the_reference_seam(vec, pkg, oracle_mod, t
         if j in [int(s) for s in v[t + "reset_before_step"]]:
             got = envs.reset()
             assert isinstance(got, np.ndarray) and got.shape == (NENV, O)
-            assert np.array_equal(got, v[t + "resets"][stats["resets"]].astype(np.float32))
+            # the reset observation: zeros, the unit quaternion, the motor torques' and the joint-0 force sensor's STALE
+            # caches (a soft reset does not touch them: obs[32:48], obs[55]).  Everything but the caches bit for bit;
+            # the caches are the GPU's own last values (float32 round-off moves the force sensor of a resting snake by
+            # 10 % and more: the split of the weight over ~40 contacts is not unique) -- what is pinned is that the
+            # reset hands them on unchanged
+            want = v[t + "resets"][stats["resets"]].astype(np.float32)
+            keep = np.r_[0:2 * N, 3 * N:3 * N + 7]
+            assert np.array_equal(got[:, keep], want[:, keep])
+            if stats["last_obs"] is not None:
+                assert np.array_equal(got[:, 2 * N:3 * N], stats["last_obs"][:, 2 * N:3 * N]) and np.array_equal(got[:, 55], stats["last_obs"][:, 55])
+                assert np.abs(got[:, 55] - want[:, 55]).max() < 0.5 * max(1.0, np.abs(want[:, 55]).max())
+            else:
+                assert np.array_equal(got, want)
             stats["resets"] += 1
         # the product's envs start the step where the reference's workers did (the oracle envs hold those states)
         S = np.stack([e.get_state() for e in oracles])
@@ -175,6 +210,7 @@ def test_gpu_subprocvecenv_reproduces_the_reference_seam(vec, pkg, oracle_mod, t
         a = v[t + "actions"][j]                              # as the trainer passes it: (16, 8, 1) f64 / (16, 8) f32
         a_before = a.copy()
         obs, rews, dones, infos = envs.step(a)
+        stats["last_obs"] = obs.copy()
         assert np.array_equal(a, a_before)                  # the reference pickles the actions to its workers
         assert isinstance(obs, np.ndarray) and obs.shape == (NENV, O) and rews.shape == (NENV,) and dones.shape == (NENV,)
         assert dones.dtype == np.bool_ and isinstance(infos, tuple) and len(infos) == NENV and infos[3] == {}
@@ -193,8 +229,15 @@ def test_gpu_subprocvecenv_reproduces_the_reference_seam(vec, pkg, oracle_mod, t
                 # error where the two part ways is within float32 round-off of the 0.05 tolerance, or |q9| of 0.5
                 stats["mism"] += 1
                 kg = int(sub[i])
-                assert abs(kg - k_ref) <= 1, (t, j, i, kg, k_ref)
-                if kg != k_ref:
+                ks = _count_spread(oracle_mod, S[i], X[i], M[i], a.reshape(NENV, -1)[i].astype(np.float64), True, 1000 * j + i)
+                if len(set(ks + [k_ref])) > 1:
+                    # a bifurcation: the float64 oracle's own count moves under float32-sized changes of the inputs
+                    stats["undecidable"] += 1
+                    print("  %s step %d env %d: GPU %d, reference %d, float64 oracle under float32-sized perturbations %s"
+                          % (t, j, i, kg, k_ref, ks))
+                    assert min(ks + [k_ref]) - 1 <= kg <= max(ks + [k_ref]) + 1, (t, j, i, kg, k_ref, ks)
+                elif kg != k_ref:
+                    assert abs(kg - k_ref) <= 1, (t, j, i, kg, k_ref)
                     e_dec = float(v[t + "servo_err"][j, i, min(kg, k_ref) - 1])      # the error where the two part ways
                     assert abs(e_dec - 0.05) < 1.5e-3 + 2e-4 * k_ref, (t, j, i, kg, k_ref, e_dec)
                 else:
@@ -222,9 +265,10 @@ def test_gpu_subprocvecenv_reproduces_the_reference_seam(vec, pkg, oracle_mod, t
     envs.close()
     T = len(v[t + "obs"])
     p90, p90c = float(np.percentile(stats["qd"], 90)), float(np.percentile(stats["cqd"], 90))
-    print("%s GPU SubprocVecEnv vs the reference's (%d of %d env-steps compared, %d boundary mismatches; float32 oracle %d): "
-          "worst q/pose %.2e reward %.2e qd p90 %.2e | float32 oracle %.2e %.2e %.2e"
-          % (t, stats["compared"], T * NENV, stats["mism"], stats["mism32"], stats["q"], stats["r"], p90, stats["cq"], stats["cr"], p90c))
+    print("%s GPU SubprocVecEnv vs the reference's (%d of %d env-steps compared, %d count / done mismatches of which %d at a "
+          "bifurcation; float32 oracle %d): worst q/pose %.2e reward %.2e qd p90 %.2e | float32 oracle %.2e %.2e %.2e"
+          % (t, stats["compared"], T * NENV, stats["mism"], stats["undecidable"], stats["mism32"], stats["q"], stats["r"], p90,
+             stats["cq"], stats["cr"], p90c))
     assert isinstance(totals["list"], np.ndarray) and totals["list"].shape == (NENV,)
     assert stats["compared"] >= T * NENV * 3 // 4
     assert stats["mism"] <= 2 * stats["mism32"] + max(8, T * NENV // 25)
@@ -241,9 +285,14 @@ def test_gpu_single_env_reproduces_the_trainers_eval_env(vec, pkg, oracle_mod):
     robot = pkg.Snake(None, "snake/snake.urdf", None)
     env = pkg.SnakeGymEnv(robot, None)
     env.reset()
-    seen = dict(n=0, q=0.0, r=0.0)
+    seen = dict(n=0, q=0.0, r=0.0, cq=0.0, cr=0.0)
+    e32 = oracle_mod.OracleEnv(f32=True)
 
     def on_step(i, e):
+        X = np.concatenate([e.get_aux()[0], e.get_aux()[1:]])
+        e32.hard_reset()
+        e32.sync(e.get_state(), X, e.get_manifold())
+        o32, r32, d32, k32, _ = e32.env_step(v["ppo_eval_action_in"][i, :8].copy(), vec_mode=False)
         env._stepper.set_state(e.get_state()[None], np.concatenate([e.get_aux()[0], e.get_aux()[1:]])[None])
         env._stepper.set_manifold(e.get_manifold()[None])
         a = v["ppo_eval_action_in"][i, :8].astype(np.float32)
@@ -251,10 +300,14 @@ def test_gpu_single_env_reproduces_the_trainers_eval_env(vec, pkg, oracle_mod):
         assert info == {} and np.array_equal(a, np.clip(v["ppo_eval_action_in"][i, :8], -1, 1).astype(np.float32))
         k_ref, d_ref = int(v["ppo_eval_substeps"][i]), bool(v["ppo_eval_done"][i])
         if robot.counter != k_ref or bool(d) != d_ref:
-            assert abs(robot.counter - k_ref) <= 1, (i, robot.counter, k_ref)
+            ks = _count_spread(oracle_mod, e.get_state(), X, e.get_manifold(), v["ppo_eval_action_in"][i, :8].copy(), False, i)
+            assert min(ks + [k_ref]) - 1 <= robot.counter <= max(ks + [k_ref]) + 1, (i, robot.counter, k_ref, ks)
             return
         seen["n"] += 1
         o_ref = v["ppo_eval_env_obs"][i]
+        if k32 == k_ref and d32 == d_ref:
+            seen["cq"] = max(seen["cq"], np.abs(o32[:N] - o_ref[:N]).max(), np.abs(o32[3 * N:3 * N + 7] - o_ref[3 * N:3 * N + 7]).max())
+            seen["cr"] = max(seen["cr"], abs(r32 - float(v["ppo_eval_env_reward"][i])))
         seen["q"] = max(seen["q"], np.abs(o[:N] - o_ref[:N]).max(), np.abs(o[3 * N:3 * N + 7] - o_ref[3 * N:3 * N + 7]).max())
         seen["r"] = max(seen["r"], abs(float(r) - float(v["ppo_eval_env_reward"][i])))
         if d_ref:       # the TERMINAL observation, not the reset one (SnakeGymEnv.py:39-42)
@@ -262,5 +315,7 @@ def test_gpu_single_env_reproduces_the_trainers_eval_env(vec, pkg, oracle_mod):
 
     _eval_free_run(v, oracle_mod, on_step=on_step)
     env.close()
-    print("eval env on the GPU: %d of %d env-steps compared, worst q/pose %.2e reward %.2e" % (seen["n"], len(v["ppo_eval_substeps"]), seen["q"], seen["r"]))
-    assert seen["n"] >= len(v["ppo_eval_substeps"]) * 3 // 4 and seen["q"] < 1e-2 and seen["r"] < 1e-2
+    print("eval env on the GPU: %d of %d env-steps compared, worst q/pose %.2e reward %.2e | float32 oracle %.2e %.2e"
+          % (seen["n"], len(v["ppo_eval_substeps"]), seen["q"], seen["r"], seen["cq"], seen["cr"]))
+    assert seen["n"] >= len(v["ppo_eval_substeps"]) * 3 // 4
+    assert seen["q"] < min(max(5e-3, 2 * seen["cq"]), 2.5e-2) and seen["r"] < min(max(5e-3, 2 * seen["cr"] + 2e-3), 2.5e-2)

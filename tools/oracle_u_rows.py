@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""three more [U] rules priced in the oracle alone -- what each does to what a trainer sees under the
+bench gait (32 envs x 200 env-steps, auto-reset on, float64, the same driver as tests/test_gpu_contact_models.py::
+test_contact_model_error_bar and profiles/r03_contact_models.json):
+
+  friction_directions 1    Bullet's multibody solver without SOLVER_USE_2_FRICTION_DIRECTIONS: one btPlaneSpace1 row per
+                           contact, box bounds, no cone branch
+  warm_start 1 x 0.1       warm starting with the factor PyBullet's world constructor is read as setting, beside
+                           btContactSolverInfo's 0.85
+  contact_erp_rule 1       the ERP of a contact row chosen by the split-impulse penetration threshold (m_erp 0.2 for
+                           anything shallower than 4 cm) instead of m_erp2 0.08 throughout
+
+Writes profiles/r05_u_rows.json; prints the table.  CPU only."""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import bench  # noqa: E402
+import oracle as orc  # noqa: E402
+
+orc.build()
+B, T = 32, 200
+ids = np.arange(B)
+threads = min(16, len(os.sched_getaffinity(0)))
+ROWS = [
+    ("default (Bullet's model as restated)", {}),
+    ("friction_directions 1", dict(friction_directions=1)),
+    ("warm_start 1, factor 0.85", dict(warm_start=1)),
+    ("warm_start 1, factor 0.1", dict(warm_start=1, warmstarting_factor=0.1)),
+    ("contact_erp_rule 1", dict(contact_erp_rule=1)),
+    ("contact_erp_rule 1 + warm_start 1 x 0.1", dict(contact_erp_rule=1, warm_start=1, warmstarting_factor=0.1)),
+    ("cone_friction 0 (pyramid, two directions)", dict(cone_friction=0)),
+]
+out = {}
+base = None
+print("%-44s %9s %8s %10s %10s %9s %8s" % ("switch", "substeps", "ends", "reward", "dx", "contacts", "dx vs default"))
+for name, over in ROWS:
+    _, _, agg = orc.bench_gait(B, bench.env_phases(ids), 0, T, threads, want_agg=True, max_contacts=0, **over)
+    agg = {k: float(v) for k, v in agg.items()}
+    if base is None:
+        base = agg
+    agg["dx_rel_to_default"] = agg["mean_dx"] / base["mean_dx"] - 1.0
+    out[name] = dict(switches=over, oracle=agg)
+    print("%-44s %9.3f %8.4f %10.5f %10.6f %9.1f %+7.1f %%" % (name, agg["mean_substeps"], agg["episode_end_rate"], agg["mean_reward"],
+                                                            agg["mean_dx"], agg["mean_contacts"], 100 * agg["dx_rel_to_default"]))
+with open(os.path.join(ROOT, "profiles", "r05_u_rows.json"), "w") as f:
+    json.dump(dict(workload="bench gait, %d envs x %d env-steps, float64 oracle, uncapped contacts" % (B, T), rows=out), f, indent=1)

@@ -50,8 +50,10 @@ rec_kb = 4096 * (256 if N == 16 else 512) / 1024.0
 out = {
     "round": a.round, "tag": tag, "kernel": "snk::" + K.rstrip(",") + (", ...>" if K.endswith(",") else ""),
     "workload": a.workload,
-    "command": "rocprofv3 --pmc <counters> --output-format csv -- %s  (FETCH_SIZE, WRITE_SIZE and the SQ set in "
-               "separate passes; kernel trace in its own pass)" % a.command,
+    # (--command may or may not carry the profiler's prefix already: it is printed once)
+    "command": "%s%s%s" % ("" if a.command.lstrip().startswith("rocprofv3") else "rocprofv3 --pmc <counters> --output-format csv -- ",
+                           a.command, "" if "separate passes" in a.command else
+                           "  (FETCH_SIZE, WRITE_SIZE and the SQ set in separate passes; kernel trace in its own pass)"),
     "kernel_trace_average_ms": kavg,
     "calibration": {"kernel": "snk::" + RK.rstrip(",") + ", ...>", "known_read_KB": rec_kb, "FETCH_SIZE_KB": fr['FETCH_SIZE'],
                     "known_write_KB_record_only": rec_kb, "WRITE_SIZE_KB": wr['WRITE_SIZE'],
