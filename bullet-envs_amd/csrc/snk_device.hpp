@@ -1312,15 +1312,7 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
     constexpr unsigned kFricB = (unsigned)LT::kFric * kRecB;          // the first friction pair
     // (buffer loads: resource descriptor and record offset in SGPRs, the column in a VGPR, the half in the immediate)
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(rows, 0, (int)(LT::kRowFloats * sizeof(float)), 0x00020000);
-    // The solve runs with ALL 64 lanes enabled (round 5; rounds 1-4 ran it inside `if (lane < kMO)`): lanes kMO .. 63 have
-    // no column, their loads are sent out of the buffer's range (a raw buffer load returns 0 there and fetches nothing),
-    // and what they compute is never read -- the DPP reductions below collect lanes 0 .. kMO - 1 into lane kMO - 1
-    // whatever the upper lanes hold (each step moves data towards higher lanes only).  What that buys: the upper 24 lanes
-    // of every register that lives through the solve are storage the compiler knows about (a copy or a spill moves all 64
-    // lanes), and they hold further resident rows (the stash, below).
-    const bool col = lane < LT::kMO;
-    const int vcol = col ? 4 * lane : 0x20000000;
-    const int vcol4 = col ? 16 * lane : 0x20000000;
+    const int vcol = 4 * lane;
     auto ldJ = [&](unsigned rec_bytes) {             // a column of a plain (motor) row
         return __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, vcol, (int)rec_bytes, 0));
     };
@@ -1329,20 +1321,23 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
     auto ldN = [&](unsigned rec_bytes, float& j, float& m) {       // {J, M^-1 J^T} of a normal's record
         // (rec_bytes = contact x kRecB as before; inside its pair's record the contact's two floats sit at 16 d + 8 (ci & 1))
         const unsigned odd = (rec_bytes / kRecB) & 1u;
-        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, vcol4, (int)(rec_bytes - odd * kRecB + odd * 8u), SNK_V1_LDAUX);
+        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, 4 * vcol, (int)(rec_bytes - odd * kRecB + odd * 8u), SNK_V1_LDAUX);
         j = __uint_as_float(v.x); m = __uint_as_float(v.y);
     };
     auto ldN2 = [&](unsigned rec_bytes, float& j0, float& m0, float& j1, float& m1) {      // rec_bytes: of the EVEN contact
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vcol4, (int)rec_bytes, SNK_V1_LDAUX);
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, 4 * vcol, (int)rec_bytes, SNK_V1_LDAUX);
         j0 = __uint_as_float(v.x); m0 = __uint_as_float(v.y); j1 = __uint_as_float(v.z); m1 = __uint_as_float(v.w);
     };
     auto ldF = [&](unsigned rec_bytes, float& ja, float& jb, float& ma, float& mb) {    // a friction pair's record
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vcol4, (int)rec_bytes, SNK_V1_LDAUX);
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, 4 * vcol, (int)rec_bytes, SNK_V1_LDAUX);
         ja = __uint_as_float(v.x); jb = __uint_as_float(v.y); ma = __uint_as_float(v.z); mb = __uint_as_float(v.w);
     };
+    // (Round 5 tried the solve with all 64 lanes enabled -- neutral -- and further resident rows in the upper 24 lanes of
+    //  the resident registers, fetched with ds_bpermute: bit-identical and 2 % SLOWER, a stashed row costs more issue
+    //  slots than the stream it saves; profiles/r05_c32_stash_experiment.txt)
     float dv = lane == kSpec ? 1.0f : 0.f;        // lane kSpec: the constant that multiplies the rows' -rhs column
     int it = 0;
-    {
+    if (lane < LT::kMO) {
     // the motors' M^-1 columns stay in registers for the whole solve (they are read 50 x n times)
     float RMm[N];
 #pragma unroll
@@ -1361,48 +1356,6 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
     float RNJ[kResN], RNM[kResN];
 #pragma unroll
     for (int k = 0; k < kResN; k += 2) ldN2((unsigned)k * kRecB, RNJ[k], RNM[k], RNJ[k + 1], RNM[k + 1]);
-    // THE STASH (round 5).  A row occupies lanes 0 .. kMO - 1 of its registers; lanes kMO .. 63 of the 2 kResN + N
-    // registers that live through the solve anyway -- the resident normals and the motors' M^-1 columns -- are 24 lanes
-    // of storage each, and they hold the normal rows of the next kXN contacts: stashed row e (contact kResN + e) has
-    // columns 0 .. 23 of its J half in lanes 40 .. 63 of host A and columns 24 .. 39 in lanes 40 .. 55 of host B, its
-    // M^-1 J^T half likewise in hosts C, D (SNK_XHOST).  Written once per substep (a ds_bpermute each: the LDS crossbar,
-    // no memory), read back once per iteration with the inverse gather -- two ds_bpermute and a v_cndmask per half row
-    // instead of 320 bytes from the cache the kernel is bound by.  Hosts: rows e < kResN / 2 in the
-    // resident normals 2e, 2e + 1; the next four in the motor columns 4 (e - kResN / 2) .. + 3.
-#ifndef SNK_V1_STASH
-#define SNK_V1_STASH 1
-#endif
-    constexpr int kXN = (INPLACE || !SNK_V1_STASH) ? 0 : ((kResN / 2 + 4) / 8) * 8;
-    static_assert(kXN == 0 || (kXN <= kResN / 2 + 4 && N >= 16), "stash hosts: kResN / 2 rows in the resident normals, 4 in the first 16 motor columns");
-    static_assert(kResN + kXN + kRN <= LT::NCT, "resident + stashed + in-flight normal rows exceed the contact slots of this layout");
-#define SNK_XHOST(e, w) ((e) < kResN / 2 ? ((w) < 2 ? RNJ[2 * (e) + (w)] : RNM[2 * (e) + (w) - 2]) : RMm[4 * ((e) - kResN / 2) + (w)])
-    // gather index of the read: column d < 24 from lane d + 40 (hosts A / C), 24 <= d < 40 from lane d + 16 (hosts B / D)
-    const int xrd = 4 * (lane < 24 ? lane + 40 : (lane < LT::kMO ? lane + 16 : lane));
-    auto bperm = [](int idx, float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute(idx, __float_as_int(v))); };
-    if constexpr (kXN > 0) {
-        const int wrA = 4 * (lane >= LT::kMO ? lane - 40 : lane);                       // lanes 40 .. 63 take columns 0 .. 23
-        const int wrB = 4 * ((lane >= LT::kMO && lane < 56) ? lane - 16 : lane);        // lanes 40 .. 55 take columns 24 .. 39
-        const bool up = lane >= LT::kMO;
-        // (all the records requested first, then scattered: one memory latency for the twelve loads, not twelve)
-        float sj[kXN], sm[kXN];
-#pragma unroll
-        for (int e = 0; e < kXN; e += 2) ldN2((unsigned)(kResN + e) * kRecB, sj[e], sm[e], sj[e + 1], sm[e + 1]);
-#pragma unroll
-        for (int e = 0; e < kXN; e++) {
-            asm volatile("" : "+v"(sj[e]), "+v"(sm[e]));          // (keeps the loads ahead of the first scatter)
-        }
-#pragma unroll
-        for (int e = 0; e < kXN; e++) {
-            { const float t = bperm(wrA, sj[e]); SNK_XHOST(e, 0) = up ? t : SNK_XHOST(e, 0); }
-            { const float t = bperm(wrB, sj[e]); SNK_XHOST(e, 1) = up ? t : SNK_XHOST(e, 1); }
-            { const float t = bperm(wrA, sm[e]); SNK_XHOST(e, 2) = up ? t : SNK_XHOST(e, 2); }
-            { const float t = bperm(wrB, sm[e]); SNK_XHOST(e, 3) = up ? t : SNK_XHOST(e, 3); }
-        }
-    }
-    auto unstash = [&](float hA, float hB) {          // one half row back in lanes 0 .. kMO - 1
-        const float a = bperm(xrd, hA), b = bperm(xrd, hB);
-        return lane < 24 ? a : b;
-    };
     if (__builtin_amdgcn_readfirstlane(M.warm_start)) {
         // warm starting: the normal rows start at the impulses build_rows_v1 took from the contact cache, delta-v at the
         // sum of M^-1 J^T of those (the scalar columns' part of that sum is dropped again: lane kSpec stays 1, and
@@ -1460,7 +1413,7 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
             // accumulated impulse comes from LDS one step ahead.
             float jr[kRN], mr[kRN];
 #pragma unroll
-            for (int k = 0; k < kRN; k += 2) ldN2((unsigned)(kResN + kXN + k) * kRecB, jr[k], mr[k], jr[k + 1], mr[k + 1]);
+            for (int k = 0; k < kRN; k += 2) ldN2((unsigned)(kResN + k) * kRecB, jr[k], mr[k], jr[k + 1], mr[k + 1]);
             // two contacts per step (row_step_normal2): {impulse of the even one, impulse and coupling of the odd one} come
             // from LDS one step ahead
             float a0n = L.acc[0][0];
@@ -1476,44 +1429,8 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
                 L.acc[k][0] = a0;
                 L.acc[k + 1][0] = a1;
             }
-            if constexpr (kXN > 0) {
-                // the stashed rows: the eight gathers of a pair are ISSUED in front of the previous pair's step and
-                // merged (v_cndmask) behind it, so that the step covers the crossbar's latency
-                float ga[8];
-                auto gather = [&](auto e_c) {
-                    constexpr int e = decltype(e_c)::value;
-                    ga[0] = bperm(xrd, SNK_XHOST(e, 0)); ga[1] = bperm(xrd, SNK_XHOST(e, 1));
-                    ga[2] = bperm(xrd, SNK_XHOST(e, 2)); ga[3] = bperm(xrd, SNK_XHOST(e, 3));
-                    ga[4] = bperm(xrd, SNK_XHOST(e + 1, 0)); ga[5] = bperm(xrd, SNK_XHOST(e + 1, 1));
-                    ga[6] = bperm(xrd, SNK_XHOST(e + 1, 2)); ga[7] = bperm(xrd, SNK_XHOST(e + 1, 3));
-                };
-                const bool lo24 = lane < 24;
-                gather(std::integral_constant<int, 0>{});
-                float xj0 = lo24 ? ga[0] : ga[1], xm0 = lo24 ? ga[2] : ga[3], xj1 = lo24 ? ga[4] : ga[5], xm1 = lo24 ? ga[6] : ga[7];
-                bool more = true;
-                auto stash_step = [&](auto e_c) {
-                    constexpr int e = decltype(e_c)::value;
-                    if (!more) return;
-                    if ((e & 7) == 0 && kResN + e >= nc_pad) { more = false; return; }     // wave-uniform
-                    if constexpr (e + 2 < kXN) gather(std::integral_constant<int, e + 2>{});
-                    float a0 = a0n, a1 = a1n.x;
-                    const float c1 = a1n.y;
-                    a0n = L.acc[kResN + e + 2][0];
-                    a1n = make_float2(L.acc[kResN + e + 3][0], L.acc[kResN + e + 3][3]);
-                    row_step_normal2<LT::kMO - 1>(xj0, xm0, xj1, xm1, a0, a1, c1, dv, lsq);
-                    L.acc[kResN + e][0] = a0;
-                    L.acc[kResN + e + 1][0] = a1;
-                    if constexpr (e + 2 < kXN) {
-                        asm volatile("" : "+v"(ga[0]), "+v"(ga[1]), "+v"(ga[2]), "+v"(ga[3]));      // (merged here, not in front of the step)
-                        asm volatile("" : "+v"(ga[4]), "+v"(ga[5]), "+v"(ga[6]), "+v"(ga[7]));
-                        xj0 = lo24 ? ga[0] : ga[1]; xm0 = lo24 ? ga[2] : ga[3]; xj1 = lo24 ? ga[4] : ga[5]; xm1 = lo24 ? ga[6] : ga[7];
-                    }
-                };
-                [&]<int... E>(std::integer_sequence<int, E...>) { (stash_step(std::integral_constant<int, 2 * E>{}), ...); }
-                (std::make_integer_sequence<int, kXN / 2>{});
-            }
             unsigned rb = 0;           // record the current group of eight refills counts from (wave-uniform)
-            for (int base = kResN + kXN; base < nc_pad; base += kRN) {
+            for (int base = kResN; base < nc_pad; base += kRN) {
 #pragma unroll
                 for (int k = 0; k < kRN; k += 2) {
                     if ((k & 7) == 0 && k > 0 && base + k >= nc_pad) break;      // wave-uniform
@@ -1548,7 +1465,7 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
                 for (int p = 0; p < kP; p++) {
                     const int c = LT::kMO * p + lane;
                     bool lv = false;
-                    if (col && c < nc_pad) {
+                    if (c < nc_pad) {
                         const float4 a = *reinterpret_cast<const float4*>(L.acc[c]);
                         lv = (mu * a.x > 0.f) || (a.y != 0.f) || (a.z != 0.f);     // (-0 counts as zero: a pair projected onto radius 0)
                     }
@@ -1618,7 +1535,6 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
     iters = it;
     return act ? dv : 0.f;
 }
-#undef SNK_XHOST
 
 // ----------------------------------------------------------------------------------
 // one physics substep
