@@ -32,7 +32,7 @@ class SnkParams(C.Structure):
         ("contact_erp", C.c_double), ("linear_slop", C.c_double),
         ("breaking_threshold", C.c_double), ("relative_breaking_threshold", C.c_int32), ("cone_friction", C.c_int32),
         ("n_iterations", C.c_int32), ("residual_threshold", C.c_double),
-        ("warm_start", C.c_int32), ("warmstarting_factor", C.c_double),
+        ("warm_start", C.c_int32), ("warmstarting_factor", C.c_double), ("friction_directions", C.c_int32),
         ("scaling_factor", C.c_double), ("gait", C.c_int32),
         ("servo_tol", C.c_double), ("max_counter", C.c_int32),
         ("height_threshold", C.c_double), ("energy_dt", C.c_double),

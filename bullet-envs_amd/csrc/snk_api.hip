@@ -236,6 +236,7 @@ void snk_default_params(snk_params* p) {
     p->residual_threshold = 1e-7;
     p->warm_start = 0;          // disabled in btMultiBodyConstraintSolver [U]
     p->warmstarting_factor = 0.85;
+    p->friction_directions = 2;
     p->scaling_factor = 3.14159265358979323846 / 6.0;
     p->gait = 1;
     p->servo_tol = 0.05;
@@ -404,6 +405,7 @@ int snk_create(const snk_params* p, int32_t n_envs, int32_t device, snk_handle**
                     "the snake's 22 in the 40-lane solve)");
     if (p->obstacle == 2 && !(p->obstacle_mass > 0.0)) return fail("snk_create: obstacle_mass must be positive");
     if (p->warm_start != 0 && p->warm_start != 1) return fail("snk_create: warm_start must be 0 or 1");
+    if (p->friction_directions != 1 && p->friction_directions != 2) return fail("snk_create: friction_directions must be 1 or 2");
     if (p->warm_start && p->contact_model != 1)
         return fail("snk_create: warm_start needs contact_model 1 (the impulses live in the persistent contact cache)");
     if (!(p->breaking_threshold > 0.0)) return fail("snk_create: breaking_threshold must be positive");

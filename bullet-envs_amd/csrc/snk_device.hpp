@@ -604,7 +604,7 @@ __device__ int find_contacts_v1(LT& L, const DevModel& M, int lane, float* __res
             f3 l1 = mulRtv(Rw, mk3(0.f, -1.f, 0.f));
             f3 l2 = mulRtv(Rw, mk3(1.f, 0.f, 0.f));
             st3(geo + 4, mulRv(Rw, mk3(l1.x * a.x, l1.y * a.y, l1.z * a.z)));
-            st3(geo + 7, mulRv(Rw, mk3(l2.x * a.x, l2.y * a.y, l2.z * a.z)));
+            st3(geo + 7, mulRv(Rw, mk3(l2.x * a.x, l2.y * a.y, l2.z * a.z)) * M.fricB);
             st3(geo + 10, mk3(0.f, 0.f, 1.f));
             st3(geo + 13, mk3(0.f, 0.f, 0.f));
             geo[16] = (float)b; geo[17] = -1.0f; geo[18] = 1.0f; geo[19] = 0.f;

@@ -124,7 +124,7 @@ __device__ __forceinline__ int find_box_ground_v1(LT& L, const DevModel& M, int 
                 st3(geo, wa[j]);
                 geo[3] = p[j].d;
                 st3(geo + 4, mk3(0.f, -1.f, 0.f));
-                st3(geo + 7, mk3(1.f, 0.f, 0.f));
+                st3(geo + 7, mk3(M.fricB, 0.f, 0.f));
                 st3(geo + 10, mk3(0.f, 0.f, 1.f));
                 st3(geo + 13, mk3(0.f, 0.f, 0.f));
                 geo[16] = (float)LT::kBoxBody; geo[17] = -1.0f; geo[18] = rho;

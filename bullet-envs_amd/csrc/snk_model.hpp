@@ -60,6 +60,7 @@ struct DevModel {
     int poison;                          // SNK_POISON=1 at snk_create: LDS images start as NaNs (snk_device.hpp: poison)
     int hist;                            // snk_contact_histogram_enable: count every substep's contact points (one atomic each)
     float warm_factor;
+    float fricB;                         // snk_params::friction_directions: 1.0 (two tangents), 0.0 (the second tangent gets no row)
     int obstacle;                        // a static box on the ground (snake/block.urdf), contacts through the streamed-row solve
     float obs_c[3], obs_h[3], mu_obs;    // its centre, half extents, lateral friction
     // obstacle 2 (a free body): mass, inverse inertia diagonal in box axes, breaking threshold of its manifold with the plane
@@ -266,7 +267,11 @@ inline void build_dev_model(const snk_params& P, const HostModel& H, DevModel& D
         D.hull_xy[s][1] = (float)(kCylR * cos(th));
     }
     D.resid_thr = (float)P.residual_threshold;
-    D.n_iter = P.n_iterations; D.cone = P.cone_friction;
+    D.n_iter = P.n_iterations;
+    // (Bullet enters the implicit-cone branch only under SOLVER_USE_2_FRICTION_DIRECTIONS [U]: with one direction the
+    //  friction rows go through the box-bounded loop, which skips a row while its contact carries no normal impulse)
+    D.cone = (P.cone_friction && P.friction_directions == 2) ? 1 : 0;
+    D.fricB = P.friction_directions == 1 ? 0.0f : 1.0f;
     D.scaling = (float)P.scaling_factor; D.servo_tol = (float)P.servo_tol;
     D.height_thr = (float)P.height_threshold; D.energy_dt = (float)P.energy_dt;
     D.alpha = (float)P.alpha; D.beta = (float)P.beta; D.gamma = (float)P.gamma;

@@ -127,7 +127,9 @@ __device__ __forceinline__ void friction_dirs(const DevModel& M, const float* Rw
     const f3 l1 = mulRtv(Rw, mk3(0.f, -1.f, 0.f));
     const f3 l2 = mulRtv(Rw, mk3(1.f, 0.f, 0.f));
     dA = mulRv(Rw, mk3(l1.x * a.x, l1.y * a.y, l1.z * a.z));
-    dB = mulRv(Rw, mk3(l2.x * a.x, l2.y * a.y, l2.z * a.z));
+    // friction_directions 1: the second tangent is a zero vector -- its row comes out J = 0, M^-1 J^T = 0, den = 0 and
+    // resolves to nothing in either friction form (the cone over (x, 0) is the box bound of the one row)
+    dB = mulRv(Rw, mk3(l2.x * a.x, l2.y * a.y, l2.z * a.z)) * M.fricB;
 }
 
 // One cached manifold point: the point on the link in the LINK's coordinates (cylinder frame + cyl_zoff along z),
@@ -437,7 +439,7 @@ __device__ __forceinline__ int find_obstacle_v2(LT& L, const DevModel& M, int la
         h.hit = h.dist < M.break_thr;
         plane_space(h.n, h.dA, h.dB);
         h.dA = aniso_scale(M, A.R, h.dA);
-        h.dB = aniso_scale(M, A.R, h.dB);
+        h.dB = aniso_scale(M, A.R, h.dB) * M.fricB;
     }
     // (more than kObs of them: the caller sends the substep to the streamed-row solve, which has room for every cylinder)
     return __popcll(__ballot(h.hit));

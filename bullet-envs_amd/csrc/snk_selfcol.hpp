@@ -448,7 +448,7 @@ __device__ int find_self_contacts_v1(LT& L, const DevModel& M, int lane, float m
                 f3 dA, dB;
                 plane_space(nrm, dA, dB);
                 dA = aniso_scale(M, B.R, aniso_scale(M, A.R, dA));
-                dB = aniso_scale(M, B.R, aniso_scale(M, A.R, dB));
+                dB = aniso_scale(M, B.R, aniso_scale(M, A.R, dB)) * M.fricB;
                 st3(geo, P);
                 geo[3] = dist;
                 st3(geo + 4, dA);
@@ -475,7 +475,7 @@ __device__ int find_self_contacts_v1(LT& L, const DevModel& M, int lane, float m
             f3 dA, dB;
             plane_space(ob_n, dA, dB);
             dA = aniso_scale(M, ob_R, dA);
-            dB = aniso_scale(M, ob_R, dB);
+            dB = aniso_scale(M, ob_R, dB) * M.fricB;
             st3(geo, ob_P);
             geo[3] = ob_dist;
             st3(geo + 4, dA);

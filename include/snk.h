@@ -87,6 +87,13 @@ typedef struct snk_params {
                                    keeps it: btManifoldPoint::m_appliedImpulse), delta-v at the sum of M^-1 J^T of those;
                                    friction rows start at zero.  Needs contact_model 1                            */
     double  warmstarting_factor;/* 0.85 [U] btContactSolverInfo::m_warmstartingFactor            */
+    int32_t friction_directions;/* 2 (default) [U]: SOLVER_USE_2_FRICTION_DIRECTIONS -- both btPlaneSpace1 tangents of a
+                                   contact get a friction row (with cone_friction: the implicit cone over the pair).
+                                   1: Bullet's multibody solver WITHOUT that flag -- one row per contact, along the first
+                                   tangent ((0,-1,0) for the ground's normal), bounds +-mu lambda_n.  A switch since
+                                   round 5 because the oracle prices it above the error bar's other rows (+14 % forward
+                                   motion under the bench gait: profiles/r05_u_rows.json); the default is the reading
+                                   under which a body pushed along world x comes to rest, as it does in PyBullet      */
     /* Snake / SnakeGymEnv */
     double  scaling_factor;     /* snake.py:63   pi/6                                         */
     int32_t gait;               /* snake.py:62   1: actions drive odd motor slots             */

@@ -35,6 +35,7 @@ SWITCHES = {
     "default": dict(),                                                   # hull + manifold, relative threshold (1.2 mm)
     "default+warm": dict(warm_start=1),
     "default+pyramid": dict(cone_friction=0),                            # two friction rows, box bounds, no implicit cone
+    "default+1dir": dict(friction_directions=1),                         # no SOLVER_USE_2_FRICTION_DIRECTIONS: one row per contact
 }
 
 

@@ -151,6 +151,40 @@ def test_rare_branch_pyramid_friction(pkg, oracle_mod):
     assert (np.abs(G[:, 29:] - R[:, 29:]) / (1 + np.abs(R[:, 29:]))).max() < 5e-2
 
 
+@pytest.mark.parametrize("n", [16, 32])
+def test_one_friction_direction(pkg, oracle_mod, n):
+    """friction_directions=1 (round 5): Bullet's multibody solver without
+    SOLVER_USE_2_FRICTION_DIRECTIONS [U] -- one friction row per contact along the first btPlaneSpace1 tangent, bounds
+    +-mu lambda_n, no cone branch.  One substep from ground states with lateral motion, GPU against the oracle under the
+    same switch, calibrated per state against the float32 build of the oracle (box-bounded rows switch on and off with the
+    normal impulse, as in the pyramid test above); and the switch does something: the result differs from the default's."""
+    B = 16 if n == 16 else 8
+    rng = np.random.default_rng(79)
+    S = np.array([random_state(rng, n, z=0.026, qamp=0.3, vamp=0.3, flat=True) for _ in range(B)])
+    S[:, 7:9] *= 0.1; S[:, 9] *= 0.1
+    T = rng.uniform(-0.5, 0.5, (B, n))
+    over = dict(friction_directions=1, residual_threshold=0.0, self_collision=0)
+    G, _, info, R, its, ncs = _substep_compare(pkg, oracle_mod, S, T, n=n, **over)
+    over["n_modules"] = n
+    assert np.array_equal(info[:, 1], ncs) and np.array_equal(info[:, 0], its)
+    S32 = S.astype(np.float32)
+    moved = 0.0
+    for i in range(B):
+        o = oracle_mod.OracleEnv(f32=True, **over)
+        o.set_state(S32[i].astype(np.float64))
+        o.substep(T[i].astype(np.float32).astype(np.float64))
+        r32 = o.get_state()
+        cal_p, cal_q = np.abs(r32[:7] - R[i, :7]).max(), np.abs(r32[13:13 + n] - R[i, 13:13 + n]).max()
+        assert np.abs(G[i, :7] - R[i, :7]).max() < min(max(5e-5, 2 * cal_p), 5e-4), i
+        assert np.abs(G[i, 13:13 + n] - R[i, 13:13 + n]).max() < min(max(2e-4, 2 * cal_q), 2e-3), i
+        d = oracle_mod.OracleEnv(**dict(over, friction_directions=2))
+        d.set_state(S32[i].astype(np.float64))
+        d.substep(T[i].astype(np.float32).astype(np.float64))
+        moved = max(moved, np.abs(d.get_state()[7:13] - R[i, 7:13]).max())
+    assert (np.abs(G[:, 13 + n:] - R[:, 13 + n:]) / (1 + np.abs(R[:, 13 + n:]))).max() < 5e-2
+    assert moved > 1e-3          # base twist after one substep: the second tangent's friction is really gone
+
+
 def test_rare_branch_joint_limits(pkg, oracle_mod):
     """Joints beyond +-1.57 create limit rows (kept in LDS, generic path)."""
     n, B = 16, 8
