@@ -184,8 +184,11 @@ def test_gpu_env_step_reproduces_the_reference(vec, pkg, oracle_mod):
           "qd p90 %.2e | float32 oracle: %.2e %.2e %.2e" % (compared, mism, worst["q"], worst["r"], p90, cal["q"], cal["r"], p90c))
     print("  (the float32 oracle's own boundary mismatches among the compared rows: %d)" % mism32)
     # every mismatch was checked to sit at a decision boundary above; their number stays in the float32 oracle's range
-    assert mism <= 2 * mism32 + 12 and compared >= n_rows * 3 // 4
-    # float32 sensitivity of one env-step (tests/test_gpu_env.py): calibrated, with a hard outer cap next to it
-    assert worst["q"] < min(max(5e-3, 2 * cal["q"]), 2.5e-2)
-    assert worst["r"] < min(max(5e-3, 2 * cal["r"] + 2e-3), 2.5e-2)
-    assert p90 < min(max(5e-2, 2 * p90c), 0.25)
+    # (observed, round 5: 16 of 161, the float32 oracle's own 2 -- profiles/r05_accuracy_calibration.txt; + 4 of slack)
+    assert mism <= 20 and compared >= n_rows * 3 // 4
+    # float32 sensitivity of one env-step (DESIGN.md 3 states the tolerance): within 1.5 x the float32 oracle's own
+    # distance from the reference on the same rows (observed 1.00 x for angles / pose: 1.20e-2 both; 1.13 x for the
+    # reward; 1.25 x for the velocities' 90th percentile), with a hard outer cap next to it
+    assert worst["q"] < min(max(5e-3, 1.5 * cal["q"]), 2.5e-2)
+    assert worst["r"] < min(max(5e-3, 1.5 * cal["r"] + 1e-3), 2.5e-2)
+    assert p90 < min(max(5e-2, 1.5 * p90c), 0.25)

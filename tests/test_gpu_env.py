@@ -83,7 +83,10 @@ def test_env_step_parity_resynced(pkg, oracle_mod, n):
     print("n", n, "GPU-f32 vs oracle-f64 worst", worst, "qd p90", p90, "| oracle-f32 vs oracle-f64", cal, "qd p90", p90c,
           "| boundary mismatches", mism, "(oracle-f32:", cal_mism, ") of", B * J)
     # the 32-link chain is twice as long and correspondingly more sensitive to round-off
-    tq, tp90, tmax, kcal = (5e-3, 5e-2, 0.75, 2.0) if n == 16 else (1e-2, 0.4, 1.0, 3.0)
+    # kcal: how far beyond the float32 oracle's own distance from float64 the GPU may be.  Observed (round 5,
+    # profiles/r05_accuracy_calibration.txt): 16 links q 1.00 x, reward 1.12 x, qd 0.61 x; 32 links 1.04 x, 1.16 x, 0.61 x
+    # -- so 1.5 (2.0 for the longer chain's 24 samples), where rounds 3-4 allowed 2.0 (3.0)
+    tq, tp90, tmax, kcal = (5e-3, 5e-2, 0.75, 1.5) if n == 16 else (1e-2, 0.4, 1.0, 2.0)
     # (hulls on a persistent manifold of one to four points roll more easily than round 1's two end-cap points per
     #  cylinder: the float32 ORACLE itself is 1e-2 off the float64 one on the worst of these steps, so the absolute caps
     #  give way to the calibration below)

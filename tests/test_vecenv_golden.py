@@ -274,11 +274,13 @@ def test_gpu_subprocvecenv_reproduces_the_reference_seam(vec, pkg, oracle_mod, t
     # every mismatch was checked above to sit at a servo / angle boundary or at a bifurcation; their number stays in the
     # float32 oracle's range (observed on the GPU, round 5: ARS 58 of 1600 with 35 bifurcations, float32 oracle 29;
     # PPO 54 of 640 with 22, float32 oracle 12)
-    assert stats["mism"] - stats["undecidable"] <= 2 * stats["mism32"] + max(8, T * NENV // 25)
-    assert stats["undecidable"] <= T * NENV // 16
-    assert stats["q"] < min(max(5e-3, 2 * stats["cq"]), 2.5e-2)
-    assert stats["r"] < min(max(5e-3, 2 * stats["cr"] + 2e-3), 2.5e-2)
-    assert p90 < min(max(5e-2, 2 * p90c), 0.25)
+    assert stats["mism"] - stats["undecidable"] <= (27 if t == "ars_" else 36)       # observed + 4
+    assert stats["undecidable"] <= (39 if t == "ars_" else 26)                       # observed + 4
+    # (observed: ARS 1.32e-2 / 5.9e-3 / 7.25e-2 against the float32 oracle's 2.74e-2 / 5.2e-3 / 7.28e-2; PPO 1.84e-2 / 2.20e-2 /
+    #  8.58e-2 against 1.85e-2 / 2.19e-2 / 8.62e-2: the GPU is where the float32 oracle is)
+    assert stats["q"] < min(max(5e-3, 1.5 * stats["cq"]), 2.5e-2)
+    assert stats["r"] < min(max(5e-3, 1.5 * stats["cr"] + 1e-3), 2.5e-2)
+    assert p90 < min(max(5e-2, 1.5 * p90c), 0.25)
 
 
 @pytest.mark.gpu
