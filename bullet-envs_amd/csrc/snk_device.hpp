@@ -1248,96 +1248,6 @@ __device__ __forceinline__ void row_step_cone(float jA, float mA, float jB, floa
     accB = xB;
 }
 
-// ---- the same two steps with ONE reduction for both rows (round 5).  With every lane of the wave enabled and exact zeros
-// in lanes kMO .. 63 of all operands, v_permlane32_swap turns the two product vectors (A | B) into ([A_lo | B_lo],
-// [A_hi | B_hi]); their sum holds A folded onto lanes 0 .. 31 and B folded onto lanes 32 .. 63, and the five DPP stages of
-// a 32-lane reduction leave both sums in lanes 31 and 63: 1 swap + 1 add + 5 DPP adds instead of 12 DPP adds -- 23 VALU
-// per pair of normals instead of 28, 26 per friction pair instead of 31.  The summation order differs from the
-// two-reduction form (so do the last bits), the arithmetic does not.
-#ifndef SNK_V1_MERGED
-#define SNK_V1_MERGED 1
-#endif
-#define SNK_RED_MERGED                                                                                   \
-    "s_nop 1\n\t"                                                                                        \
-    "v_permlane32_swap_b32 %[tA], %[tB]\n\t"                                                             \
-    "v_add_f32 %[tA], %[tA], %[tB]\n\t"                                                                  \
-    "s_nop 1\n\t"                                                                                        \
-    "v_add_f32_dpp %[tA], %[tA], %[tA] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"  \
-    "s_nop 1\n\t"                                                                                        \
-    "v_add_f32_dpp %[tA], %[tA], %[tA] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"  \
-    "s_nop 1\n\t"                                                                                        \
-    "v_add_f32_dpp %[tA], %[tA], %[tA] row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"            \
-    "s_nop 1\n\t"                                                                                        \
-    "v_add_f32_dpp %[tA], %[tA], %[tA] row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"            \
-    "s_nop 1\n\t"                                                                                        \
-    "v_add_f32_dpp %[tA], %[tA], %[tA] row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"                      \
-    "s_nop 0\n\t"                                                                                        \
-    "v_readlane_b32 %[sA], %[tA], 31\n\t"                                                                \
-    "v_readlane_b32 %[sB], %[tA], 63\n\t"                                                                \
-    "s_nop 0\n\t"
-__device__ __forceinline__ void row_step_normal2m(float jA, float mA, float jB, float mB, float& accA, float& accB, float c,
-                                                  float& dv, float& lsq) {
-    float tA, tB, xA, xB, dA, sA, sB;
-    asm volatile(
-        "v_mul_f32 %[tA], %[jA], %[dv]\n\t"
-        "v_mul_f32 %[tB], %[jB], %[dv]\n\t"
-        SNK_RED_MERGED
-        "v_subrev_f32 %[xA], %[sA], %[accA]\n\t"
-        "v_subrev_f32 %[xB], %[sB], %[accB]\n\t"
-        "v_max_f32 %[xA], 0, %[xA]\n\t"
-        "v_sub_f32 %[dA], %[xA], %[accA]\n\t"
-        "v_fma_f32 %[xB], -%[c], %[dA], %[xB]\n\t"
-        "v_max_f32 %[xB], 0, %[xB]\n\t"
-        "v_mul_f32 %[tA], %[dA], %[mA]\n\t"
-        "v_sub_f32 %[dA], %[xB], %[accB]\n\t"
-        "v_add_f32 %[dv], %[dv], %[tA]\n\t"
-        "v_mul_f32 %[tB], %[dA], %[mB]\n\t"
-        "v_add_f32 %[dv], %[dv], %[tB]\n\t"
-        "v_max3_f32 %[lsq], %[lsq], |%[tA]|, |%[tB]|\n\t"
-        : [tA] "=&v"(tA), [tB] "=&v"(tB), [xA] "=&v"(xA), [xB] "=&v"(xB), [dA] "=&v"(dA), [sA] "=&s"(sA), [sB] "=&s"(sB),
-          [dv] "+v"(dv), [lsq] "+v"(lsq)
-        : [jA] "v"(jA), [mA] "v"(mA), [jB] "v"(jB), [mB] "v"(mB), [accA] "v"(accA), [accB] "v"(accB), [c] "v"(c));
-    accA = xA;
-    accB = xB;
-}
-__device__ __forceinline__ void row_step_conem(float jA, float mA, float jB, float mB, float& accA, float& accB, float lim,
-                                               float EPS, float& dv, float& lsq) {
-    float tA, tB, xA, xB, r2, P, sA, sB;
-    asm volatile(
-        "v_mul_f32 %[tA], %[jA], %[dv]\n\t"
-        "v_mul_f32 %[tB], %[jB], %[dv]\n\t"
-        SNK_RED_MERGED
-        "v_subrev_f32 %[xA], %[sA], %[accA]\n\t"
-        "v_subrev_f32 %[xB], %[sB], %[accB]\n\t"
-        "v_fma_f32 %[r2], %[xA], %[xA], %[EPS]\n\t"
-        "v_fma_f32 %[r2], %[xB], %[xB], %[r2]\n\t"
-        "v_rsq_f32 %[r2], %[r2]\n\t"
-        "s_nop 0\n\t"
-        "v_mul_f32_e64 %[r2], %[lim], %[r2] clamp\n\t"
-        "v_mul_f32 %[xA], %[xA], %[r2]\n\t"
-        "v_mul_f32 %[xB], %[xB], %[r2]\n\t"
-        "v_sub_f32 %[tA], %[xA], %[accA]\n\t"
-        "v_sub_f32 %[tB], %[xB], %[accB]\n\t"
-        "v_mul_f32 %[P], %[tA], %[mA]\n\t"
-        "v_mul_f32 %[r2], %[tB], %[mB]\n\t"
-        "v_add_f32 %[dv], %[dv], %[P]\n\t"
-        "v_add_f32 %[dv], %[dv], %[r2]\n\t"
-        "v_max3_f32 %[lsq], %[lsq], |%[P]|, |%[r2]|\n\t"
-        : [tA] "=&v"(tA), [tB] "=&v"(tB), [xA] "=&v"(xA), [xB] "=&v"(xB), [r2] "=&v"(r2), [P] "=&v"(P), [sA] "=&s"(sA),
-          [sB] "=&s"(sB), [dv] "+v"(dv), [lsq] "+v"(lsq)
-        : [jA] "v"(jA), [mA] "v"(mA), [jB] "v"(jB), [mB] "v"(mB), [accA] "v"(accA), [accB] "v"(accB), [lim] "v"(lim),
-          [EPS] "v"(EPS));
-    accA = xA;
-    accB = xB;
-}
-#if SNK_V1_MERGED
-#define SNK_STEP_N2(...) row_step_normal2m(__VA_ARGS__)
-#define SNK_STEP_CONE(...) row_step_conem(__VA_ARGS__)
-#else
-#define SNK_STEP_N2(...) row_step_normal2<LT::kMO - 1>(__VA_ARGS__)
-#define SNK_STEP_CONE(...) row_step_cone<LT::kMO - 1>(__VA_ARGS__)
-#endif
-
 // INPLACE: the copy that runs inside the register-resident kernels for their rare substeps (substep()): it keeps rounds
 // 2-3's 32 / 32 / 16 registers' split.  With the standalone kernels' 40 / 16 / 16 (round 4: +2 % for 32 links, +7 % for the
 // 16-link streamed-row kernels) the register-resident kernel around it came out 3.6 % slower -- 352 k against 365 k
@@ -1402,13 +1312,7 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
     constexpr unsigned kFricB = (unsigned)LT::kFric * kRecB;          // the first friction pair
     // (buffer loads: resource descriptor and record offset in SGPRs, the column in a VGPR, the half in the immediate)
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(rows, 0, (int)(LT::kRowFloats * sizeof(float)), 0x00020000);
-    // The solve runs with ALL 64 lanes enabled (round 5; rounds 1-4 ran it inside `if (lane < kMO)`): lanes kMO .. 63 have
-    // no column, their loads are sent out of the buffer's range (a raw buffer load returns 0 there and fetches nothing),
-    // so every row register, delta-v and the motor columns hold exact zeros up there for the whole solve -- which is what
-    // lets the merged reduction of the row steps (SNK_V1_MERGED, below) fold lanes 32 .. 63 onto lanes 0 .. 31.
-    const bool col = lane < LT::kMO;
-    const int vcol = col ? 4 * lane : 0x20000000;
-    const int vcol4 = col ? 16 * lane : 0x20000000;
+    const int vcol = 4 * lane;
     auto ldJ = [&](unsigned rec_bytes) {             // a column of a plain (motor) row
         return __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, vcol, (int)rec_bytes, 0));
     };
@@ -1417,23 +1321,25 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
     auto ldN = [&](unsigned rec_bytes, float& j, float& m) {       // {J, M^-1 J^T} of a normal's record
         // (rec_bytes = contact x kRecB as before; inside its pair's record the contact's two floats sit at 16 d + 8 (ci & 1))
         const unsigned odd = (rec_bytes / kRecB) & 1u;
-        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, vcol4, (int)(rec_bytes - odd * kRecB + odd * 8u), SNK_V1_LDAUX);
+        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, 4 * vcol, (int)(rec_bytes - odd * kRecB + odd * 8u), SNK_V1_LDAUX);
         j = __uint_as_float(v.x); m = __uint_as_float(v.y);
     };
     auto ldN2 = [&](unsigned rec_bytes, float& j0, float& m0, float& j1, float& m1) {      // rec_bytes: of the EVEN contact
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vcol4, (int)rec_bytes, SNK_V1_LDAUX);
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, 4 * vcol, (int)rec_bytes, SNK_V1_LDAUX);
         j0 = __uint_as_float(v.x); m0 = __uint_as_float(v.y); j1 = __uint_as_float(v.z); m1 = __uint_as_float(v.w);
     };
     auto ldF = [&](unsigned rec_bytes, float& ja, float& jb, float& ma, float& mb) {    // a friction pair's record
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vcol4, (int)rec_bytes, SNK_V1_LDAUX);
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, 4 * vcol, (int)rec_bytes, SNK_V1_LDAUX);
         ja = __uint_as_float(v.x); jb = __uint_as_float(v.y); ma = __uint_as_float(v.z); mb = __uint_as_float(v.w);
     };
     // (Round 5 tried the solve with all 64 lanes enabled -- neutral -- and further resident rows in the upper 24 lanes of
     //  the resident registers, fetched with ds_bpermute: bit-identical and 2 % SLOWER, a stashed row costs more issue
-    //  slots than the stream it saves; profiles/r05_c32_stash_experiment.txt)
+    //  slots than the stream it saves; and one reduction for a step's two dots (v_permlane32_swap, 17 % fewer VALU
+    //  instructions): no change -- the solve runs at the latency of each wave's chain of dependent row steps, not at a
+    //  byte or an issue rate; profiles/r05_c32_stash_experiment.txt)
     float dv = lane == kSpec ? 1.0f : 0.f;        // lane kSpec: the constant that multiplies the rows' -rhs column
     int it = 0;
-    {
+    if (lane < LT::kMO) {
     // the motors' M^-1 columns stay in registers for the whole solve (they are read 50 x n times)
     float RMm[N];
 #pragma unroll
@@ -1521,7 +1427,7 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
                 const float c1 = a1n.y;
                 a0n = L.acc[k + 2][0];
                 a1n = make_float2(L.acc[k + 3][0], L.acc[k + 3][3]);
-                SNK_STEP_N2(RNJ[k], RNM[k], RNJ[k + 1], RNM[k + 1], a0, a1, c1, dv, lsq);
+                row_step_normal2<LT::kMO - 1>(RNJ[k], RNM[k], RNJ[k + 1], RNM[k + 1], a0, a1, c1, dv, lsq);
                 L.acc[k][0] = a0;
                 L.acc[k + 1][0] = a1;
             }
@@ -1534,7 +1440,7 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
                     const float c1 = a1n.y;
                     a0n = L.acc[base + k + 2][0];
                     a1n = make_float2(L.acc[base + k + 3][0], L.acc[base + k + 3][3]);
-                    SNK_STEP_N2(jr[k], mr[k], jr[k + 1], mr[k + 1], a0, a1, c1, dv, lsq);
+                    row_step_normal2<LT::kMO - 1>(jr[k], mr[k], jr[k + 1], mr[k + 1], a0, a1, c1, dv, lsq);
                     L.acc[base + k][0] = a0;
                     L.acc[base + k + 1][0] = a1;
                     // the refill: the contacts kRN further on if there are any, else this trip's once more
@@ -1561,7 +1467,7 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
                 for (int p = 0; p < kP; p++) {
                     const int c = LT::kMO * p + lane;
                     bool lv = false;
-                    if (col && c < nc_pad) {
+                    if (c < nc_pad) {
                         const float4 a = *reinterpret_cast<const float4*>(L.acc[c]);
                         lv = (mu * a.x > 0.f) || (a.y != 0.f) || (a.z != 0.f);     // (-0 counts as zero: a pair projected onto radius 0)
                     }
@@ -1593,7 +1499,7 @@ __device__ float pgs_v1(LT& L, const DevModel& M, int lane, int nc, int nn, floa
                         asm volatile("" : "+s"(lv));         // the test stays a scalar bit test here (hoisted, sixteen lane masks spill SGPRs)
                         if ((lv >> k) & 1ull) {
                             float aA = c.y, aB = c.z;
-                            SNK_STEP_CONE(jA[k], mA[k], jB[k], mB[k], aA, aB, mu * c.x, EPS, dv, lsq);
+                            row_step_cone<LT::kMO - 1>(jA[k], mA[k], jB[k], mB[k], aA, aB, mu * c.x, EPS, dv, lsq);
                             *reinterpret_cast<float2*>(&L.acc[base + k][1]) = make_float2(aA, aB);
                         }
                         // the refill, issued after the step (the four registers are free then): the pair kC further on
