@@ -480,6 +480,14 @@ class SubprocVecEnv(SnakeVecEnv):
         params = getattr(proto, "params", None)
         if params is None:
             raise TypeError("env_fns must build bullet-envs_amd SnakeGymEnv objects")
+        mode = getattr(proto, "mode", "train")
         if hasattr(proto, "close"):
             proto.close()
+        if mode == 'test':
+            # the reference's workers would send each env's per-substep telemetry through their Pipes
+            # (SnakeGymEnv.py:43-44); the vector seam here returns train-mode infos only -- refuse rather than hand a
+            # trainer empty dicts where it asked for telemetry
+            raise NotImplementedError("SubprocVecEnv: mode='test' (per-substep telemetry in infos) is served by the "
+                                      "single-env seam, bullet-envs_amd SnakeGymEnv(robot, args); the vector seam is "
+                                      "train-mode only")
         SnakeVecEnv.__init__(self, len(env_fns), device=device, params=params)

@@ -192,6 +192,17 @@ def test_subproc_vec_env_dropin(pkg):
     envs = pkg.SubprocVecEnv([pkg.CloudpickleWrapper(make_env()) for _ in range(3)])
     assert envs.num_envs == 3 and envs.reset().shape == (3, 56)
     envs.close()
+    # thunks that build test-mode envs (ppo/params.py --mode test): the vector seam has no per-substep telemetry to put
+    # into infos, and says so instead of returning empty dicts
+    class Args:
+        alpha, beta, gamma = 1.0, 0.01, 0.1
+        gaitSelection, scaling_factor, mode = 1, 6.0, 'test'
+        motorVelocityLimit, motorTorqueLimit = np.inf, np.inf
+
+    def make_test_env():
+        return lambda: pkg.SnakeGymEnv(pkg.Snake(None, "snake/snake.urdf", Args()), Args())
+    with pytest.raises(NotImplementedError):
+        pkg.SubprocVecEnv([make_test_env() for _ in range(2)])
 
 
 def test_ground_friction_config(pkg, oracle_mod):
