@@ -123,7 +123,7 @@ int resident_waves(size_t bytes, int device, int* out) {
     size_t lds = prop.maxSharedMemoryPerMultiProcessor;
     if (lds < 160 * 1024) lds = 160 * 1024;
     int per_cu = (int)(lds / (bytes ? bytes : 1));
-    if (per_cu > 8) per_cu = 8;
+    if (per_cu > 4 * SNK_LB) per_cu = 4 * SNK_LB;        // (the step kernels' launch bounds: SNK_LB waves per SIMD)
     if (const char* w = getenv("SNK_WAVES_PER_CU")) {       // occupancy experiments only (fewer resident waves than fit)
         const int v = atoi(w);
         if (v >= 1 && v < per_cu) per_cu = v;
