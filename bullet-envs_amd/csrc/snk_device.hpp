@@ -1636,7 +1636,15 @@ __device__ __forceinline__ void substep_v1(LT& L, const DevModel& M, int lane, f
             }
     }
     // only when this substep can be the last of its env-step (sensor_pass_needed)
-    if (sensor_pass_needed(L, M, lane, dv, hint)) {
+    const bool sensor = sensor_pass_needed(L, M, lane, dv, hint);
+    // delta-v crosses the sensor pass in LDS, not in a register (the pass is full of lane-dependent regions,
+    // and a copy or a reload the allocator places inside one moves the active lanes only -- snk_pgs_v2.hpp has the
+    // story; the register-resident substep's pass is a function of its own, here the value is parked): the solve is
+    // over, so the non-contact rows' rhs column is free (the pass reads their joint, sign and impulse only)
+    constexpr int kPark = 2 * N;        // = NL of this image (LdsCommon<N, 2 N>): 64 lanes for 32 links, 32 for 16
+    static_assert(kPark >= N + 6 + (N <= 16 ? 6 : 0), "every lane with a velocity component has a slot");
+    if (lane < kPark) L.nc_rhs[lane] = dv;
+    if (sensor) {
         // (6) constraint pass for the joint-0 sensor [U]: ABA at the velocities after (3) with the
         // constraint forces as the only link forces, joint torques still applied
         if (lane <= N) {
@@ -1731,6 +1739,7 @@ __device__ __forceinline__ void substep_v1(LT& L, const DevModel& M, int lane, f
         }
     }
     // (7) apply the solver's delta-v (clamped), motor torques, integrate positions
+    dv = lane < kPark ? L.nc_rhs[lane] : 0.f;
     if (lane < 6) {
         float x = L.base()[7 + lane] + dv;
         L.base()[7 + lane] = fminf(fmaxf(x, -M.max_vel), M.max_vel);
