@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get("SNK_LIB") or os.path.join(_HERE, "libsnk.so")
 class SnkParams(C.Structure):
     """Mirror of `snk_params` (include/snk.h)."""
     _fields_ = [
+        ("struct_size", C.c_uint32), ("abi_version", C.c_uint32),
         ("n_modules", C.c_int32), ("inertia_from_file", C.c_int32),
         ("default_mass", C.c_double), ("collision_margin", C.c_double),
         ("hull_sides", C.c_int32), ("contact_model", C.c_int32),

@@ -200,6 +200,8 @@ const char* snk_last_error(void) { return g_err.c_str(); }
 
 void snk_default_params(snk_params* p) {
     memset(p, 0, sizeof(*p));
+    p->struct_size = (uint32_t)sizeof(snk_params);
+    p->abi_version = SNK_ABI_VERSION;
     p->n_modules = 16;
     p->inertia_from_file = 0;
     p->default_mass = 1.0;
@@ -395,6 +397,13 @@ int snk_create(const snk_params* p, int32_t n_envs, int32_t device, snk_handle**
     if (!p || !out) return fail("snk_create: null argument");
     if (n_envs <= 0) return fail("snk_create: n_envs must be positive");
     if (n_envs >= (1 << 24)) return fail("snk_create: n_envs must be below 2^24 (the step queue packs the env index into 24 bits)");
+    if (p->struct_size != (uint32_t)sizeof(snk_params) || p->abi_version != SNK_ABI_VERSION) {
+        static char msg[256];
+        snprintf(msg, sizeof(msg), "snk_create: snk_params layout mismatch: the caller's struct is %u bytes, ABI version %u; this "
+                 "library's is %zu bytes, version %d (fill the struct with snk_default_params of THIS library's header)",
+                 p->struct_size, p->abi_version, sizeof(snk_params), SNK_ABI_VERSION);
+        return fail(msg);
+    }
     if (p->n_modules != 16 && p->n_modules != 32) return fail("snk_create: n_modules must be 16 or 32");
     if (p->hull_sides != 0 && (p->hull_sides < 3 || p->hull_sides > 32))
         return fail("snk_create: hull_sides must be 0 (implicit cylinder) or 3 .. 32");

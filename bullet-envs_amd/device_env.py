@@ -165,7 +165,7 @@ class ShardedVecEnv(object):
             a = t.as_tensor(actions, dtype=t.float32)       # shares memory with a float32 ndarray / tensor
             a2 = a[:, :, 0] if (a.dim() == 3 and a.shape[2] == 1) else a
             assert tuple(a2.shape) == (self.num_envs, self.A), a2.shape
-            self._act_all.copy_(a2)
+            self._act_all.copy_(a2, non_blocking=True)      # (asynchronous only from pinned host memory / the device)
             chunks = list(self._act_all.split(self.E, dim=0))
         else:
             a2 = None

@@ -22,7 +22,14 @@ extern "C" {
 
 /* Every knob the reference path depends on.  [U] = PyBullet/Bullet default taken from
  * knowledge of bullet3 (not verifiable here). */
+#define SNK_ABI_VERSION 6       /* bumped whenever snk_params' layout or an entry point's meaning changes */
+
 typedef struct snk_params {
+    /* layout guard (round 6): snk_default_params fills both, snk_create refuses a struct whose size or
+       version is not this library's -- a caller compiled against another header gets an error message, not garbage
+       parameters.  New fields are appended at the END of the struct from here on. */
+    uint32_t struct_size;       /* sizeof(snk_params) of the header the caller was compiled against */
+    uint32_t abi_version;       /* SNK_ABI_VERSION of that header                                    */
     /* model: snake/snake.urdf (constants generated parametrically, not parsed) */
     int32_t n_modules;          /* 16 = snake.urdf; 32 = BASELINE config 4 (only these two)      */
     int32_t inertia_from_file;  /* 0: inertia from collision AABB [U] (snake.py:93 passes no

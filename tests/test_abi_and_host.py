@@ -46,14 +46,23 @@ def test_default_params_mirror_reference(pkg):
 
 
 def test_params_struct_layout_matches_c(pkg):
-    """sizeof(snk_params) seen by ctypes equals the C compiler's (guards field drift)."""
-    src = '#include <stdio.h>\n#include "snk.h"\nint main(){printf("%zu", sizeof(snk_params));return 0;}\n'
+    """sizeof(snk_params) AND the offset of every field as ctypes sees them equal the C compiler's (a field
+    inserted in the middle shifts every later one without changing what a size check sees in the fields before it)."""
+    names = [n for n, _ in pkg.SnkParams._fields_]
+    src = ('#include <stdio.h>\n#include <stddef.h>\n#include "snk.h"\nint main(){printf("%zu %d", sizeof(snk_params), SNK_ABI_VERSION);\n'
+           + "".join('printf(" %%zu", offsetof(snk_params, %s));\n' % n for n in names) + "return 0;}\n")
     exe = os.path.join("/tmp", "snk_sizeof_%d" % os.getpid())
     subprocess.run(["gcc", "-x", "c", "-", "-I", os.path.join(ROOT, "include"), "-o", exe],
                    input=src.encode(), check=True)
-    size = int(subprocess.check_output([exe]))
+    out = [int(x) for x in subprocess.check_output([exe]).split()]
     os.remove(exe)
-    assert ctypes.sizeof(pkg.SnkParams) == size
+    assert ctypes.sizeof(pkg.SnkParams) == out[0]
+    for n, off in zip(names, out[2:]):
+        assert getattr(pkg.SnkParams, n).offset == off, (n, getattr(pkg.SnkParams, n).offset, off)
+    assert names[:2] == ["struct_size", "abi_version"]
+    # snk_default_params stamps the struct with this library's size and version (snk_create refuses anything else)
+    p = pkg.default_params()
+    assert p.struct_size == out[0] and p.abi_version == out[1]
 
 
 def test_oracle_and_product_defaults_agree(pkg, oracle_mod):
@@ -61,6 +70,8 @@ def test_oracle_and_product_defaults_agree(pkg, oracle_mod):
     for name, _ in pkg.SnkParams._fields_:
         if name.startswith("reserved"):
             assert getattr(a, name) == 0
+            continue
+        if name in ("struct_size", "abi_version"):      # the C ABI's layout guard: the oracle has its own struct
             continue
         va, vb = getattr(a, name), getattr(b, name)
         if name in ("aniso", "obstacle_pos", "obstacle_half"):
@@ -196,3 +207,48 @@ def test_bench_plain_multi_gpu_invocation_refuses_cleanly_without_the_gpus():
                          cwd=root, env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode != 0 and out.stdout.strip() == ""
     assert "--gpus 2 but this node shows" in out.stderr
+
+
+def test_subproc_vec_env_refuses_thunks_that_differ(pkg):
+    """The reference forks one process per thunk and honours each one's own settings (ppo/multiprocessing_env.py:106-111);
+    one GPU handle runs ONE parameter set, so thunks that differ are refused -- naming the thunk and the first differing
+    field -- instead of being replaced silently by the first.  No device needed: the refusal comes
+    before the handle is created; the stand-ins carry what a bullet-envs_amd SnakeGymEnv carries (params, mode, close)."""
+    from importlib import import_module
+    _lib = import_module("bullet-envs_amd._lib")
+    closed = []
+
+    class Proto(object):
+        def __init__(self, mode="train", **over):
+            self.params = _lib.default_params(**over)
+            self.mode = mode
+
+        def close(self):
+            closed.append(self)
+
+    def thunk(**kw):
+        return lambda: Proto(**kw)
+
+    with pytest.raises(ValueError, match=r"env_fns\[3\] differs from env_fns\[0\] in `gait` \(0 vs 1\)"):
+        pkg.SubprocVecEnv([thunk(), thunk(), thunk(), thunk(gait=0)])
+    assert len(closed) == 4                       # every probed thunk's env was closed again
+    with pytest.raises(ValueError, match=r"env_fns\[1\] differs from env_fns\[0\] in `alpha`"):
+        pkg.SubprocVecEnv([thunk(), pkg.CloudpickleWrapper(thunk(alpha=2.0)), thunk()])
+    with pytest.raises(ValueError, match=r"env_fns\[1\] differs from env_fns\[0\] in `aniso`"):
+        pkg.SubprocVecEnv([thunk(), thunk(aniso=[1.0, 0.1, 0.02])])
+    with pytest.raises(ValueError, match=r"in `mode` \('test' vs 'train'\)"):
+        pkg.SubprocVecEnv([thunk(), thunk(mode="test")])
+    # many thunks: the first, the last and evenly spaced ones in between are probed -- a different LAST one is caught
+    closed.clear()
+    with pytest.raises(ValueError, match=r"env_fns\[299\] differs from env_fns\[0\] in `beta`"):
+        pkg.SubprocVecEnv([thunk()] * 299 + [thunk(beta=0.5)])
+    assert len(closed) <= pkg.SubprocVecEnv.kHeteroProbe + 2
+    with pytest.raises(TypeError, match="must build bullet-envs_amd SnakeGymEnv objects"):
+        pkg.SubprocVecEnv([lambda: object()])
+    with pytest.raises(ValueError, match="no env_fns"):
+        pkg.SubprocVecEnv([])
+    # identical thunks pass the guard and reach the handle's creation: without a GPU that fails loudly (no fallback)
+    import torch
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError):
+            pkg.SubprocVecEnv([thunk(), thunk()])

@@ -145,3 +145,46 @@ def test_checkpoint_restores_default_friction_too(pkg, tmp_path):
     got = b_env.step(gait_actions(np.arange(n), 1).astype(np.float32))
     assert np.array_equal(ref[0], got[0]) and np.array_equal(ref[1], got[1])
     a_env.close(); b_env.close()
+
+
+def test_checkpoint_parameters_travel_field_by_field(pkg, tmp_path):
+    """checkpoints stored the raw bytes of snk_params, so a field added to the struct made every older
+    checkpoint unreadable with a misleading message.  Format 2 stores the parameters by name: a field the writing
+    build did not have yet counts as that field's default, a changed value is named, a format-1 file whose bytes no
+    longer fit says LAYOUT, not 'different parameters'.  No device needed."""
+    import json
+    from importlib import import_module
+    _lib = import_module("bullet-envs_amd._lib")
+    ck = import_module("bullet-envs_amd.checkpoint")
+
+    class St(object):
+        def __init__(self, **over):
+            self.params = _lib.default_params(**over)
+            self.n_envs = 4
+
+    def write(name, fields=None, raw=None):
+        kw = {}
+        if fields is not None:
+            kw["params_json"] = np.frombuffer(json.dumps(fields).encode(), dtype=np.uint8)
+        if raw is not None:
+            kw["params"] = np.frombuffer(raw, dtype=np.uint8)
+        path = str(tmp_path / name)
+        np.savez(path, **kw)
+        return np.load(path + ".npz")
+
+    base = ck._params_fields(_lib.default_params())
+    assert "struct_size" not in base and base["max_motor_impulse"] == float("inf")
+    ck._check_params(write("same", base), St())
+    older = dict(base)
+    del older["friction_directions"]                   # a checkpoint of a build that did not have the field yet
+    ck._check_params(write("older", older), St())
+    with pytest.raises(ValueError, match=r"`friction_directions` is 2 there \(absent: that build's default\), 1 in this handle"):
+        ck._check_params(write("older2", older), St(friction_directions=1))
+    with pytest.raises(ValueError, match=r"`kp` is 0.1 there, 0.2 in this handle"):
+        ck._check_params(write("kp", base), St(kp=0.2))
+    with pytest.raises(ValueError, match="does not know: no_such_field"):
+        ck._check_params(write("newer", dict(base, no_such_field=1)), St())
+    # format 1: identical bytes still load, anything else is reported as what it is
+    ck._check_params(write("f1", raw=bytes(_lib.default_params())), St())
+    with pytest.raises(ValueError, match="LAYOUT mismatch"):
+        ck._check_params(write("f1old", raw=bytes(_lib.default_params())[8:]), St())
