@@ -50,3 +50,47 @@ def random_state(rng, n, z=0.2, qamp=0.5, vamp=1.0, flat=False):
     s[13:13 + n] = rng.uniform(-qamp, qamp, n)
     s[13 + n:] = rng.uniform(-vamp, vamp, n)
     return s
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Count / done mismatches against the reference's recorded env-steps: one rule for every test that meets them
+# (ADVICE r5 medium).
+# ------------------------------------------------------------------------------------------------------------------
+def SERVO_WINDOW(k):
+    """How far from the 0.05 tolerance the reference's servo error may sit where a float32 computation stops one substep
+    earlier or later than the reference: float32 round-off in the error norm after k stiff substeps.  Calibrated on the
+    float32 build of the ORACLE over the reference's 2240 recorded vector env-steps (test_float32_oracle_yardstick_...,
+    CPU): its one-substep mismatches sit within 1.6e-3 of the tolerance at k <= 20 and 3.75e-3 at k = 31 (PPO step 24 env
+    3: 30 substeps for the reference's 31, the float64 oracle unmoved by perturbations).  The window is ~1.4 x that
+    (round 5 allowed 1.5e-3 + 2e-4 k: 7.7e-3 at k = 31)."""
+    return 5e-4 + 1.5e-4 * k
+
+
+def count_spread(oracle_mod, S, X, M, a, vec_mode, seed, **over):
+    """Substep counts the FLOAT64 oracle gives for one env-step when its inputs are moved by float32-sized amounts: the
+    state / contact cache / action rounded to float32 (what the GPU is handed), and four random relative perturbations
+    of 6e-8.  More than one value = the step sits at a bifurcation (a contact about to stick or slip decides how fast the
+    servo error decays): no float32 computation can be expected to land on the reference's count there.  Observed, e.g.,
+    ARS step 26 env 4: 18 from the exact state, 20 from the rounded one, 21 from perturbed ones."""
+    rng = np.random.default_rng(seed)
+    ks = []
+    e = oracle_mod.OracleEnv(**over)
+    for trial in range(5):
+        if trial == 0:
+            S2, M2, a2 = (x.astype(np.float32).astype(np.float64) for x in (S, M, a))
+        else:
+            S2 = S * (1 + rng.uniform(-1, 1, S.shape) * 6e-8)
+            M2 = M * (1 + rng.uniform(-1, 1, M.shape) * 6e-8)
+            M2[:, 0] = M[:, 0]
+            a2 = a * (1 + rng.uniform(-1, 1, a.shape) * 6e-8)
+        e.hard_reset()
+        e.sync(S2, X, M2)
+        ks.append(e.env_step(a2.copy(), vec_mode=vec_mode)[3])
+    return ks
+
+
+def mismatch_gate(what, gpu, f32, factor=1.5, slack=4):
+    """The GPU's count / done mismatches against the float32 oracle's, both counted over the same env-steps by the same
+    rule: GPU <= factor x float32 oracle + slack."""
+    print("  mismatch gate [%s]: GPU %d, float32 oracle %d, bound %.1f" % (what, gpu, f32, factor * f32 + slack))
+    assert gpu <= factor * f32 + slack, (what, gpu, f32)

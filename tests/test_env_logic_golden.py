@@ -106,6 +106,9 @@ def test_oracle_substeps_reproduce_the_test_mode_telemetry(vec, oracle_mod):
             assert np.abs(lp - v["link_positions"][t, s]).max() < 1e-12
 
 
+from conftest import SERVO_WINDOW, count_spread, mismatch_gate      # noqa: E402
+
+
 # ------------------------------------------------------------------------------------------------------------------
 @pytest.mark.gpu
 def test_gpu_env_step_reproduces_the_reference(vec, pkg, oracle_mod):
@@ -135,31 +138,38 @@ def test_gpu_env_step_reproduces_the_reference(vec, pkg, oracle_mod):
         e32 = oracle_mod.OracleEnv(f32=True, **over)
         for b, i in enumerate(rows):
             k_ref, d_ref, o_ref, r_ref = int(v["substeps"][i]), bool(v["done"][i]), v["obs"][i], float(v["reward"][i])
+            # calibration FIRST, on every row: the float32 build of the oracle on the same step (round 5 ran it only where
+            # the GPU had matched, so its mismatch count -- 2 -- was a conditional remainder; counted over every row it is
+            # 10 of 161: VERDICT r5 weak 1-ii)
+            e32.hard_reset()
+            e32.sync(v["state"][i], v["aux"][i], v["manifold"][i])
+            o32, r32, d32, k32, _ = e32.env_step(v["action_in"][i, :A].copy(), vec_mode=bool(vec_mode))
+            m32 = k32 != k_ref or d32 != d_ref
+            mism32 += m32
             if sub[b] != k_ref or bool(done[b]) != d_ref:
                 # Legitimate only AT a decision boundary: the loop stops at the first servo error <= 0.05 (snake.py:228-235),
                 # and the vectors hold the error the reference saw after every substep.  One substep fewer than the
-                # reference: the reference's error after that substep was within a few 1e-3 above the tolerance; one more:
-                # its last error as close below.  (The bench gait ends a quarter of its env-steps that close to the
-                # tolerance; float32 round-off in q -- up to 1e-3 after thirty substeps -- decides those.)
+                # reference: the reference's error after that substep was within float32 round-off above the tolerance
+                # (conftest.SERVO_WINDOW, calibrated on the float32 oracle); one more: its last error as close below.  (The
+                # bench gait ends a quarter of its env-steps that close to the tolerance.)  Or the step is a bifurcation:
+                # the float64 oracle's own count moves under float32-sized perturbations (conftest.count_spread).
                 mism += 1
                 kg = int(sub[b])
-                assert abs(kg - k_ref) <= 1, (i, kg, k_ref, done[b], d_ref)
-                e_dec = float(v["servo_err"][i, min(kg, k_ref) - 1])      # the error where the two part ways
-                # (float32 round-off in the servo error grows with the substeps behind it: 4e-4 at 15, 3e-3 at 33 observed)
-                near = abs(e_dec - 0.05) < 1.5e-3 + 2e-4 * k_ref or abs(abs(o_ref[9]) - 0.5) < 1e-3
-                print("  boundary mismatch: row %d scenario %d: substeps %d / %d, done %s / %s, servo error there %.5f"
-                      % (i, v["scenario"][i], kg, k_ref, bool(done[b]), d_ref, e_dec))
-                assert near, (i, kg, k_ref, e_dec)
+                e_dec = float(v["servo_err"][i, min(kg, k_ref) - 1]) if abs(kg - k_ref) <= 1 else 1.0
+                near = (abs(kg - k_ref) <= 1 and abs(e_dec - 0.05) < SERVO_WINDOW(k_ref)) or abs(abs(o_ref[9]) - 0.5) < 1e-3
+                print("  boundary mismatch: row %d scenario %d: substeps %d / %d (float32 oracle %d), done %s / %s, servo error "
+                      "there %.5f" % (i, v["scenario"][i], kg, k_ref, k32, bool(done[b]), d_ref, e_dec))
+                if not near:
+                    ks = count_spread(oracle_mod, v["state"][i], v["aux"][i], v["manifold"][i], v["action_in"][i, :A].copy(),
+                                      bool(vec_mode), i, **over)
+                    print("    a bifurcation? the float64 oracle under float32-sized perturbations: %s" % ks)
+                    assert len(set(ks + [k_ref])) > 1 and min(ks + [k_ref]) - 1 <= kg <= max(ks + [k_ref]) + 1, (i, kg, k_ref, e_dec, ks)
                 continue
             compared += 1
             if d_ref and vec_mode:
                 # the worker's reset(): the post-reset observation -- zeros, unit quaternion, the stale caches
                 assert np.all(obs[b, :2 * N] == 0) and np.all(obs[b, 3 * N:3 * N + 3] == 0)
                 assert np.all(obs[b, 3 * N + 3:3 * N + 7] == [0, 0, 0, 1])
-            # calibration: the float32 build of the oracle on the same step
-            e32.hard_reset()
-            e32.sync(v["state"][i], v["aux"][i], v["manifold"][i])
-            o32, r32, d32, k32, _ = e32.env_step(v["action_in"][i, :A].copy(), vec_mode=bool(vec_mode))
             if "max_motor_impulse" in over:
                 # 41 substeps of saturated motors against sticking contacts: float32 round-off grows to 1e-1 (the float32
                 # ORACLE's own distance is the yardstick, as in tests/test_gpu_env.py::test_env_logic_branches); what these
@@ -173,19 +183,19 @@ def test_gpu_env_step_reproduces_the_reference(vec, pkg, oracle_mod):
             # _observation for the next step (SnakeGymEnv.py:41-42, multiprocessing_env.py:14-15): the x of the observation
             # this step RETURNED -- the terminal one in the single-env seam, the reset one (0) behind the worker
             assert X1[b, N + 1] == obs[b, 3 * N] and (obs[b, 3 * N] == 0.0 or not (d_ref and vec_mode)), (i, X1[b, N + 1])
-            if k32 != k_ref or d32 != d_ref:
-                mism32 += 1
-            if k32 == k_ref and d32 == d_ref:
+            if not m32:
                 cal["q"] = max(cal["q"], np.abs(o32[:N] - o_ref[:N]).max(), np.abs(o32[3 * N:3 * N + 7] - o_ref[3 * N:3 * N + 7]).max())
                 cal["qd"].append((np.abs(o32[N:2 * N] - o_ref[N:2 * N]) / (1 + np.abs(o_ref[N:2 * N]))).max())
                 cal["r"] = max(cal["r"], abs(r32 - r_ref))
     p90, p90c = float(np.percentile(worst["qd"], 90)), float(np.percentile(cal["qd"], 90))
     print("GPU vs the reference's own env logic (%d env-steps compared, %d boundary mismatches): worst q/pose %.2e reward %.2e "
           "qd p90 %.2e | float32 oracle: %.2e %.2e %.2e" % (compared, mism, worst["q"], worst["r"], p90, cal["q"], cal["r"], p90c))
-    print("  (the float32 oracle's own boundary mismatches among the compared rows: %d)" % mism32)
-    # every mismatch was checked to sit at a decision boundary above; their number stays in the float32 oracle's range
-    # (observed, round 5: 16 of 161, the float32 oracle's own 2 -- profiles/r05_accuracy_calibration.txt; + 4 of slack)
-    assert mism <= 20 and compared >= n_rows * 3 // 4
+    print("  (the float32 oracle's own count / done mismatches, every row evaluated: %d of %d)" % (mism32, n_rows))
+    # every mismatch was checked to sit at a decision boundary or a bifurcation above; their number is gated against the
+    # float32 oracle's, counted over every row (observed, round 5: GPU 16 of 161; the float32 oracle 10 -- not the 2 that
+    # round 5's conditional count gave)
+    mismatch_gate("env-logic golden", mism, mism32)
+    assert compared >= n_rows * 3 // 4
     # float32 sensitivity of one env-step (DESIGN.md 3 states the tolerance): within 1.5 x the float32 oracle's own
     # distance from the reference on the same rows (observed 1.00 x for angles / pose: 1.20e-2 both; 1.13 x for the
     # reward; 1.25 x for the velocities' 90th percentile), with a hard outer cap next to it
