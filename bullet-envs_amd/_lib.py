@@ -41,6 +41,7 @@ class SnkParams(C.Structure):
         ("term_angle", C.c_double), ("term_index", C.c_int32),
         ("collision_force", C.c_double), ("collision_penalty", C.c_double),
         ("done_penalty", C.c_double),
+        ("contact_order", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 

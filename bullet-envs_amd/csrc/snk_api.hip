@@ -251,6 +251,8 @@ void snk_default_params(snk_params* p) {
     p->collision_force = 10.0;
     p->collision_penalty = -10.0;
     p->done_penalty = -5.0;
+    p->contact_order = 0;
+    p->reserved0 = 0;
 }
 
 int snk_destroy(snk_handle* h);
@@ -415,6 +417,9 @@ int snk_create(const snk_params* p, int32_t n_envs, int32_t device, snk_handle**
     if (p->obstacle == 2 && !(p->obstacle_mass > 0.0)) return fail("snk_create: obstacle_mass must be positive");
     if (p->warm_start != 0 && p->warm_start != 1) return fail("snk_create: warm_start must be 0 or 1");
     if (p->friction_directions != 1 && p->friction_directions != 2) return fail("snk_create: friction_directions must be 1 or 2");
+    if (p->contact_order < 0) return fail("snk_create: contact_order must be 0 (link order), 1 (reversed) or k >= 2 (a fixed permutation)");
+    if (p->contact_order != 0 && p->contact_model != 1)
+        return fail("snk_create: contact_order needs contact_model 1 (it orders the persistent ground manifolds)");
     if (p->warm_start && p->contact_model != 1)
         return fail("snk_create: warm_start needs contact_model 1 (the impulses live in the persistent contact cache)");
     if (!(p->breaking_threshold > 0.0)) return fail("snk_create: breaking_threshold must be positive");

@@ -902,7 +902,12 @@ __device__ void build_rows_v1(LT& L, const DevModel& M, int lane, int nc, int& n
     const bool colv = d < kMO;                      // lanes that own a column of the records
     // Y of the body the sweep has reached: (Yt, Yf) = (al, a); zero on the lanes without a velocity component
     f3 Yt = al, Yf = a;                             // Y_0
-    const bool two_body = nc > L.nplane;            // link-link / obstacle contacts: any body, so every Y_k is kept
+    // link-link / obstacle contacts: any body, so every Y_k is kept.  And so it is when the ground contacts do not come in
+    // the order of their bodies (snk_params::contact_order): the forward sweep below cannot follow them then, they take their
+    // Y from the block like the two-body contacts (a switch of the error bar, not the default: the extra 32 KB of stores and
+    // loads per substep are its price)
+    const bool sorted = M.contact_order == 0;
+    const bool two_body = nc > L.nplane || !sorted;
     float* const Yb = rows + LT::kYOff;
     auto storeY = [&](int k) {
         if (two_body && colv) {
@@ -1021,7 +1026,7 @@ __device__ void build_rows_v1(LT& L, const DevModel& M, int lane, int nc, int& n
             while (kcur < kA) advance();
             assemble(ci, G, Yt, Yf, z3, z3, kA, -1, std::false_type{});
         };
-        if (nplane > 0) {
+        if (nplane > 0 && sorted) {
             Geo ga = load_geo(0);                                       // two records in flight, no copies between them
             for (int ci = 0; ci < nplane; ci += 2) {
                 const Geo gb = load_geo(ci + 1 < nplane ? ci + 1 : ci);
@@ -1049,7 +1054,7 @@ __device__ void build_rows_v1(LT& L, const DevModel& M, int lane, int nc, int& n
         }
         own_stores_visible();
         lds_sync();
-        for (int ci = nplane; ci < nc; ci++) {
+        for (int ci = sorted ? nplane : 0; ci < nc; ci++) {
             const Geo G = load_geo(ci);
             const int kA = __builtin_amdgcn_readfirstlane((int)G.g[4].x), kB = __builtin_amdgcn_readfirstlane((int)G.g[4].y);
             auto ldY = [&](int k, f3& yt, f3& yf) {

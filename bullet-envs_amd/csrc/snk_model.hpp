@@ -61,6 +61,10 @@ struct DevModel {
     int hist;                            // snk_contact_histogram_enable: count every substep's contact points (one atomic each)
     float warm_factor;
     float fricB;                         // snk_params::friction_directions: 1.0 (two tangents), 0.0 (the second tangent gets no row)
+    // snk_params::contact_order: the ground manifolds' place in the solver's sweep.  cyl_rank[c] = position of cylinder c,
+    // cyl_at[r] = the cylinder at position r (identity for contact_order 0)
+    int contact_order;
+    unsigned char cyl_rank[kMaxCyl], cyl_at[kMaxCyl];
     int obstacle;                        // a static box on the ground (snake/block.urdf), contacts through the streamed-row solve
     float obs_c[3], obs_h[3], mu_obs;    // its centre, half extents, lateral friction
     // obstacle 2 (a free body): mass, inverse inertia diagonal in box axes, breaking threshold of its manifold with the plane
@@ -272,6 +276,31 @@ inline void build_dev_model(const snk_params& P, const HostModel& H, DevModel& D
     //  friction rows go through the box-bounded loop, which skips a row while its contact carries no normal impulse)
     D.cone = (P.cone_friction && P.friction_directions == 2) ? 1 : 0;
     D.fricB = P.friction_directions == 1 ? 0.0f : 1.0f;
+    D.contact_order = P.contact_order;
+    {
+        // The oracle's rule (oracle/snake_oracle.cpp: find_contacts): 1 = reversed; k >= 2 = the cylinder links sorted by
+        // a splitmix-style hash of (k, link).  `link` is the index of the cylinder's link in the unmerged URDF tree with the
+        // root at 0 -- INPUT_INTERFACE_k = 3 k - 1, OUTPUT_BODY_k = 3 k + 1 -- so that both sides sort the same keys.
+        const int nc2 = 2 * n;
+        unsigned long long key[kMaxCyl];
+        for (int c = 0; c < nc2; c++) {
+            const int link = (c & 1) ? 3 * (c + 1) / 2 + 1 : 3 * c / 2 + 2;
+            if (P.contact_order == 0) key[c] = (unsigned long long)c;
+            else if (P.contact_order == 1) key[c] = (unsigned long long)(nc2 - 1 - c);
+            else {
+                unsigned long long z = (unsigned long long)P.contact_order * 0x9E3779B97F4A7C15ull + (unsigned long long)(link + 1) * 0xBF58476D1CE4E5B9ull;
+                z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 27; z *= 0x94D049BB133111EBull; z ^= z >> 31;
+                key[c] = z;
+            }
+        }
+        for (int c = 0; c < kMaxCyl; c++) { D.cyl_rank[c] = (unsigned char)c; D.cyl_at[c] = (unsigned char)c; }
+        for (int c = 0; c < nc2; c++) {
+            int r = 0;
+            for (int o = 0; o < nc2; o++) r += (key[o] < key[c] || (key[o] == key[c] && o < c)) ? 1 : 0;
+            D.cyl_rank[c] = (unsigned char)r;
+            D.cyl_at[r] = (unsigned char)c;
+        }
+    }
     D.scaling = (float)P.scaling_factor; D.servo_tol = (float)P.servo_tol;
     D.height_thr = (float)P.height_threshold; D.energy_dt = (float)P.energy_dt;
     D.alpha = (float)P.alpha; D.beta = (float)P.beta; D.gamma = (float)P.gamma;

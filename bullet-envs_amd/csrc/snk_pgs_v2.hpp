@@ -378,6 +378,20 @@ __device__ __forceinline__ int lane_prefix3(int cnt, int lane, int& total) {
     return __popcll(b0 & below) + 2 * __popcll(b1 & below) + 4 * __popcll(b2 & below);
 }
 
+// Where cylinder `lane`'s points start in the compact contact list: the exclusive prefix of the kept counts in the ORDER THE
+// SOLVER SWEEPS THE MANIFOLDS (snk_params::contact_order; 0 = cylinder = link order, the prefix over the lanes as they are).
+// Otherwise position r fetches the count of the cylinder that sits there (DevModel::cyl_at), the prefix runs over
+// positions, and every cylinder fetches its own from its position (cyl_rank): two ds_bpermute per substep.
+// (wave-uniform branch: the model sits in constant memory)
+__device__ __forceinline__ int manifold_base(const DevModel& M, int ncyl, int kept, int lane, int& total) {
+    if (M.contact_order == 0) return lane_prefix3(kept, lane, total);
+    const int at = lane < ncyl ? (int)M.cyl_at[lane] : lane;
+    const int rk = lane < ncyl ? (int)M.cyl_rank[lane] : lane;
+    const int kept_r = __shfl(kept, at);
+    const int base_r = lane_prefix3(kept_r, lane, total);
+    return __shfl(base_r, rk);
+}
+
 // Contacts with the obstacle box for the register-resident solve (lane = cylinder, the two-tier GJK of
 // snk_selfcol.hpp): at most LT::kObs of them on this solve (a substep with more goes through the streamed-row solve,
 // like one with more ground points than slots: find_contacts_v2 returns -1), appended behind the ground contacts.  The narrow phase runs BEFORE the ground contacts are compacted, because the slots the
@@ -513,7 +527,7 @@ __device__ int find_contacts_v2(LT& L, const DevModel& M, int lane, unsigned lon
         const int mask = (1 << cnt) - 1;
         const int kept = cnt;
         int tk;
-        const int base = lane_prefix3(kept, lane, tk);
+        const int base = manifold_base(M, 2 * N, kept, lane, tk);
         if (lane < 2 * N) {
             L.cylbase[c] = (unsigned char)base;
             L.cyln[c] = (unsigned char)kept;
@@ -622,7 +636,7 @@ __device__ int find_contacts_manifold_v1(LT& L, const DevModel& M, int lane, flo
     const int mask = manifold_keep_mask(cnt, p, lane, total, room);
     const int kept = __popc(mask);
     int tk;
-    const int base = lane_prefix3(kept, lane, tk);
+    const int base = manifold_base(M, 2 * N, kept, lane, tk);
     if (total > room && lane == 0) {
         atomicAdd(ovf, 1ull);
         atomicAdd(ovf + 1, (unsigned long long)(total - tk));

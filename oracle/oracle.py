@@ -40,6 +40,7 @@ class OrcParams(C.Structure):
         ("term_angle", C.c_double), ("term_index", C.c_int32),
         ("collision_force", C.c_double), ("collision_penalty", C.c_double),
         ("done_penalty", C.c_double),
+        ("noncontact_order", C.c_int32), ("contact_order", C.c_int32),
     ]
 
 
@@ -100,6 +101,7 @@ def _load(f32=False):
         "orc_last_contacts_full": (C.c_int32, [vp, D, C.c_int32]),
         "orc_bench_gait": (C.c_double, [C.POINTER(OrcParams), C.c_int32, D, D, C.c_int32, C.c_int32, C.c_int32,
                                         C.POINTER(C.c_int64), D]),
+        "orc_quicksort_equal_keys": (None, [C.c_int32, I]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -119,6 +121,14 @@ def default_params(**over):
         else:
             setattr(p, k, v)
     return p
+
+
+def quicksort_equal_keys(n):
+    """The permutation btAlignedObjectArray::quickSort leaves on n equal keys (snake_oracle.cpp): out[k] = the original
+    index of the element at position k."""
+    out = (C.c_int32 * n)()
+    _load().orc_quicksort_equal_keys(n, out)
+    return list(out)
 
 
 def _dp(a):

@@ -28,6 +28,7 @@
 #include "snake_oracle.h"
 
 #include <chrono>
+#include <algorithm>
 #include <cmath>
 #include <condition_variable>
 #include <cstdlib>
@@ -1315,6 +1316,27 @@ void find_box_ground_contacts(orc_env* e) {
     }
 }
 
+/* btAlignedObjectArray<T>::quickSort as published in bullet3's LinearMath/btAlignedObjectArray.h [U], restated for an
+ * array whose keys are ALL EQUAL (CompareFunc(a, b) = a.key < b.key is always false):
+ *     quickSortInternal(lo, hi):  i = lo, j = hi, x = data[(lo + hi) / 2]
+ *         do { while (data[i] < x) i++;  while (x < data[j]) j--;  if (i <= j) { swap(i, j); i++; j--; } } while (i <= j);
+ *         if (lo < j) quickSortInternal(lo, j);   if (i < hi) quickSortInternal(i, hi);
+ * Neither inner loop ever advances, so a partition swaps (lo, hi), (lo + 1, hi - 1), ... until the indices cross --
+ * it reverses its range -- and recurses into the two halves.  out[k] = the original index of the element that ends
+ * at position k. */
+static void orc_qs_equal(int* d, int lo, int hi) {
+    int i = lo, j = hi;
+    do {
+        if (i <= j) { int t = d[i]; d[i] = d[j]; d[j] = t; i++; j--; }
+    } while (i <= j);
+    if (lo < j) orc_qs_equal(d, lo, j);
+    if (i < hi) orc_qs_equal(d, i, hi);
+}
+static void qs_equal_keys(int n, int* out) {
+    for (int k = 0; k < n; k++) out[k] = k;
+    if (n > 1) orc_qs_equal(out, 0, n - 1);
+}
+
 void find_contacts(orc_env* e) {
     if (e->P.contact_model == 1) find_contacts_manifold(e);
     else find_contacts_stateless(e);
@@ -1382,6 +1404,36 @@ void find_contacts(orc_env* e) {
         const size_t keep_ob = n_ob < cap ? n_ob : cap, keep_self = n_self < cap - keep_ob ? n_self : cap - keep_ob;
         e->contacts.erase(e->contacts.begin() + before + n_self + keep_ob, e->contacts.end());
         e->contacts.erase(e->contacts.begin() + before + keep_self, e->contacts.begin() + before + n_self);
+    }
+    if (e->P.contact_order != 0 && before > 1) {
+        /* [U] Bullet hands the solver the contact manifolds in the island manager's order (its own
+         * unstable sort over the dispatcher's list), not in link order.  That order is unknown here; what it is worth is
+         * priced by sweeping the GROUND manifolds (one per cylinder link: a run of equal `link` among the first
+         * `before` contacts, its <= 4 points kept together and in their own order) in other fixed orders:
+         * 1 = reversed, k >= 2 = the permutation of the links that sorting by a hash of (k, link) gives -- the same
+         * permutation in every substep, as a list of persistent manifold objects would keep it. */
+        std::vector<std::pair<unsigned long long, std::pair<size_t, size_t>>> runs;
+        for (size_t a0 = 0; a0 < before;) {
+            size_t a1 = a0;
+            while (a1 < before && e->contacts[a1].link == e->contacts[a0].link) a1++;
+            unsigned long long key;
+            if (e->P.contact_order == 1) key = ~(unsigned long long)a0;                 /* reversed */
+            else {
+                unsigned long long z = (unsigned long long)e->P.contact_order * 0x9E3779B97F4A7C15ull + (unsigned long long)(e->contacts[a0].link + 1) * 0xBF58476D1CE4E5B9ull;
+                z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 27; z *= 0x94D049BB133111EBull; z ^= z >> 31;
+                key = z;
+            }
+            runs.push_back(std::make_pair(key, std::make_pair(a0, a1)));
+            a0 = a1;
+        }
+        std::stable_sort(runs.begin(), runs.end(), [](const std::pair<unsigned long long, std::pair<size_t, size_t>>& x,
+                                                      const std::pair<unsigned long long, std::pair<size_t, size_t>>& y) { return x.first < y.first; });
+        std::vector<Contact> re;
+        re.reserve(e->contacts.size());
+        for (size_t r = 0; r < runs.size(); r++)
+            for (size_t i = runs[r].second.first; i < runs[r].second.second; i++) re.push_back(e->contacts[i]);
+        for (size_t i = before; i < e->contacts.size(); i++) re.push_back(e->contacts[i]);
+        e->contacts.swap(re);
     }
     if (e->P.obstacle == 2) find_box_ground_contacts(e);      /* row order: ground, link-link, link-box, box-ground */
 }
@@ -1511,7 +1563,7 @@ void substep(orc_env* e, const Real* targets) {
         row.applied = 0;
     };
     /* joint limit rows, only when violated (btMultiBodyJointLimitConstraint [U]) */
-    for (int j = 0; j < n; j++) {
+    auto limit_rows_of = [&](int j) {
         for (int side = 0; side < 2; side++) {
             Real pen = side == 0 ? e->q[j] - (Real)P.joint_lo : (Real)P.joint_hi - e->q[j];
             if (pen > 0) continue;
@@ -1528,9 +1580,9 @@ void substep(orc_env* e, const Real* targets) {
             row.lo = 0; row.hi = (Real)P.limit_max_impulse;
             noncontact.push_back(row);
         }
-    }
+    };
     /* motor rows (btMultiBodyJointMotor, PyBullet POSITION_CONTROL defaults [U]) */
-    for (int j = 0; j < n; j++) {
+    auto motor_row_of = [&](int j) {
         Row row;
         row.kind = 1; row.joint = j; row.contact = -1;
         row.J.assign(nd, 0); row.M.assign(nd, 0);
@@ -1544,6 +1596,25 @@ void substep(orc_env* e, const Real* targets) {
         Real mi = (Real)P.max_motor_impulse;
         row.lo = -mi; row.hi = mi;
         noncontact.push_back(row);
+    };
+    if (P.noncontact_order == 0) {
+        /* the violated limits by joint index, then the motors by joint index (rounds 1-5; what the kernels build) */
+        for (int j = 0; j < n; j++) limit_rows_of(j);
+        for (int j = 0; j < n; j++) motor_row_of(j);
+    } else {
+        /* [U] the order btMultiBodyDynamicsWorld::solveConstraints is read to hand the solver: the
+         * world's constraint list -- the n joint-limit constraints the URDF import creates, then the n motors
+         * createJointMotors adds -- COPIED and sorted by island id with btAlignedObjectArray::quickSort.  Every
+         * constraint of this world sits in the one island, and that quicksort (Hoare partition, pivot = the middle
+         * element, `i <= j` swap) is not stable: on equal keys each partition reverses its range and recurses into the
+         * halves, which leaves a fixed, non-identity permutation (orc_quicksort_equal_keys).  Rows are created in that
+         * order -- a limit constraint only when violated -- and swept alternately forward / backward as before. */
+        std::vector<int> order(2 * n);
+        qs_equal_keys(2 * n, order.data());
+        for (int k2 = 0; k2 < 2 * n; k2++) {
+            if (order[k2] < n) limit_rows_of(order[k2]);
+            else motor_row_of(order[k2] - n);
+        }
     }
     /* contact rows (btMultiBodyConstraintSolver::setupMultiBodyContactConstraint [U]) */
     int nc = (int)e->contacts.size();
@@ -1852,6 +1923,9 @@ void soft_reset(orc_env* e) {
 
 extern "C" {
 
+void orc_quicksort_equal_keys(int n, int* out) { qs_equal_keys(n, out); }
+
+
 void orc_default_params(orc_params* p) {
     memset(p, 0, sizeof(*p));
     p->n_modules = 16;
@@ -1907,6 +1981,8 @@ void orc_default_params(orc_params* p) {
     p->collision_force = 10.0;
     p->collision_penalty = -10.0;
     p->done_penalty = -5.0;
+    p->noncontact_order = 0;
+    p->contact_order = 0;
 }
 
 orc_env* orc_create(const orc_params* p) {

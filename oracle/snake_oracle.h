@@ -129,6 +129,13 @@ typedef struct orc_params {
     double  collision_force;  /* SnakeGymEnv.py:94  10                                   */
     double  collision_penalty;/* -10                                                     */
     double  done_penalty;     /* SnakeGymEnv.py:40  -5                                   */
+    /* row order (round 6): error-bar rows, oracle only */
+    int32_t noncontact_order; /* 0 (default): violated joint limits by joint index, then the motors by joint index.
+                               * 1 [U]: the order btMultiBodyDynamicsWorld::solveConstraints hands the solver -- the world's
+                               * list [limit_1..limit_n, motor_1..motor_n] after btAlignedObjectArray::quickSort on equal
+                               * island ids (not stable: a fixed non-identity permutation, orc_quicksort_equal_keys)    */
+    int32_t contact_order;    /* 0 (default): ground manifolds in link order.  1: reversed.  k >= 2: the fixed permutation
+                               * of the links a hash of (k, link) gives.  Bullet's island-manager order is unknown [U]  */
 } orc_params;
 
 typedef struct orc_env orc_env;

@@ -94,3 +94,26 @@ def mismatch_gate(what, gpu, f32, factor=1.5, slack=4):
     rule: GPU <= factor x float32 oracle + slack."""
     print("  mismatch gate [%s]: GPU %d, float32 oracle %d, bound %.1f" % (what, gpu, f32, factor * f32 + slack))
     assert gpu <= factor * f32 + slack, (what, gpu, f32)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The float32 tolerance, stated once (DESIGN.md 3) and applied through ONE function (VERDICT r5 item 3): a GPU figure
+# against the same figure of the oracle built in float32, both measured against the float64 oracle (or the reference's
+# recorded run) on the same inputs in the same run.
+#   factor   1.5  medians, and worst values over >= 30 samples of the 16-link chain
+#            2.0  90th percentiles, anything over < 30 samples, the 32-link chain
+#            a test that needs more says why where it calls this, and DESIGN.md 3's table lists it with the observed ratio
+#   floor    the value below which the figure is round-off of the comparison itself (max(floor, factor x float32))
+#   cap      the hard outer bound, whatever the float32 oracle does
+# Every call prints one "GATE" line (pytest -s): profiles/r06_accuracy_calibration.txt is those lines.
+# SNK_GATE_SOFT=1: print, do not assert (a calibration run).
+# ------------------------------------------------------------------------------------------------------------------
+def f32_gate(what, gpu, f32, factor=1.5, floor=0.0, cap=float("inf")):
+    gpu, f32 = float(gpu), float(f32)
+    limit = min(max(floor, factor * f32), cap)
+    ratio = gpu / f32 if f32 > 0 else float("inf") if gpu > 0 else 0.0
+    print("  GATE %-58s GPU %.3e | float32 oracle %.3e | ratio %5.2f | limit %.3e = min(max(%.1e, %.1f x), %.1e) %s"
+          % (what, gpu, f32, ratio, limit, floor, factor, cap, "" if gpu < limit else "<-- OVER"))
+    if not os.environ.get("SNK_GATE_SOFT"):
+        assert gpu < limit, (what, gpu, f32, limit)
+    return gpu < limit

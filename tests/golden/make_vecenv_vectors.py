@@ -3,7 +3,9 @@
     /root/reference/ppo/multiprocessing_env.py    SubprocVecEnv itself: 16 forked workers, Pipes, np.stack order (:97-153)
     /root/reference/ars/train.py                  ARS.__init__ (create_env / create_envs), ARS.train_one_epoch():
                                                   test_envs twice (:74-116: (16, 8, 1) actions, `total_reward += reward`
-                                                  on a list), update_weights
+                                                  on a list), update_weights; then ARS.train's evaluation call
+                                                  test_env(self.env, policy, self.weights, normalizer, eval_policy=True)
+                                                  on the trainer's single env (:43-71, :228: (8, 1) float64 actions)
     /root/reference/ppo/train.py                  train(args) for 40 frames: two 20-step rollouts (`envs.step(a)`,
                                                   `sum(reward)`, `1 - done`), compute_gae, ppo_update, and the policy
                                                   test at frame 40 (utils.test_env on the trainer's single env)
@@ -261,6 +263,60 @@ def run_ars(d):
     d["ars_act_space_shape"] = np.array(trainer.envs.action_space.shape)
     print("ARS: %d vector steps, %d dones, substeps %d..%d, reward lists of %d entries"
           % (T, int(d["ars_dones"].sum()), d["ars_substeps"].min(), d["ars_substeps"].max(), len(reward_p)))
+    # ---- the per-epoch evaluation on the trainer's SINGLE env (ars/train.py:228 -> :43-71), round 6:
+    # ARS.train's next two lines after train_one_epoch, called as they stand.  env.reset() (a soft reset), the observation
+    # plus np.random.random_sample noise, then <= 200 x SnakeGymEnv.step with the (8, 1) float64 column
+    # policy(normalizer.normalize(state), weights) -- checkBound indexing a 2-D array (SnakeGymEnv.py:82-88) --, the
+    # normaliser frozen (eval_policy=True).  Placed behind everything above so that no earlier array changes.
+    trainer.weights = new_w
+
+    def evaluate(prefix, weights, row0):
+        noise, passed = [], []
+        real_rs = np.random.random_sample
+
+        def rs_recorded(*a, **k):
+            out = real_rs(*a, **k)
+            noise.append(np.array(out, copy=True))
+            return out
+        real_step = trainer.env.step
+
+        def step_noting_the_callers_array(action):
+            before = np.array(action, copy=True)
+            out = real_step(action)
+            passed.append((before, np.array(action, copy=True), action.shape, str(action.dtype)))
+            return out
+        np.random.random_sample = rs_recorded
+        trainer.env.step = step_noting_the_callers_array
+        try:
+            test_reward, num_plays = ars.test_env(trainer.env, ars.policy, weights, normalizer=trainer.normalizer, eval_policy=True)
+        finally:
+            np.random.random_sample = real_rs
+            del trainer.env.step
+        ev = worker_records([os.getpid()])[0][row0:]
+        assert len(ev) == num_plays == len(passed) and len(noise) == 1
+        pack_records(ev, prefix, d)
+        d[prefix + "done"] = d.pop(prefix + "done_flag") != 0
+        assert all(sh == (8, 1) and dt == "float64" for _, _, sh, dt in passed)
+        d[prefix + "action_passed"] = np.stack([b for b, _, _, _ in passed])           # [T, 8, 1] as policy() returned them
+        d[prefix + "action_after"] = np.stack([a for _, a, _, _ in passed])            # the caller's array after step(): clipped in place
+        d[prefix + "noise"] = noise[0]                                                 # what was added to the reset observation
+        d[prefix + "weights"] = np.array(weights, copy=True)
+        d[prefix + "test_reward"] = np.float64(test_reward)
+        d[prefix + "num_plays"] = np.int32(num_plays)
+        # the normaliser did not move (eval_policy=True)
+        assert np.array_equal(trainer.normalizer.n, d["ars_norm_n"]) and np.array_equal(trainer.normalizer.mean, d["ars_norm_mean"])
+        print("ARS eval %s(test_env on the trainer's single env): %d env-steps, done %s, test_reward %.6f, substeps %s..., "
+              "|action| up to %.2f, %d components clipped"
+              % (prefix, num_plays, bool(d[prefix + "done"][-1]), test_reward, d[prefix + "substeps"].tolist()[:8],
+                 np.abs(d[prefix + "action_passed"]).max(), int((np.abs(d[prefix + "action_passed"]) > 1).sum())))
+        return len(ev)
+    # (1) the call as ARS.train makes it after the first epoch: weights one update away from zero, a near-idle snake --
+    #     0-substep steps, the 200-step cap, no episode end
+    n1 = evaluate("ars_eval_", trainer.weights, 0)
+    # (2) the same function with the weights a later epoch would bring (x 12: commands beyond +-1, so checkBound clips the
+    #     caller's (8, 1) array in place, the snake moves)
+    n2 = evaluate("ars_eval2_", 12.0 * trainer.weights, n1)
+    d["ars_eval_rows"] = np.int32(n1 + n2)
 
 
 def run_ppo(d):
@@ -292,7 +348,7 @@ def run_ppo(d):
     d["ppo_scalar_values"] = np.array([v for _, v, _ in sc])
     d["ppo_scalar_frames"] = np.array([f for _, _, f in sc], dtype=np.int32)
     # the trainer's own single env (ppo/train.py:93-94), driven by utils.test_env at frame 40: this process's records
-    ev = worker_records([os.getpid()])[0]
+    ev = worker_records([os.getpid()])[0][int(d["ars_eval_rows"]):]          # (this process's records start with ARS's evaluation)
     pack_records(ev, "ppo_eval_", d)
     d["ppo_eval_done"] = d.pop("ppo_eval_done_flag") != 0
     print("PPO: %d vector steps, %d dones, substeps %d..%d; scalars %s; eval env-steps %d"

@@ -18,6 +18,8 @@ import os
 import numpy as np
 import pytest
 
+from conftest import f32_gate      # noqa: E402
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
@@ -128,7 +130,13 @@ def test_gpu_client_runs_the_script_to_the_wall(vec, pkg, oracle_mod):
             gq = np.abs(s[0, 13:29] - r32[13:29]).max()
             print("after %3d steps: GPU vs the recorded run |dq| %.2e |d head| %.2e; float32 oracle vs the same %.2e %.2e; "
                   "GPU vs float32 oracle |dq| %.2e" % (k + 1, dq, dx, cq, cx, gq))
-            assert dq < 4 * cq + 1e-3 and dx < 4 * cx + 1e-3, (k, dq, cq, dx, cx)
+            # (one trajectory, one sample per check: 2 x)
+            # FREE-RUNNING from the script's start: after 120 steps of 10 ms the comparison is between three chaotic
+            # trajectories, not between roundings of one step (observed: 1.0 / 1.0 / 1.31 x in the joint angles, 1.0 / 1.0 /
+            # 2.34 x in the head position after 1 / 15 / 120 steps) -- 3 x from 100 steps on, said here and in DESIGN.md 3
+            fk = 2.0 if k < 100 else 3.0
+            f32_gate("gait-test script after %d steps: |dq| vs the recorded run" % (k + 1), dq, cq, fk, 1e-3)
+            f32_gate("gait-test script after %d steps: |d head|" % (k + 1), dx, cx, fk, 1e-3)
             assert k > 14 or gq < 1e-4, (k, gq)          # measured 4e-7 / 3e-6: the same arithmetic, the same rim
         if k % 100 == 99 and k < 1300:                                       # the crawl itself, sampled every 100 steps
             s, _ = p._stepper().get_state()

@@ -23,6 +23,8 @@ import os
 import numpy as np
 import pytest
 
+from conftest import f32_gate      # noqa: E402
+
 from conftest import ROUND1, random_state
 
 pytestmark = pytest.mark.gpu
@@ -36,6 +38,10 @@ SWITCHES = {
     "default+warm": dict(warm_start=1),
     "default+pyramid": dict(cone_friction=0),                            # two friction rows, box bounds, no implicit cone
     "default+1dir": dict(friction_directions=1),                         # no SOLVER_USE_2_FRICTION_DIRECTIONS: one row per contact
+    # the ORDER in which the solver sweeps the ground manifolds (round 6: the largest entry of the error bar, -20 % .. +4.5 %
+    # of forward motion in the oracle, profiles/r06_u_rows.json): link order reversed, and one fixed permutation
+    "default+reversed": dict(contact_order=1),
+    "default+perm3": dict(contact_order=3),
 }
 
 
@@ -84,7 +90,8 @@ def _ground_states(B, n=16, seed=0):
 
 
 @pytest.mark.parametrize("name,n", [("round1", 16), ("hull", 16), ("manifold", 16), ("hull+manifold@0.02", 16),
-                                    ("default", 16), ("default+warm", 16), ("default+warm", 32)])
+                                    ("default", 16), ("default+warm", 16), ("default+warm", 32),
+                                    ("default+reversed", 16), ("default+perm3", 16), ("default+reversed", 32), ("default+perm3", 32)])
 def test_substep_parity_under_contact_switch(pkg, oracle_mod, name, n):
     over = dict(SWITCHES[name], n_modules=n, self_collision=0)
     B, K = (48, 3) if n == 16 else (12, 3)
@@ -139,7 +146,8 @@ def test_substep_parity_under_contact_switch(pkg, oracle_mod, name, n):
     # (hard outer caps beside the calibrated bounds; the 32-link states of this test start with links deep in the ground:
     #  the float32 ORACLE is 6e-2 / 1.7 off the float64 one on them)
     cap_p, cap_v = (5e-3, 1.0) if n == 16 else (0.25, 5.0)
-    assert worst_p < min(max(5e-4, 3 * cal_p), cap_p) and worst_v < min(max(5e-2 if n == 16 else 0.2, 3 * cal_v), cap_v)
+    f32_gate("%s %d substep parity: worst pos of %d x 3" % (name, n, B), worst_p, cal_p, 2.0, 1e-4, cap_p)
+    f32_gate("%s %d substep parity: worst rel qd" % (name, n), worst_v, cal_v, 2.0, 1e-2 if n == 16 else 0.2, cap_v)
     if manifold:
         counts = st.get_manifold()[:, :, 0]
         assert counts.max() <= 4 and counts.sum() > 0
@@ -149,15 +157,17 @@ def test_substep_parity_under_contact_switch(pkg, oracle_mod, name, n):
     st.close()
 
 
-@pytest.mark.parametrize("n", [16, 32])
-def test_manifold_parity_from_gait_states(pkg, oracle_mod, n):
+@pytest.mark.parametrize("n,order", [(16, 0), (32, 0), (16, 3), (32, 3), (16, 1)])
+def test_manifold_parity_from_gait_states(pkg, oracle_mod, n, order):
     """Hull + persistent manifold from states the gait itself produces (a populated contact cache, the snake in
     motion on the ground), both chain lengths: state AND cache are handed to the oracle, then K substeps are compared.
-    The 32-link chain goes through the streamed-row solve."""
+    The 32-link chain goes through the streamed-row solve.  order: snk_params::contact_order (round 6) -- the solver sweeps
+    the manifolds in another order, the compact contact list, the couplings of consecutive normals, the sensor pass's way
+    from a body to its contacts and the impulses' way back into the cache all follow."""
     import bench
     B, K = (16, 3) if n == 16 else (8, 3)
     A = n // 2
-    over = dict(n_modules=n, self_collision=0)          # the defaults: hull + manifold + relative threshold
+    over = dict(n_modules=n, self_collision=0, contact_order=order)          # the defaults: hull + manifold + relative threshold
     st = pkg.Stepper(B, residual_threshold=0.0, **over)
     st.reset()
     ids = np.arange(B)
@@ -210,8 +220,29 @@ def test_manifold_parity_from_gait_states(pkg, oracle_mod, n):
     assert bad <= B // 4
     # states in motion include stick-slip ones that amplify float32 round-off: no worse than 3x the float32 oracle
     # (the velocity error is heavy-tailed and this is the maximum of two dozen samples: factor 5 on it)
-    assert worst_p < min(max(5e-4, 3 * cal_p), 5e-3) and worst_v < min(max(5e-2, 5 * cal_v), 1.0)
-    assert worst_f < min(max(0.05, 3 * cal_f), 0.5)
+    f32_gate("manifold from gait states n = %d order %d: worst pos of %d" % (n, order, B), worst_p, cal_p, 2.0, 1e-4, 5e-3)
+    f32_gate("manifold from gait states n = %d order %d: worst rel qd" % (n, order), worst_v, cal_v, 2.0, 1e-2, 1.0)
+    f32_gate("manifold from gait states n = %d order %d: sensor force" % (n, order), worst_f, cal_f, 2.0, 0.02, 0.5)
+    if order:
+        # ... and the order IS part of the answer: the same substeps swept in link order end elsewhere (oracle against
+        # oracle, float64) -- in the median over the environments hundreds of times farther than float32 round-off puts
+        # the GPU from the oracle under the SAME order (the maxima of both are stick-slip states: no yardstick)
+        moved, near = [], []
+        G, _ = st.get_state()
+        for i in range(B):
+            if not alive[i]:
+                continue
+            d = oracle_mod.OracleEnv(residual_threshold=0.0, max_contacts=0, **dict(over, contact_order=0))
+            d.set_state(S[i].astype(np.float64))
+            d.set_manifold(Mf[i].astype(np.float64))
+            for k in range(K):
+                d.substep(T[i].astype(np.float64))
+            a, b = d.get_state(), refs[i].get_state()
+            moved.append((np.abs(a[13 + n:] - b[13 + n:]) / (1 + np.abs(b[13 + n:]))).max())
+            near.append((np.abs(G[i, 13 + n:] - b[13 + n:]) / (1 + np.abs(b[13 + n:]))).max())
+        print("  contact_order %d against link order, oracle float64, after %d substeps: rel qd differs by %.3e in the median; the "
+              "GPU from the oracle under the same order: %.3e" % (order, K, np.median(moved), np.median(near)))
+        assert np.median(moved) > 50 * np.median(near) and np.median(moved) > 2e-3, (np.median(moved), np.median(near))
     st.close()
 
 
@@ -419,7 +450,8 @@ def test_env_steps_beyond_64_contacts_match_the_oracle(pkg, oracle_mod, monkeypa
                   "points cached at the end", st.get_manifold()[:, :, 0].sum(axis=1).max())
             assert st.contact_overflow()[0] > 0 and st.contact_overflow()[1] == 0
             assert st.get_manifold()[:, :, 0].sum(axis=1).max() > 64
-            assert worst < min(max(2e-3, 3 * cal), 2e-2) and mism <= B * J // 10
+            f32_gate("env-steps beyond 64 contacts: worst q / pose", worst, cal, 1.5, 1e-3, 2e-2)
+            assert mism <= B * J // 10
         st.close()
     monkeypatch.delenv("SNK_POISON")
     for other in (0, "poison"):
@@ -476,5 +508,6 @@ def test_thirty_two_links_at_rest_keep_every_point(pkg, oracle_mod):
     assert most > 6 * n and rows_most > 6 * n          # well past the 128 slots of the earlier builds
     assert st.contact_overflow() == (0, 0, 0)
     assert flips <= 170 * B // 8 and compared > 100 * B
-    assert worst < min(max(1e-3, 3 * cal), 1e-2)      # (one substep of a 250-contact, 32-link resting snake: float32 against float64)
+    # (one substep of a 250-contact, 32-link resting snake: float32 against float64)
+    f32_gate("32 links at rest, 250 contacts: worst one-substep difference", worst, cal, 2.0, 5e-4, 1e-2)
     st.close()

@@ -16,6 +16,8 @@ reaction force, which is impulse / dt: a 240x amplification of the solver's roun
 import numpy as np
 import pytest
 
+from conftest import f32_gate      # noqa: E402
+
 from conftest import ROUND1, random_state
 
 gpu = pytest.mark.gpu
@@ -103,8 +105,9 @@ def test_obstacle_env_step_parity(pkg, oracle_mod, n, model):
     print("obstacle parity n =", n, model, "GPU-f32", w, "| oracle-f32", c, "| boundary mismatches", mism, "| steps touching the box", touched)
     assert touched >= B - 2          # the case does exercise box / link-link contacts (a count along a chaotic trajectory)
     assert mism <= max(2, B * J // 10)
-    assert w["q"] < max(1e-3, 4 * c["q"]) and w["qd"] < max(5e-2, 4 * c["qd"])       # (maxima of ~40 chaotic samples)
-    assert w["r"] < max(5e-3, 3 * c["r"]) and w["f3"] < max(2.0, 3 * c["f3"])
+    # (maxima of ~40 chaotic samples; 32 links: 2 x anyway)
+    for key, fl in (("q", 5e-4), ("qd", 5e-2), ("r", 2e-3), ("f3", 2.0)):
+        f32_gate("obstacle parity n = %d %s: worst %s" % (n, model, key), w[key], c[key], 2.0, fl)
     st.close()
 
 
@@ -335,9 +338,8 @@ def test_free_box_env_step_parity(pkg, oracle_mod, world):
           touched, "| peak joint-3 reaction", peak, "| overflow", st.contact_overflow())
     assert touched >= B and compared >= B * J // 2
     assert mism <= max(2, B * J // 8, 2 * mism32)          # threshold decisions (servo tolerance, 41-substep cap)
-    assert w["q"] < max(1e-3, 4 * c["q"]) and w["qd"] < max(5e-2, 4 * c["qd"])
-    assert w["r"] < max(5e-3, 4 * c["r"]) and w["f3"] < max(2.0, 4 * c["f3"])
-    assert w["box"] < max(1e-5, 4 * c["box"])
+    for key, fl in (("q", 5e-4), ("qd", 5e-2), ("r", 2e-3), ("f3", 2.0), ("box", 1e-5)):
+        f32_gate("free box parity, %s: worst %s" % (world, key), w[key], c[key], 2.0, fl)
     assert peak > 20.0                                   # snake_gait_test.py:126: "The snake has hit the wall"
     st.close()
 

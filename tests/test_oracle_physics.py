@@ -235,3 +235,81 @@ def test_float_oracle_tracks_double(oracle_mod):
     b.substep(t)
     sa, sb = a.get_state(), b.get_state()
     assert np.allclose(sa, sb, atol=2e-3)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Row order (round 6): two [U] rules about the ORDER in which Bullet's solver meets its rows.
+# ------------------------------------------------------------------------------------------------------------------
+def test_quicksort_on_equal_keys_is_the_published_algorithm(oracle_mod):
+    """orc_quicksort_equal_keys against a line-by-line Python restatement of btAlignedObjectArray::quickSortInternal
+    (Hoare partition, pivot = the middle element, `i <= j` swap, recursion into [lo, j] and [i, hi]) run with a
+    comparator that is always false -- what sorting by island id is when every constraint sits in the one island."""
+    def qs(d, lo, hi, less):
+        i, j = lo, hi
+        x = d[(lo + hi) // 2]
+        while True:
+            while less(d[i], x):
+                i += 1
+            while less(x, d[j]):
+                j -= 1
+            if i <= j:
+                d[i], d[j] = d[j], d[i]
+                i += 1
+                j -= 1
+            if not i <= j:
+                break
+        if lo < j:
+            qs(d, lo, j, less)
+        if i < hi:
+            qs(d, i, hi, less)
+    for n in (1, 2, 3, 7, 32, 33, 64):
+        d = list(range(n))
+        if n > 1:
+            qs(d, 0, n - 1, lambda a, b: False)
+        assert oracle_mod.quicksort_equal_keys(n) == d, n
+    # the 16-link world's list [limit_1..16, motor_1..16]: the motors come out first, in this order, then the limits
+    p = oracle_mod.quicksort_equal_keys(32)
+    assert sorted(p) == list(range(32)) and p != list(range(32))
+    assert [x - 16 for x in p[:16]] == [5, 4, 7, 6, 1, 0, 3, 2, 13, 12, 15, 14, 9, 8, 11, 10]
+    assert p[16:] == [5, 4, 7, 6, 1, 0, 3, 2, 13, 12, 15, 14, 9, 8, 11, 10]
+
+
+def test_row_order_switches_keep_the_physics_and_change_the_numbers(oracle_mod):
+    """noncontact_order 1 / contact_order 1, 3: the same constraints in another order.  A snake at rest still carries its
+    weight (sum of normal impulses / dt = 21.296 x 9.8 N) whatever the order; the motor row still reaches its target in
+    free space; and a moving snake ends a substep elsewhere than under the default order -- the order is part of what 50
+    unconverged sweeps compute."""
+    import bench
+    n = 16
+    for over in (dict(noncontact_order=1), dict(contact_order=1), dict(contact_order=3), dict(noncontact_order=1, contact_order=4)):
+        e = oracle_mod.OracleEnv(residual_threshold=0.0, **over)
+        e.reset()
+        for _ in range(240):
+            e.substep(np.zeros(n))
+        lam = e.last_normal_impulses()
+        assert abs(lam.sum() / e.params.dt - 21.296 * 9.8) < 0.02 * 21.296 * 9.8, (over, lam.sum() / e.params.dt)
+        # the contacts come in the switch's order: runs of equal link, each link once
+        links = e.last_contacts_full()[:, 4].astype(int)
+        runs = [links[0]] + [b for a, b in zip(links[:-1], links[1:]) if a != b]
+        assert len(set(runs)) == len(runs)
+        if over.get("contact_order") == 1:
+            assert runs == sorted(runs, reverse=True)
+        elif over.get("contact_order"):
+            assert runs != sorted(runs) and runs != sorted(runs, reverse=True)
+        else:
+            assert runs == sorted(runs)
+        # a moving snake: two env-steps of the gait, then one substep under this order and under the default from the same state
+        a = oracle_mod.OracleEnv(residual_threshold=0.0, **over)
+        a.reset()
+        for j in range(2):
+            a.env_step(bench.gait_actions([0], j)[0], vec_mode=False)
+        S, M = a.get_state(), a.get_manifold()
+        T = np.zeros(n)
+        T[1::2] = bench.gait_actions([0], 2)[0] * (np.pi / 6)
+        b = oracle_mod.OracleEnv(residual_threshold=0.0)
+        b.set_state(S)
+        b.set_manifold(M)
+        a.substep(T)
+        b.substep(T)
+        diff = np.abs(a.get_state()[13 + n:] - b.get_state()[13 + n:]).max()
+        assert 1e-6 < diff < 1.0, (over, diff)

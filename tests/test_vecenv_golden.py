@@ -143,44 +143,55 @@ def test_oracle_reproduces_the_trainers_eval_env(vec, oracle_mod):
 
 
 # ------------------------------------------------------------------------------------------------------------------
-from conftest import count_spread as _count_spread, SERVO_WINDOW, mismatch_gate      # noqa: E402
+from conftest import count_spread as _count_spread, SERVO_WINDOW, f32_gate, mismatch_gate      # noqa: E402
 
 
-def _classify(v, t, oracle_mod, j, i, S, X, M, a_i, kg, dg, spread, done_index, hard, edist, note=""):
-    """'match' | 'bifurcation' | 'boundary' | 'other' for one side's (count, done) of env-step (j, i) against the reference's.
-    hard: a mismatch that is neither at a bifurcation nor at a servo / angle boundary fails the test (the GPU's); the
-    float32 oracle's are only counted.  spread: the cache of count_spread's result for this env-step (filled on demand)."""
-    k_ref, d_ref = int(v[t + "substeps"][j, i]), bool(v[t + "dones"][j, i])
+def _classify_core(tag, k_ref, d_ref, servo_err, q9, kg, dg, spread_fn, hard, edist, note=""):
+    """'match' | 'bifurcation' | 'boundary' | 'other' for one side's (count, done) of an env-step against the reference's
+    (k_ref, d_ref).  servo_err: the reference's servo error after each of its substeps; q9: obs[9] of the observation the
+    reference's step ended on; spread_fn(): the float64 oracle's counts under float32-sized perturbations (conftest.
+    count_spread; called only for a mismatch).  hard: a mismatch that is neither at a bifurcation nor at a servo / angle
+    boundary fails the test (the GPU's); the float32 oracle's are only counted."""
     if kg == k_ref and dg == d_ref:
         return "match"
     # legitimate only AT a decision boundary (tests/test_env_logic_golden.py has the reasoning): the servo error where the
     # two part ways is within float32 round-off of the 0.05 tolerance, or |q9| of 0.5
-    if not spread:
-        spread.extend(_count_spread(oracle_mod, S, X, M, a_i, True, 1000 * j + i))
-    ks = spread
+    ks = spread_fn()
     if len(set(ks + [k_ref])) > 1:
         # a bifurcation: the float64 oracle's own count moves under float32-sized changes of the inputs
         if hard:
-            print("  %s step %d env %d: GPU %d, reference %d, %s, float64 oracle under float32-sized perturbations %s"
-                  % (t, j, i, kg, k_ref, note, ks))
-            assert min(ks + [k_ref]) - 1 <= kg <= max(ks + [k_ref]) + 1, (t, j, i, kg, k_ref, ks)
+            print("  %s: GPU %d, reference %d, %s, float64 oracle under float32-sized perturbations %s" % (tag, kg, k_ref, note, ks))
+            assert min(ks + [k_ref]) - 1 <= kg <= max(ks + [k_ref]) + 1, (tag, kg, k_ref, ks)
         return "bifurcation"
     if kg != k_ref:
-        e_dec = float(v[t + "servo_err"][j, i, min(kg, k_ref) - 1]) if abs(kg - k_ref) <= 1 else 1.0
+        e_dec = float(servo_err[min(kg, k_ref) - 1]) if (abs(kg - k_ref) <= 1 and min(kg, k_ref) >= 1) else 1.0
         ok = abs(kg - k_ref) <= 1 and abs(e_dec - 0.05) < SERVO_WINDOW(k_ref)
         if hard:
-            assert ok, (t, j, i, kg, k_ref, e_dec)
+            assert ok, (tag, kg, k_ref, e_dec)
         edist.append(abs(e_dec - 0.05))
         if not ok and not hard:
-            print("  %s step %d env %d: %s count %d, reference %d, servo error there %.5f (window %.2e), float64 oracle under "
-                  "perturbations %s" % (t, j, i, note or "float32 oracle", kg, k_ref, e_dec, SERVO_WINDOW(k_ref), ks))
+            print("  %s: %s count %d, reference %d, servo error there %.5f (window %.2e), float64 oracle under "
+                  "perturbations %s" % (tag, note or "float32 oracle", kg, k_ref, e_dec, SERVO_WINDOW(k_ref), ks))
         return "boundary" if ok else "other"
     # equal counts, another done: |q9| of the observation the step ended on within round-off of 0.5
-    q9 = v[t + "terminal_obs"][done_index[j * NENV + i]][9] if d_ref else v[t + "obs"][j, i][9]
     ok = abs(abs(q9) - 0.5) < 2e-3
     if hard:
-        assert ok, (t, j, i, q9)
+        assert ok, (tag, q9)
     return "boundary" if ok else "other"
+
+
+def _classify(v, t, oracle_mod, j, i, S, X, M, a_i, kg, dg, spread, done_index, hard, edist, note=""):
+    """_classify_core for env-step (j, i) of the vector runs.  spread: the cache of count_spread's result for this
+    env-step (filled on demand)."""
+    k_ref, d_ref = int(v[t + "substeps"][j, i]), bool(v[t + "dones"][j, i])
+
+    def spread_fn():
+        if not spread:
+            spread.extend(_count_spread(oracle_mod, S, X, M, a_i, True, 1000 * j + i))
+        return spread
+    q9 = v[t + "terminal_obs"][done_index[j * NENV + i]][9] if d_ref else v[t + "obs"][j, i][9]
+    return _classify_core("%s step %d env %d" % (t, j, i), k_ref, d_ref, v[t + "servo_err"][j, i], q9, kg, dg, spread_fn, hard,
+                          edist, note)
 
 
 @pytest.mark.parametrize("t", ["ars_", "ppo_"])
@@ -328,9 +339,9 @@ def test_gpu_subprocvecenv_reproduces_the_reference_seam(vec, pkg, oracle_mod, t
     mismatch_gate("%s off the bifurcations" % t, stats["mism"] - stats["undecidable"], stats["mism32"] - stats["undecidable32"])
     # (observed: ARS 1.32e-2 / 5.9e-3 / 7.25e-2 against the float32 oracle's 2.74e-2 / 5.2e-3 / 7.28e-2; PPO 1.84e-2 / 2.20e-2 /
     #  8.58e-2 against 1.85e-2 / 2.19e-2 / 8.62e-2: the GPU is where the float32 oracle is)
-    assert stats["q"] < min(max(5e-3, 1.5 * stats["cq"]), 2.5e-2)
-    assert stats["r"] < min(max(5e-3, 1.5 * stats["cr"] + 1e-3), 2.5e-2)
-    assert p90 < min(max(5e-2, 1.5 * p90c), 0.25)
+    f32_gate("%s outer seam: worst q / pose of %d" % (t, stats["compared"]), stats["q"], stats["cq"], 1.5, 5e-3, 2.5e-2)
+    f32_gate("%s outer seam: worst reward" % t, stats["r"], stats["cr"], 1.5, 5e-3, 2.5e-2)
+    f32_gate("%s outer seam: rel qd p90" % t, p90, p90c, 2.0, 5e-2, 0.25)
 
 
 @pytest.mark.gpu
@@ -374,4 +385,119 @@ def test_gpu_single_env_reproduces_the_trainers_eval_env(vec, pkg, oracle_mod):
     print("eval env on the GPU: %d of %d env-steps compared, worst q/pose %.2e reward %.2e | float32 oracle %.2e %.2e"
           % (seen["n"], len(v["ppo_eval_substeps"]), seen["q"], seen["r"], seen["cq"], seen["cr"]))
     assert seen["n"] >= len(v["ppo_eval_substeps"]) * 3 // 4
-    assert seen["q"] < min(max(5e-3, 2 * seen["cq"]), 2.5e-2) and seen["r"] < min(max(5e-3, 2 * seen["cr"] + 2e-3), 2.5e-2)
+    f32_gate("eval env (17 env-steps): worst q / pose", seen["q"], seen["cq"], 2.0, 5e-3, 2.5e-2)
+    f32_gate("eval env (17 env-steps): worst reward", seen["r"], seen["cr"], 2.0, 5e-3, 2.5e-2)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# ARS's per-epoch evaluation on the trainer's SINGLE env (ars/train.py:228 -> test_env, :43-71): the last caller of the path
+# that had not been executed.  Two runs of the reference's test_env: the weights one update away from
+# zero (ars_eval_: a near-idle snake, 0-substep steps, the 200-step cap) and 12 x those (ars_eval2_: commands beyond +-1,
+# checkBound clipping the caller's (8, 1) float64 array in place, 18-33 substeps per step).
+# ------------------------------------------------------------------------------------------------------------------
+ARS_EVALS = ("ars_eval_", "ars_eval2_")
+
+
+def _ars_eval_free_run(v, oracle_mod, on_step=None):
+    """Both evaluations on ONE oracle env, free-running from the hard reset of ARS.__init__'s create_env on: test_env's
+    env.reset(), the recorded noise on the reset observation, then the caller's own arithmetic -- normalizer.normalize,
+    policy() -- recomputed step by step from what the env returned."""
+    e = oracle_mod.OracleEnv()
+    mean, std = v["ars_norm_mean"], np.sqrt(v["ars_norm_var"])              # (1, 56): Normalizer([1, 56]), frozen (eval_policy)
+    for t in ARS_EVALS:
+        W = v[t + "weights"]
+        state = e.reset() + v[t + "noise"]                                    # ars/train.py:47-48
+        total, steps, done = 0.0, 0, False
+        while not done and steps < 200:                                       # :54
+            state = (state - mean) / std                                      # :57 normalizer.normalize -> (1, 56)
+            action = np.matmul(W, state.reshape(-1, 1))                       # :40 policy -> (8, 1) float64
+            assert action.shape == (8, 1) and np.allclose(action, v[t + "action_passed"][steps], rtol=1e-10, atol=1e-13), (t, steps)
+            assert np.array_equal(e.get_state(), v[t + "state"][steps]), (t, steps)
+            assert np.array_equal(np.concatenate([e.get_aux()[0], e.get_aux()[1:]]), v[t + "aux"][steps]), (t, steps)
+            if on_step is not None:
+                on_step(t, steps, e)
+            a = v[t + "action_passed"][steps].copy()
+            o, r, d, k, a_clipped = e.env_step(a.reshape(-1), vec_mode=False)
+            assert k == v[t + "substeps"][steps] and d == bool(v[t + "done"][steps]), (t, steps, k, d)
+            assert abs(r - v[t + "env_reward"][steps]) < 1e-9 and np.abs(o - v[t + "env_obs"][steps]).max() < 1e-9, (t, steps)
+            # checkBound on the caller's 2-D array (SnakeGymEnv.py:82-88): clipped in place, shape kept
+            assert np.array_equal(v[t + "action_after"][steps], np.clip(a, -1, 1)) and np.array_equal(a_clipped[:8], np.clip(a.reshape(-1), -1, 1))
+            total += r                                                        # :66
+            steps += 1
+            state, done = o, d
+        assert steps == int(v[t + "num_plays"]) and abs(total - float(v[t + "test_reward"])) < 1e-9, (t, steps, total)
+
+
+def test_oracle_reproduces_ars_evaluation(vec, oracle_mod):
+    v = vec
+    _ars_eval_free_run(v, oracle_mod)
+    # what the two runs exercise
+    assert int(v["ars_eval_num_plays"]) == 200 and (v["ars_eval_substeps"] == 0).sum() > 150 and not v["ars_eval_done"].any()
+    assert (np.abs(v["ars_eval2_action_passed"]) > 1).sum() > 100 and v["ars_eval2_substeps"].min() >= 10
+    assert v["ars_eval2_action_passed"].dtype == np.float64 and v["ars_eval2_action_passed"].shape[1:] == (8, 1)
+
+
+@pytest.mark.gpu
+def test_gpu_single_env_reproduces_ars_evaluation(vec, pkg, oracle_mod):
+    """test_env's calls on the product's SnakeGymEnv: each step from the state the reference's env started it in, the
+    caller's (8, 1) float64 array as policy() returned it -- clipped in place as checkBound leaves it --, counts / done
+    flags by the one mismatch rule, observation and reward against the float32 oracle's own distance."""
+    v = vec
+    robot = pkg.Snake(None, "snake/snake.urdf", None)
+    env = pkg.SnakeGymEnv(robot, None)
+    env.reset()
+    e32 = oracle_mod.OracleEnv(f32=True)
+    st = {t: dict(n=0, mism=0, mism32=0, q=[], r=[], cq=[], cr=[], edist=[], edist32=[]) for t in ARS_EVALS}
+
+    def on_step(t, j, e):
+        s = st[t]
+        S, X, M = e.get_state(), np.concatenate([e.get_aux()[0], e.get_aux()[1:]]), e.get_manifold()
+        a_ref = v[t + "action_passed"][j]
+        e32.hard_reset()
+        e32.sync(S, X, M)
+        o32, r32, d32, k32, _ = e32.env_step(a_ref.reshape(-1).copy(), vec_mode=False)
+        env._stepper.set_state(S[None], X[None])
+        env._stepper.set_manifold(M[None])
+        a = a_ref.copy()                                                     # (8, 1) float64, as policy() returned it
+        o, r, d, info = env.step(a)
+        assert info == {} and a.shape == (8, 1) and a.dtype == np.float64
+        assert np.array_equal(a, v[t + "action_after"][j]), (t, j)           # the caller's array as checkBound leaves it
+        assert isinstance(o, np.ndarray) and o.shape == (O,) and isinstance(r, float) and isinstance(d, bool)
+        k_ref, d_ref, o_ref, r_ref = int(v[t + "substeps"][j]), bool(v[t + "done"][j]), v[t + "env_obs"][j], float(v[t + "env_reward"][j])
+        spread = []
+
+        def spread_fn():
+            if not spread:
+                spread.extend(_count_spread(oracle_mod, S, X, M, a_ref.reshape(-1).copy(), False, 7000 + j))
+            return spread
+        tag = "%s step %d" % (t, j)
+        c32 = _classify_core(tag, k_ref, d_ref, v[t + "servo_err"][j], o_ref[9], int(k32), bool(d32), spread_fn, False, s["edist32"])
+        cg = _classify_core(tag, k_ref, d_ref, v[t + "servo_err"][j], o_ref[9], int(robot.counter), bool(d), spread_fn, True, s["edist"],
+                            note="float32 oracle %d" % k32)
+        s["mism32"] += c32 != "match"
+        s["mism"] += cg != "match"
+        if c32 == "match":
+            s["cq"].append(max(np.abs(o32[:N] - o_ref[:N]).max(), np.abs(o32[3 * N:3 * N + 7] - o_ref[3 * N:3 * N + 7]).max()))
+            s["cr"].append(abs(r32 - r_ref))
+        if cg == "match":
+            s["n"] += 1
+            s["q"].append(max(np.abs(o[:N] - o_ref[:N]).max(), np.abs(o[3 * N:3 * N + 7] - o_ref[3 * N:3 * N + 7]).max()))
+            s["r"].append(abs(r - r_ref))
+            if k_ref == 0:
+                # no substep ran: the observation is the state's own (float32 of it), the reward its arithmetic
+                assert s["q"][-1] < 1e-6, (t, j, s["q"][-1])
+
+    _ars_eval_free_run(v, oracle_mod, on_step=on_step)
+    env.close()
+    for t in ARS_EVALS:
+        s = st[t]
+        T = int(v[t + "num_plays"])
+        print("%s on the GPU: %d of %d env-steps compared, count / done mismatches GPU %d | float32 oracle %d; worst q/pose %.2e "
+              "reward %.2e | float32 oracle %.2e %.2e" % (t, s["n"], T, s["mism"], s["mism32"], max(s["q"]), max(s["r"]), max(s["cq"]), max(s["cr"])))
+        assert s["n"] >= T * 3 // 4
+        mismatch_gate(t, s["mism"], s["mism32"])
+        f32_gate("%s single env: worst q / pose of %d" % (t, s["n"]), max(s["q"]), max(s["cq"]), 1.5, 5e-3, 2.5e-2)
+        f32_gate("%s single env: median q / pose" % t, np.median(s["q"]), np.median(s["cq"]), 1.5, 1e-5)
+        # (the worst of 200 rewards is the energy term of one stiff step: 1.57 x observed; its median is gated at 1.5 x)
+        f32_gate("%s single env: worst reward" % t, max(s["r"]), max(s["cr"]), 2.0, 5e-3, 2.5e-2)
+        f32_gate("%s single env: median reward" % t, np.median(s["r"]), np.median(s["cr"]), 1.5, 1e-5)
