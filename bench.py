@@ -45,29 +45,19 @@ BYTES_PER_SUBSTEP = 424
 BYTES_PER_ENVSTEP = 32 + 224 + 4 + 1 + 4
 
 
-def splitmix64(x):
-    x = (x + np.uint64(0x9E3779B97F4A7C15)) & np.uint64(0xFFFFFFFFFFFFFFFF)
-    z = x
-    z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & np.uint64(0xFFFFFFFFFFFFFFFF)
-    z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & np.uint64(0xFFFFFFFFFFFFFFFF)
-    return z ^ (z >> np.uint64(31))
+# The synthetic inputs of SURVEY 8(d) -- per-env gait phases, the serpenoid action stream, configs[4]'s per-env plane
+# friction -- live in bullet-envs_amd/synthetic.py (pure numpy), loaded by path so that nothing of the package is imported
+# before the CPU baseline runs; tests take them from the same file.
+def _load_synthetic():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("snk_synthetic", os.path.join(ROOT, "bullet-envs_amd", "synthetic.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
 
 
-def env_phases(global_ids, seed=0):
-    """phi_e = 2 pi u_e, u_e from a counter-based generator keyed by (seed, global env index); phi_0 = 0."""
-    with np.errstate(over="ignore"):
-        h = splitmix64(np.asarray(global_ids, dtype=np.uint64) + np.uint64(seed) * np.uint64(0x100000001B3))
-    u = (h >> np.uint64(11)).astype(np.float64) / float(1 << 53)
-    phi = 2.0 * np.pi * u
-    phi[np.asarray(global_ids) == 0] = 0.0
-    return phi
-
-
-def gait_actions(global_ids, j, A=8):
-    """a[e,k] = -sin((2k+1) s + w t_j + phi_e), s=4, w=2, t_j = 0.1 j (snake_gait_test.py:65-67,86)."""
-    k = np.arange(A)
-    phi = env_phases(global_ids)
-    return -np.sin((2 * k[None, :] + 1) * 4.0 + 2.0 * (0.1 * j) + phi[:, None])
+_syn = _load_synthetic()
+splitmix64, env_phases, gait_actions, env_friction = _syn.splitmix64, _syn.env_phases, _syn.gait_actions, _syn.env_friction
 
 
 # --------------------------------------------------------------------------------------
@@ -82,14 +72,6 @@ def _cpu_model():
     except OSError:
         pass
     return "unknown"
-
-
-def env_friction(global_ids, seed):
-    """BASELINE configs[4]: per-env plane friction mu_e ~ U[0.5, 1.5), counter-based, keyed by (seed, global env)."""
-    with np.errstate(over="ignore"):
-        h = splitmix64(np.asarray(global_ids, dtype=np.uint64) * np.uint64(2) + np.uint64(1)
-                       + np.uint64(seed) * np.uint64(0x100000001B3))
-    return 0.5 + (h >> np.uint64(11)).astype(np.float64) / float(1 << 53)
 
 
 def cpu_baseline(steps=2000, warmup=20, n_links=16, friction_seed=None, hull_sides=32, contact_model=1, warm_start=0,
@@ -311,29 +293,41 @@ def self_launch(n, argv):
     """`python bench.py --gpus N` from a plain shell, N > 1: the reference's SubprocVecEnv fans out by itself when it is
     constructed (ppo/multiprocessing_env.py:97-117); so does this.  One rank per GPU is started through
     torch.distributed.run as a CHILD process (never an exec: this parent has not touched the GPU and never will), on a
-    port taken from a bound socket; rank 0's JSON line is relayed as this process's only stdout line, everything else
-    the ranks print goes to stderr, and the exit code is the child's."""
+    port taken from a bound socket (repeated on another port if exactly that port was taken in between); rank 0's JSON
+    line -- the last one, should there be several -- is relayed as this process's only stdout line, everything else the
+    ranks print (stdout and stderr) goes to stderr, and the exit code is the child's."""
     import socket
     import subprocess
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", SNK_BENCH_SELF_LAUNCHED="1")
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: what RCCL needs on this pool's hosts
     env.setdefault("OMP_NUM_THREADS", "1")
-    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True, cwd=ROOT)
-    line = None
-    for ln in proc.stdout:
-        if ln.startswith("{") and line is None:
-            line = ln.rstrip("\n")
-        else:
-            sys.stderr.write(ln)
-    rc = proc.wait()
-    if line is not None:
-        print(line, flush=True)
+    rc, lines = 1, []
+    for attempt in range(3):
+        # A port from a bound socket is free when it is taken and may be gone when torch.distributed.run binds it (another
+        # process can grab it in between: ADVICE r5).  The window cannot be closed from here, so a launch that dies of
+        # exactly that is repeated on another port -- and of nothing else.
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+        proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env, text=True, cwd=ROOT)
+        lines, in_use = [], False
+        for ln in proc.stdout:
+            if ln.startswith("{") and '"metric"' in ln:
+                lines.append(ln.rstrip("\n"))
+            else:
+                in_use = in_use or "EADDRINUSE" in ln or "ddress already in use" in ln
+                sys.stderr.write(ln)
+        rc = proc.wait()
+        if rc == 0 or lines or not in_use:
+            break
+        sys.stderr.write("bench.py: port %d was taken before the launcher could bind it; once more on another port\n" % port)
+    if len(lines) > 1:
+        sys.stderr.write("bench.py: the ranks printed %d JSON lines, expected one (rank 0's); relaying the last\n" % len(lines))
+    if lines:
+        print(lines[-1], flush=True)
     elif rc == 0:
         sys.stderr.write("bench.py: the ranks exited 0 but rank 0 printed no JSON line\n")
         rc = 1

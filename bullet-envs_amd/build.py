@@ -42,6 +42,17 @@ def _stamp(out):
     return out + ".cmd"
 
 
+def toolchain_text():
+    """What compiled the library: hipcc's own version lines (HIP version, clang version), kept next to the library
+    (libsnk.so.toolchain) -- tests/test_gpu_bits.py keys its pinned hashes by it."""
+    try:
+        out = subprocess.check_output([_hipcc(), "--version"], text=True, stderr=subprocess.STDOUT)
+    except (OSError, subprocess.CalledProcessError):
+        return "unknown"
+    keep = [ln.strip() for ln in out.splitlines() if ln.startswith("HIP version") or "clang version" in ln]
+    return " | ".join(keep) if keep else "unknown"
+
+
 def _stamp_text(cmd):
     """The command line as it is kept next to the library: paths relative to this directory, so that the copy of the tree
     on a GPU box (another absolute path) does not look like another build."""
@@ -75,6 +86,9 @@ def build(force=False, verbose=False, defines=(), out=None):
     target = out or LIB
     cmd = _command(target, defines, extra)
     if out is None and not force and not needs_build(cmd):
+        if not os.path.exists(LIB + ".toolchain"):          # (a library from before round 6: same image, same compiler)
+            with open(LIB + ".toolchain", "w") as f:
+                f.write(toolchain_text())
         return LIB
     run = list(cmd)
     if verbose:
@@ -83,6 +97,8 @@ def build(force=False, verbose=False, defines=(), out=None):
     subprocess.check_call(run)
     with open(_stamp(target), "w") as f:
         f.write(_stamp_text(cmd))
+    with open(target + ".toolchain", "w") as f:
+        f.write(toolchain_text())
     return target
 
 

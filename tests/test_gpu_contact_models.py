@@ -23,7 +23,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import f32_gate      # noqa: E402
+from conftest import f32_gate, mismatch_gate      # noqa: E402
 
 from conftest import ROUND1, random_state
 
@@ -94,7 +94,7 @@ def _ground_states(B, n=16, seed=0):
                                     ("default+reversed", 16), ("default+perm3", 16), ("default+reversed", 32), ("default+perm3", 32)])
 def test_substep_parity_under_contact_switch(pkg, oracle_mod, name, n):
     over = dict(SWITCHES[name], n_modules=n, self_collision=0)
-    B, K = (48, 3) if n == 16 else (12, 3)
+    B, K = (48, 3) if n == 16 else (36, 3)     # (round 5: 12 for 32 links -- 36 samples, too few for a 90th percentile)
     st = pkg.Stepper(B, residual_threshold=0.0, **over)
     S = _ground_states(B, n, seed=3)
     st.set_state(S, np.zeros((B, n + 2), np.float32))
@@ -109,6 +109,7 @@ def test_substep_parity_under_contact_switch(pkg, oracle_mod, name, n):
             lst.append(e)
     bad = 0
     worst_p, worst_v, cal_p, cal_v = 0.0, 0.0, 0.0, 0.0
+    wl_p, wl_v, cl_p, cl_v = [], [], [], []          # per (environment, substep): the distribution, not only its worst
     why = {}
     alive = np.ones(B, bool)
     for k in range(K):
@@ -123,8 +124,9 @@ def test_substep_parity_under_contact_switch(pkg, oracle_mod, name, n):
                 continue
             if refs32[i].last_num_contacts == e.last_num_contacts:       # calibration: the oracle built in float32
                 r64, r32 = e.get_state(), refs32[i].get_state()
-                cal_p = max(cal_p, np.abs(r32[:7] - r64[:7]).max(), np.abs(r32[13:13 + n] - r64[13:13 + n]).max())
-                cal_v = max(cal_v, (np.abs(r32[13 + n:] - r64[13 + n:]) / (1 + np.abs(r64[13 + n:]))).max())
+                cl_p.append(max(np.abs(r32[:7] - r64[:7]).max(), np.abs(r32[13:13 + n] - r64[13:13 + n]).max()))
+                cl_v.append((np.abs(r32[13 + n:] - r64[13 + n:]) / (1 + np.abs(r64[13 + n:]))).max())
+                cal_p, cal_v = max(cal_p, cl_p[-1]), max(cal_v, cl_v[-1])
             same = e.last_num_contacts == info[i, 1]
             reason = "" if same else "contact count"
             if same and manifold:
@@ -136,8 +138,9 @@ def test_substep_parity_under_contact_switch(pkg, oracle_mod, name, n):
                 bad += 1                  # deep vertices is the support point) fell the other way
                 continue
             ref = e.get_state()
-            worst_p = max(worst_p, np.abs(G[i, :7] - ref[:7]).max(), np.abs(G[i, 13:13 + n] - ref[13:13 + n]).max())
-            worst_v = max(worst_v, (np.abs(G[i, 13 + n:] - ref[13 + n:]) / (1 + np.abs(ref[13 + n:]))).max())
+            wl_p.append(max(np.abs(G[i, :7] - ref[:7]).max(), np.abs(G[i, 13:13 + n] - ref[13:13 + n]).max()))
+            wl_v.append((np.abs(G[i, 13 + n:] - ref[13 + n:]) / (1 + np.abs(ref[13 + n:]))).max())
+            worst_p, worst_v = max(worst_p, wl_p[-1]), max(worst_v, wl_v[-1])
     print(name, n, "substep parity: worst pos", worst_p, "worst rel qd", worst_v, "| oracle-f32", cal_p, cal_v,
           "| threshold flips", bad, "of", B, why)
     assert bad <= (B // 6 if n == 16 else B // 3)      # (the 32-link chain: twice the contacts, twice the decisions)
@@ -146,8 +149,17 @@ def test_substep_parity_under_contact_switch(pkg, oracle_mod, name, n):
     # (hard outer caps beside the calibrated bounds; the 32-link states of this test start with links deep in the ground:
     #  the float32 ORACLE is 6e-2 / 1.7 off the float64 one on them)
     cap_p, cap_v = (5e-3, 1.0) if n == 16 else (0.25, 5.0)
-    f32_gate("%s %d substep parity: worst pos of %d x 3" % (name, n, B), worst_p, cal_p, 2.0, 1e-4, cap_p)
-    f32_gate("%s %d substep parity: worst rel qd" % (name, n), worst_v, cal_v, 2.0, 1e-2 if n == 16 else 0.2, cap_v)
+    # The error is heavy-tailed (stick-slip states amplify float32 round-off by 1e5), so the calibrated gates sit on the
+    # DISTRIBUTION over the (environment, substep) samples -- median 1.5 x, 90th percentile 2 x the float32 oracle's -- and
+    # the worst of the 36-144 samples gets 2 x or the absolute level the test demands of any sample (5e-4 rad, 5 % of a
+    # velocity), whichever is larger (observed worst ratios 0.3 .. 4.9 between two equally accurate float32 computations)
+    f2 = 1.5 if n == 16 else 2.0
+    f32_gate("%s %d substep parity: median pos of %d" % (name, n, len(wl_p)), np.median(wl_p), np.median(cl_p), f2, 2e-6)
+    f32_gate("%s %d substep parity: p90 pos" % (name, n), np.percentile(wl_p, 90), np.percentile(cl_p, 90), 2.0, 1e-5)
+    f32_gate("%s %d substep parity: median rel qd" % (name, n), np.median(wl_v), np.median(cl_v), f2, 2e-5)
+    f32_gate("%s %d substep parity: p90 rel qd" % (name, n), np.percentile(wl_v, 90), np.percentile(cl_v, 90), 2.0, 2e-4)
+    f32_gate("%s %d substep parity: worst pos" % (name, n), worst_p, cal_p, 2.0, 5e-4, cap_p)
+    f32_gate("%s %d substep parity: worst rel qd" % (name, n), worst_v, cal_v, 2.0, 5e-2 if n == 16 else 0.2, cap_v)
     if manifold:
         counts = st.get_manifold()[:, :, 0]
         assert counts.max() <= 4 and counts.sum() > 0
@@ -186,8 +198,8 @@ def test_manifold_parity_from_gait_states(pkg, oracle_mod, n, order):
             e.set_manifold(Mf[i].astype(np.float64))
             lst.append(e)
     worst_p = worst_v = cal_p = cal_v = worst_f = cal_f = 0.0
-    bad = 0
-    alive = np.ones(B, bool)
+    bad = bad32 = 0
+    alive, alive32 = np.ones(B, bool), np.ones(B, bool)
     for k in range(K):
         info = st.substep(T, 1)
         G, GX = st.get_state()
@@ -203,6 +215,11 @@ def test_manifold_parity_from_gait_states(pkg, oracle_mod, n, order):
                 cal_p = max(cal_p, np.abs(r32[:7] - r64[:7]).max(), np.abs(r32[13:13 + n] - r64[13:13 + n]).max())
                 cal_v = max(cal_v, (np.abs(r32[13 + n:] - r64[13 + n:]) / (1 + np.abs(r64[13 + n:]))).max())
                 cal_f = max(cal_f, abs(refs32[i].get_aux()[1] - e.get_aux()[1]))
+            # the yardstick for the cache flips: the float32 oracle's own cache against the float64 oracle's, same rule
+            if alive32[i] and not (refs32[i].last_num_contacts == e.last_num_contacts
+                                   and _same_manifold(refs32[i].get_manifold(), e.get_manifold(), n)):
+                alive32[i] = False
+                bad32 += 1
             same = e.last_num_contacts == info[i, 1] and _same_manifold(M[i], e.get_manifold(), n)
             if not same:
                 alive[i] = False
@@ -216,8 +233,11 @@ def test_manifold_parity_from_gait_states(pkg, oracle_mod, n, order):
             # unwritten table under this one -- state parity did not notice, this comparison does)
             worst_f = max(worst_f, abs(float(GX[i, n]) - e.get_aux()[1]))
     print("manifold from gait states, n =", n, ": worst pos", worst_p, "worst rel qd", worst_v, "sensor force", worst_f,
-          "| oracle-f32", cal_p, cal_v, cal_f, "| cache flips", bad, "of", B)
-    assert bad <= B // 4
+          "| oracle-f32", cal_p, cal_v, cal_f, "| cache flips", bad, "of", B, "(float32 oracle:", bad32, ")")
+    # an environment leaves the comparison when the two sides' caches part ways (a breaking-threshold / merge decision that
+    # float32 round-off tips): as often as the float32 oracle's own cache leaves the float64 oracle's, by the one rule
+    mismatch_gate("manifold from gait states n = %d order %d: cache flips" % (n, order), bad, bad32, 1.5, 2)
+    assert bad <= B // 2
     # states in motion include stick-slip ones that amplify float32 round-off: no worse than 3x the float32 oracle
     # (the velocity error is heavy-tailed and this is the maximum of two dozen samples: factor 5 on it)
     f32_gate("manifold from gait states n = %d order %d: worst pos of %d" % (n, order, B), worst_p, cal_p, 2.0, 1e-4, 5e-3)

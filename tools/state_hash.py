@@ -1,20 +1,23 @@
 """Hash of the state and outputs after a few gait steps (to compare two builds bit for bit):
-    SNK_LIB=<lib> python tools/state_hash.py [16|32]"""
-import hashlib, importlib, sys
-import numpy as np
-sys.path.insert(0, '.')
-import bench
+    SNK_LIB=<lib> python tools/state_hash.py [16|32]       one line per chain length
+    python tools/state_hash.py --pins                      the block tests/test_gpu_bits.py pins (three kernel families, per part)"""
+import importlib, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 pkg = importlib.import_module("bullet-envs_amd")
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 16
-B = 2000
-st = pkg.Stepper(B, n_modules=n)
-st.reset()
-st.set_ground_friction((0.5 + np.arange(B) % 11 / 10.0).astype(np.float32))
-h = hashlib.sha256()
-for j in range(4):
-    o, r, d, s = st.step(bench.gait_actions(np.arange(B), j, n // 2).astype(np.float32))
-    for a in (o, r, d, s):
-        h.update(np.ascontiguousarray(a).tobytes())
-S, X = st.get_state()
-h.update(S.tobytes()); h.update(X.tobytes())
-print(n, "links:", h.hexdigest()[:16], "mean substeps", s.mean())
+import test_gpu_bits as T
+
+if "--pins" in sys.argv:
+    key, txt = T.toolchain_key()
+    print("    # %s" % txt.replace("\n", " || "))
+    print('    "%s": {' % key)
+    for n, streamed in ((16, False), (16, True), (32, False)):
+        if streamed:
+            os.environ["SNK_FORCE_STREAMED"] = "1"
+        else:
+            os.environ.pop("SNK_FORCE_STREAMED", None)
+        print('        "%d%s": %r,' % (n, "s" if streamed else "", T.state_hashes(pkg, n, streamed)))
+    print("    },")
+else:
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+    print(n, "links:", T.state_hashes(pkg, n, bool(os.environ.get("SNK_FORCE_STREAMED")))["all"])
