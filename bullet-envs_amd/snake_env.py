@@ -428,10 +428,14 @@ class SnakeVecEnv(VecEnv):
     (multiprocessing_env.py:13-16, SnakeGymEnv.py:39-41).
     """
 
-    def __init__(self, num_envs, args=None, device=0, n_modules=16, params=None, shared_infos=False, **over):
+    def __init__(self, num_envs, args=None, device=0, n_modules=16, params=None, shared_infos=False, mode=None, **over):
         self.params = params if params is not None else params_from_args(args, n_modules=n_modules, **over)
         self._stepper = _lib.Stepper(num_envs, device=device, params=self.params)
         self.nenvs = num_envs
+        # 'test' (ppo/params.py --mode test): every env's info carries its per-substep telemetry, as each of the
+        # reference's workers would send it through its Pipe (SnakeGymEnv.py:43-44 via multiprocessing_env.py:11-16)
+        self.mode = mode if mode is not None else (getattr(args, "mode", "train") if args is not None else "train")
+        self._scratch = None
         self._shared_infos = (FrozenInfo(),) * num_envs if shared_infos else None
         self.waiting = False
         self.closed = False
@@ -449,14 +453,58 @@ class SnakeVecEnv(VecEnv):
         self.waiting = True
 
     def step_wait(self):
+        if self.mode == 'test':
+            st = self._stepper
+            before = st.get_state() + (st.get_manifold(), st.get_box() if self.params.obstacle == 2 else None)
         obs, rew, done, sub = self._stepper.step(self._pending, vec_mode=True)
         self.waiting = False
         self.last_substeps = sub
+        if self.mode == 'test':
+            return obs, rew, done, self._telemetry(before, self._pending, sub, obs, done)
         # train mode: one fresh empty dict per env per step, as the reference's workers send (SnakeGymEnv.py:46-47 through
         # multiprocessing_env.py:11-16; zip(*results) makes the tuple): wrappers may annotate infos[i], rollout buffers
         # may pickle them.  0.15 ms for 4096 envs; shared_infos=True hands out one read-only FrozenInfo instead.
         infos = self._shared_infos if self._shared_infos is not None else tuple({} for _ in range(self.nenvs))
         return obs, rew, done, infos
+
+    def _telemetry(self, before, clipped_actions, sub, obs, done):
+        """Test mode through the vector seam: what each of the reference's workers would put into its info -- the
+        observation and the link positions after every physics substep of ITS env-step (snake.py:275-293; the lists are
+        cleared at the start of the next step, not by the worker's reset, so a done env's info still carries the step that
+        ended its episode).  As in the single-env seam the fused kernel stays the authority and the substeps are replayed
+        one launch at a time on a scratch handle of the same size from the state, contact cache and box the step started
+        in; env i's lists take the first sub[i] of them.  The replay of an env that did not end its episode must end bit
+        for bit on the observation the step returned."""
+        if self._scratch is None:
+            self._scratch = _lib.Stepper(self.nenvs, device=self._stepper.device, params=self.params)
+            self._scratch.set_ground_friction(self._stepper.get_ground_friction())
+        sc = self._scratch
+        sc.set_state(before[0], before[1])
+        if before[2] is not None:
+            sc.set_manifold(before[2])
+        if before[3] is not None:
+            sc.set_box(*before[3])
+        n = self.params.n_modules
+        targets = np.zeros((self.nenvs, n), dtype=np.float32)
+        if self.params.gait == 0:
+            targets[:, 0::2] = clipped_actions
+        elif self.params.gait == 1:
+            targets[:, 1::2] = clipped_actions
+        else:
+            targets[:, :] = clipped_actions
+        targets *= np.float32(self.params.scaling_factor)
+        io = [[] for _ in range(self.nenvs)]
+        lp = [[] for _ in range(self.nenvs)]
+        for s_ in range(int(sub.max()) if len(sub) else 0):
+            sc.substep(targets, 1)
+            o, l = sc.get_obs(), sc.link_positions()
+            for i in np.nonzero(sub > s_)[0]:
+                io[i].append(o[i].astype(np.float64))
+                lp[i].append(l[i].astype(np.float64))
+        for i in range(self.nenvs):
+            if sub[i] and not done[i] and not np.array_equal(io[i][-1].astype(np.float32), obs[i]):
+                raise SystemError("test-mode replay diverged from the step kernel (env %d)" % i)
+        return tuple({'frames': [], 'internal_observations': io[i], 'link_positions': lp[i]} for i in range(self.nenvs))
 
     def reset(self):
         return self._stepper.reset()
@@ -466,11 +514,15 @@ class SnakeVecEnv(VecEnv):
 
     def set_ground_friction(self, mu):
         self._stepper.set_ground_friction(mu)
+        if self._scratch is not None:
+            self._scratch.set_ground_friction(self._stepper.get_ground_friction())
 
     def close(self):
         if self.closed:
             return
         self._stepper.close()
+        if self._scratch is not None:
+            self._scratch.close()
         self.closed = True
 
     def __len__(self):
@@ -480,9 +532,11 @@ class SnakeVecEnv(VecEnv):
 class SubprocVecEnv(SnakeVecEnv):
     """Drop-in for `SubprocVecEnv(env_fns)` (ppo/multiprocessing_env.py:97-117).
 
-    The reference forks one process per thunk.  Here the FIRST thunk is called once, only to
-    read the env's parameters (it is closed again); len(env_fns) environments are then
-    created on the GPU in one handle.
+    The reference forks one process per thunk.  Here the thunks are called only to read each env's
+    parameters and mode (the envs are closed again; thunks that differ are refused, see below);
+    len(env_fns) environments are then created on the GPU in one handle.  Thunks that build
+    mode='test' envs get what the reference's workers would send: every env's info carries its
+    per-substep telemetry (SnakeVecEnv._telemetry).
     """
 
     #: every thunk is called and compared up to this many; beyond it the first, the last and kHeteroProbe - 2 evenly
@@ -523,11 +577,4 @@ class SubprocVecEnv(SnakeVecEnv):
                 raise ValueError("SubprocVecEnv: env_fns[%d] differs from env_fns[0] in `%s` (%r vs %r); one GPU handle "
                                  "runs one parameter set -- build one SubprocVecEnv per distinct configuration"
                                  % (i, diff[0], diff[2], diff[1]))
-        if mode == 'test':
-            # the reference's workers would send each env's per-substep telemetry through their Pipes
-            # (SnakeGymEnv.py:43-44); the vector seam here returns train-mode infos only -- refuse rather than hand a
-            # trainer empty dicts where it asked for telemetry
-            raise NotImplementedError("SubprocVecEnv: mode='test' (per-substep telemetry in infos) is served by the "
-                                      "single-env seam, bullet-envs_amd SnakeGymEnv(robot, args); the vector seam is "
-                                      "train-mode only")
-        SnakeVecEnv.__init__(self, n, device=device, params=params)
+        SnakeVecEnv.__init__(self, n, device=device, params=params, mode=mode)

@@ -197,8 +197,9 @@ def test_subproc_vec_env_dropin(pkg):
     envs = pkg.SubprocVecEnv([pkg.CloudpickleWrapper(make_env()) for _ in range(3)])
     assert envs.num_envs == 3 and envs.reset().shape == (3, 56)
     envs.close()
-    # thunks that build test-mode envs (ppo/params.py --mode test): the vector seam has no per-substep telemetry to put
-    # into infos, and says so instead of returning empty dicts
+    # thunks that build test-mode envs (ppo/params.py --mode test): every env's info carries its per-substep telemetry,
+    # as each of the reference's workers would send it through its Pipe (SnakeGymEnv.py:43-44 via multiprocessing_env.py:
+    # 11-16) -- the same lists, bit for bit, that the single-env seam gives for the same env-step
     class Args:
         alpha, beta, gamma = 1.0, 0.01, 0.1
         gaitSelection, scaling_factor, mode = 1, 6.0, 'test'
@@ -206,8 +207,38 @@ def test_subproc_vec_env_dropin(pkg):
 
     def make_test_env():
         return lambda: pkg.SnakeGymEnv(pkg.Snake(None, "snake/snake.urdf", Args()), Args())
-    with pytest.raises(NotImplementedError):
-        pkg.SubprocVecEnv([make_test_env() for _ in range(2)])
+    import bench
+    NE = 3
+    envs = pkg.SubprocVecEnv([make_test_env() for _ in range(NE)])
+    assert envs.mode == 'test'
+    singles = [make_test_env()() for _ in range(NE)]
+    envs.reset()
+    for e in singles:
+        e.reset()
+    ends = 0
+    for j in range(12):
+        a = bench.gait_actions(np.arange(NE), j).astype(np.float32)
+        a[1] *= 1.5                                     # env 1: beyond the bounds (clipped), so the three differ
+        S, X = envs._stepper.get_state()
+        M = envs._stepper.get_manifold()
+        obs, rews, dones, infos = envs.step(a)
+        assert isinstance(infos, tuple) and len(infos) == NE
+        for i, e in enumerate(singles):
+            e._stepper.set_state(S[i:i + 1], X[i:i + 1])
+            e._stepper.set_manifold(M[i:i + 1])
+            o1, r1, d1, info1 = e.step(a[i].copy())
+            k = envs.last_substeps[i]
+            assert sorted(infos[i]) == sorted(info1) == ['frames', 'internal_observations', 'link_positions']
+            assert infos[i]['frames'] == [] and len(infos[i]['internal_observations']) == len(infos[i]['link_positions']) == k == e.robot.counter
+            for u, v in zip(infos[i]['internal_observations'] + infos[i]['link_positions'], info1['internal_observations'] + info1['link_positions']):
+                assert u.dtype == np.float64 and np.array_equal(u, v)
+            assert bool(dones[i]) == d1 and rews[i] == np.float32(r1)
+            if k and not d1:
+                assert np.array_equal(infos[i]['internal_observations'][-1].astype(np.float32), obs[i])
+            ends += int(d1)
+    envs.close()
+    for e in singles:
+        e.close()
 
 
 def test_ground_friction_config(pkg, oracle_mod):

@@ -14,6 +14,7 @@
 //   tools/ubench_stream [iterations per wave, default 2000]
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -83,6 +84,83 @@ __device__ __forceinline__ void row_step_normal4(float jA, float mA, float jB, f
         : [jA] "v"(jA), [mA] "v"(mA), [jB] "v"(jB), [mB] "v"(mB), [jC] "v"(jC), [mC] "v"(mC), [jD] "v"(jD), [mD] "v"(mD),
           [accA] "v"(accA), [accB] "v"(accB), [accC] "v"(accC), [accD] "v"(accD), [c21] "v"(c21), [c31] "v"(c31),
           [c32] "v"(c32), [c41] "v"(c41), [c42] "v"(c42), [c43] "v"(c43), [SL] "n"(SUM_LANE));
+    accA = xA; accB = xB; accC = xC; accD = xD;
+}
+
+// The same four normals with a TRANSPOSED reduction (round 6, counted in profiles/r06_ubench_stream.txt, then measured):
+// all 64 lanes enabled, lanes 40..63 of the rows exact zeros.  v_permlane32_swap folds two 40-lane product vectors into
+// the halves of one register ([A | B], [C | D]); after the first DPP stage every lane pair holds its sum twice, so one
+// v_cndmask merges the two registers (even lanes AB, odd lanes CD); three more DPP stages leave the row sums by class in
+// lanes 12..15 of every row of 16; a v_permlane16_swap of the register with its copy adds rows 0+1 and 2+3.  A's dot ends in
+// lane 14, C's in lane 15, B's in lane 46, D's in lane 47.  21 instructions for four dots instead of 32; 45 VALU in all.
+__device__ __forceinline__ void row_step_normal4t(float jA, float mA, float jB, float mB, float jC, float mC, float jD, float mD,
+                                                  float& accA, float& accB, float& accC, float& accD, float c21, float c31,
+                                                  float c32, float c41, float c42, float c43, unsigned long long odd,
+                                                  float& dv, float& lsq) {
+    float tA, tB, tC, tD, xA, xB, xC, xD, dA, dB, dC, dD, sA, sB, sC, sD;
+    asm volatile(
+        "v_mul_f32 %[tA], %[jA], %[dv]\n\t"
+        "v_mul_f32 %[tB], %[jB], %[dv]\n\t"
+        "v_mul_f32 %[tC], %[jC], %[dv]\n\t"
+        "v_mul_f32 %[tD], %[jD], %[dv]\n\t"
+        "v_permlane32_swap_b32 %[tA], %[tB]\n\t"
+        "s_nop 0\n\t"
+        "v_permlane32_swap_b32 %[tC], %[tD]\n\t"
+        "v_add_f32 %[tA], %[tA], %[tB]\n\t"
+        "v_add_f32 %[tC], %[tC], %[tD]\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %[tA], %[tA], %[tA] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %[tC], %[tC], %[tC] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_cndmask_b32_e64 %[tA], %[tA], %[tC], %[odd]\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %[tA], %[tA], %[tA] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %[tA], %[tA], %[tA] row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %[tA], %[tA], %[tA] row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_mov_b32 %[tB], %[tA]\n\t"
+        "s_nop 1\n\t"
+        "v_permlane16_swap_b32 %[tA], %[tB]\n\t"
+        "v_add_f32 %[tA], %[tA], %[tB]\n\t"
+        "s_nop 0\n\t"
+        "v_readlane_b32 %[sA], %[tA], 14\n\t"
+        "v_readlane_b32 %[sC], %[tA], 15\n\t"
+        "v_readlane_b32 %[sB], %[tA], 46\n\t"
+        "v_readlane_b32 %[sD], %[tA], 47\n\t"
+        "v_subrev_f32 %[xA], %[sA], %[accA]\n\t"
+        "v_subrev_f32 %[xB], %[sB], %[accB]\n\t"
+        "v_subrev_f32 %[xC], %[sC], %[accC]\n\t"
+        "v_subrev_f32 %[xD], %[sD], %[accD]\n\t"
+        "v_max_f32 %[xA], 0, %[xA]\n\t"
+        "v_sub_f32 %[dA], %[xA], %[accA]\n\t"
+        "v_fma_f32 %[xB], -%[c21], %[dA], %[xB]\n\t"
+        "v_fma_f32 %[xC], -%[c31], %[dA], %[xC]\n\t"
+        "v_fma_f32 %[xD], -%[c41], %[dA], %[xD]\n\t"
+        "v_max_f32 %[xB], 0, %[xB]\n\t"
+        "v_mul_f32 %[tA], %[dA], %[mA]\n\t"
+        "v_sub_f32 %[dB], %[xB], %[accB]\n\t"
+        "v_add_f32 %[dv], %[dv], %[tA]\n\t"
+        "v_fma_f32 %[xC], -%[c32], %[dB], %[xC]\n\t"
+        "v_fma_f32 %[xD], -%[c42], %[dB], %[xD]\n\t"
+        "v_mul_f32 %[tB], %[dB], %[mB]\n\t"
+        "v_max_f32 %[xC], 0, %[xC]\n\t"
+        "v_add_f32 %[dv], %[dv], %[tB]\n\t"
+        "v_sub_f32 %[dC], %[xC], %[accC]\n\t"
+        "v_max3_f32 %[lsq], %[lsq], |%[tA]|, |%[tB]|\n\t"
+        "v_fma_f32 %[xD], -%[c43], %[dC], %[xD]\n\t"
+        "v_mul_f32 %[tC], %[dC], %[mC]\n\t"
+        "v_max_f32 %[xD], 0, %[xD]\n\t"
+        "v_add_f32 %[dv], %[dv], %[tC]\n\t"
+        "v_sub_f32 %[dD], %[xD], %[accD]\n\t"
+        "v_mul_f32 %[tD], %[dD], %[mD]\n\t"
+        "v_add_f32 %[dv], %[dv], %[tD]\n\t"
+        "v_max3_f32 %[lsq], %[lsq], |%[tC]|, |%[tD]|\n\t"
+        : [tA] "=&v"(tA), [tB] "=&v"(tB), [tC] "=&v"(tC), [tD] "=&v"(tD), [xA] "=&v"(xA), [xB] "=&v"(xB), [xC] "=&v"(xC),
+          [xD] "=&v"(xD), [dA] "=&v"(dA), [dB] "=&v"(dB), [dC] "=&v"(dC), [dD] "=&v"(dD), [sA] "=&s"(sA), [sB] "=&s"(sB),
+          [sC] "=&s"(sC), [sD] "=&s"(sD), [dv] "+v"(dv), [lsq] "+v"(lsq)
+        : [jA] "v"(jA), [mA] "v"(mA), [jB] "v"(jB), [mB] "v"(mB), [jC] "v"(jC), [mC] "v"(mC), [jD] "v"(jD), [mD] "v"(mD),
+          [accA] "v"(accA), [accB] "v"(accB), [accC] "v"(accC), [accD] "v"(accD), [c21] "v"(c21), [c31] "v"(c31),
+          [c32] "v"(c32), [c41] "v"(c41), [c42] "v"(c42), [c43] "v"(c43), [odd] "s"(odd));
     accA = xA; accB = xB; accC = xC; accD = xD;
 }
 
@@ -195,7 +273,8 @@ __global__ __launch_bounds__(64, 2) void stream_mock(const float* __restrict__ i
     unsigned long long t0;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
     __builtin_amdgcn_s_setprio(3);
-    if (lane < kMO) {
+    const unsigned long long kOdd = 0xAAAAAAAAAAAAAAAAull;
+    if (lane < kMO || (MODE & 8)) {
         for (int it = 0; it < n_iter; it++) {
 #pragma unroll
             for (int s = 0; s < NC; s++)
@@ -212,7 +291,7 @@ __global__ __launch_bounds__(64, 2) void stream_mock(const float* __restrict__ i
                 ACCV += Uv;
             }
             if (WHAT != 2) {
-                if (MODE & 1) {
+                if (MODE & 9) {
                     float4 an = make_float4(L.acc[0][0], L.acc[1][0], L.acc[2][0], L.acc[3][0]);
                     float4 cp = *reinterpret_cast<const float4*>(&L.cn[0][0]);
                     float2 cq = *reinterpret_cast<const float2*>(&L.cn[0][4]);
@@ -225,8 +304,12 @@ __global__ __launch_bounds__(64, 2) void stream_mock(const float* __restrict__ i
                         an = make_float4(L.acc[kn][0], L.acc[kn + 1][0], L.acc[kn + 2][0], L.acc[kn + 3][0]);
                         cp = *reinterpret_cast<const float4*>(&L.cn[kn / 4][0]);
                         cq = *reinterpret_cast<const float2*>(&L.cn[kn / 4][4]);
-                        row_step_normal4<kMO - 1>(NJ[k], NM[k], NJ[k + 1], NM[k + 1], NJ[k + 2], NM[k + 2], NJ[k + 3], NM[k + 3], a0,
-                                                  a1, a2, a3, c.x, c.y, c.z, c.w, e.x, e.y, dv, lsq);
+                        if (MODE & 8)
+                            row_step_normal4t(NJ[k], NM[k], NJ[k + 1], NM[k + 1], NJ[k + 2], NM[k + 2], NJ[k + 3], NM[k + 3], a0, a1, a2,
+                                              a3, c.x, c.y, c.z, c.w, e.x, e.y, kOdd, dv, lsq);
+                        else
+                            row_step_normal4<kMO - 1>(NJ[k], NM[k], NJ[k + 1], NM[k + 1], NJ[k + 2], NM[k + 2], NJ[k + 3], NM[k + 3], a0,
+                                                      a1, a2, a3, c.x, c.y, c.z, c.w, e.x, e.y, dv, lsq);
                         L.acc[k][0] = a0; L.acc[k + 1][0] = a1; L.acc[k + 2][0] = a2; L.acc[k + 3][0] = a3;
                     }
                 } else {
@@ -300,8 +383,8 @@ void run(const char* name, const float* d_in, float* d_out, long long* d_ticks, 
     hipFuncAttributes fa;
     CHECK(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(kern)));
     // issue slots (VALU + s_nop) of one iteration, hand count of the asm blocks
-    const double nrm = WHAT == 2 ? 0.0 : ((MODE & 1) ? (NC / 4) * 56.0 : (NC / 2) * 36.0);
-    const double nrm_valu = WHAT == 2 ? 0.0 : ((MODE & 1) ? (NC / 4) * 56.0 : (NC / 2) * 28.0);
+    const double nrm = WHAT == 2 ? 0.0 : ((MODE & 8) ? (NC / 4) * 52.0 : (MODE & 1) ? (NC / 4) * 56.0 : (NC / 2) * 36.0);
+    const double nrm_valu = WHAT == 2 ? 0.0 : ((MODE & 8) ? (NC / 4) * 45.0 : (MODE & 1) ? (NC / 4) * 56.0 : (NC / 2) * 28.0);
     const double frc = WHAT == 1 ? 0.0 : ((MODE & 2) ? (NC / 2) * 71.0 : NC * 39.0);
     const double frc_valu = WHAT == 1 ? 0.0 : ((MODE & 2) ? (NC / 2) * 70.0 : NC * 31.0);
     const double mot = (MODE & 4) ? 32 * 5.0 : 0.0;
@@ -329,6 +412,43 @@ void run(const char* name, const float* d_in, float* d_out, long long* d_ticks, 
     }
 }
 
+// ---- self-check of the transposed reduction: the four sums against a plain per-row sum on the host
+__global__ void check_kernel(const float* __restrict__ in, float* __restrict__ out) {
+    const int lane = threadIdx.x;
+    float j[4], m[4];
+    for (int r = 0; r < 4; r++) { j[r] = lane < 40 ? in[r * 64 + lane] : 0.f; m[r] = 0.f; }
+    float dv = lane < 40 ? in[4 * 64 + lane] : 0.f;
+    // acc = 1e30 and couplings 0: x = max(acc - s, 0) = acc - s exactly representable?  no: read the sums back through acc = 0
+    // and the sign: x_r = max(0 - s_r, 0); run twice, with the rows as they are and negated
+    for (int sign = 0; sign < 2; sign++) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, lsq = 0.f, d = dv;
+        const float sg = sign ? -1.f : 1.f;
+        row_step_normal4t(sg * j[0], m[0], sg * j[1], m[1], sg * j[2], m[2], sg * j[3], m[3], a0, a1, a2, a3, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f,
+                          0xAAAAAAAAAAAAAAAAull, d, lsq);
+        if (lane == 0) { out[4 * sign + 0] = a0; out[4 * sign + 1] = a1; out[4 * sign + 2] = a2; out[4 * sign + 3] = a3; }
+    }
+}
+
+static void check_transposed(const float* d_in) {
+    float* d_out;
+    CHECK(hipMalloc(&d_out, 8 * sizeof(float)));
+    hipLaunchKernelGGL(check_kernel, dim3(1), dim3(64), 0, nullptr, d_in, d_out);
+    float got[8];
+    CHECK(hipMemcpy(got, d_out, sizeof(got), hipMemcpyDeviceToHost));
+    std::vector<float> h(5 * 64);
+    CHECK(hipMemcpy(h.data(), d_in, h.size() * sizeof(float), hipMemcpyDeviceToHost));
+    double worst = 0;
+    for (int r = 0; r < 4; r++) {
+        double s = 0;
+        for (int l = 0; l < 40; l++) s += (double)h[r * 64 + l] * (double)h[4 * 64 + l];
+        // x = max(-s, 0) for the rows as they are, max(s, 0) for the negated ones
+        const double want0 = s < 0 ? -s : 0, want1 = s > 0 ? s : 0;
+        worst = fmax(worst, fmax(fabs(got[r] - want0), fabs(got[4 + r] - want1)));
+        printf("transposed reduction check: row %d  dot %+.6f  got %+.6f / %+.6f\n", r, s, got[r], got[4 + r]);
+    }
+    printf("transposed reduction check: worst difference %.2e %s\n", worst, worst < 1e-5 ? "(ok)" : "(WRONG)");
+}
+
 int main(int argc, char** argv) {
     const int n_iter = argc > 1 ? atoi(argv[1]) : 2000;
     hipDeviceProp_t prop;
@@ -347,6 +467,7 @@ int main(int argc, char** argv) {
     constexpr int NC = 24;
     run<NC, 0, 1>("normals: normal2 (shipped)", d_in, d_out, d_ticks, n_iter, n_cu);
     run<NC, 1, 1>("normals: normal4", d_in, d_out, d_ticks, n_iter, n_cu);
+    run<NC, 8, 1>("normals: normal4t (transposed)", d_in, d_out, d_ticks, n_iter, n_cu);
     run<NC, 0, 2>("friction: cone (shipped)", d_in, d_out, d_ticks, n_iter, n_cu);
     run<NC, 2, 2>("friction: cone2", d_in, d_out, d_ticks, n_iter, n_cu);
     run<NC, 0, 0>("iteration: normal2 + cone", d_in, d_out, d_ticks, n_iter, n_cu);
@@ -354,5 +475,7 @@ int main(int argc, char** argv) {
     run<NC, 1, 0>("iteration: normal4 + cone", d_in, d_out, d_ticks, n_iter, n_cu);
     run<NC, 4, 0>("iteration + 32 motors: shipped", d_in, d_out, d_ticks, n_iter, n_cu);
     run<NC, 7, 0>("iteration + 32 motors: 4-row", d_in, d_out, d_ticks, n_iter, n_cu);
+    run<NC, 8, 0>("iteration: normal4t + cone", d_in, d_out, d_ticks, n_iter, n_cu);
+    check_transposed(d_in);
     return 0;
 }
