@@ -277,7 +277,8 @@ def test_env_step_parity_random_actions(pkg, oracle_mod, n):
                                   dict(n_modules=16, obstacle=1, obstacle_pos=[0.25, 0.0, 0.1]),
                                   dict(ROUND1, n_modules=16, obstacle=1, obstacle_pos=[0.25, 0.0, 0.1]),
                                   dict(ROUND1, n_modules=16), dict(n_modules=16, warm_start=1),
-                                  dict(n_modules=16, obstacle=2, obstacle_pos=[0.25, 0.0, 0.1])])
+                                  dict(n_modules=16, obstacle=2, obstacle_pos=[0.25, 0.0, 0.1]),
+                                  dict(n_modules=16, contact_order=3), dict(n_modules=32, contact_order=1)])
 def test_outputs_do_not_depend_on_what_ran_before(pkg, monkeypatch, over):
     """Every output of a step -- observation incl. the force sensor, reward, done, substep count, the joint-3 read-out --
     is a function of state and action only: two handles, one created after kernels of ANOTHER configuration have run on

@@ -430,10 +430,13 @@ def test_no_contact_is_left_without_rows(pkg, oracle_mod):
     st.close()
 
 
-def test_env_steps_beyond_64_contacts_match_the_oracle(pkg, oracle_mod, monkeypatch):
+@pytest.mark.parametrize("order", [0, 3])
+def test_env_steps_beyond_64_contacts_match_the_oracle(pkg, oracle_mod, monkeypatch, order):
     """The same inside the fused env-step kernels (scheduled and unscheduled): small random actions keep the snake
     nearly at rest, its manifolds fill up past 64 points, and whole env-steps still match the uncapped oracle from
-    synchronised states; outputs and the counters do not depend on the schedule."""
+    synchronised states; outputs and the counters do not depend on the schedule.  order 3 (snk_params::contact_order): the
+    in-place streamed substep with its ground contacts NOT in the order of their bodies -- the row builder takes them
+    through the Y block -- inside a register-resident kernel."""
     B, n, J = 16, 16, 14
     rng = np.random.default_rng(5)
     acts = [(0.04 * rng.standard_normal((B, 8))).astype(np.float32) for _ in range(J)]
@@ -444,10 +447,10 @@ def test_env_steps_beyond_64_contacts_match_the_oracle(pkg, oracle_mod, monkeypa
         monkeypatch.setenv("SNK_QUANTUM", "1" if quantum == "poison" else str(quantum))
         if quantum == "poison":
             monkeypatch.setenv("SNK_POISON", "1")
-        st = pkg.Stepper(B)
+        st = pkg.Stepper(B, contact_order=order)
         st.reset()
-        refs = [oracle_mod.OracleEnv() for _ in range(B)]
-        ref32 = oracle_mod.OracleEnv(f32=True)
+        refs = [oracle_mod.OracleEnv(contact_order=order) for _ in range(B)]
+        ref32 = oracle_mod.OracleEnv(f32=True, contact_order=order)
         res = []
         worst = cal = 0.0
         mism = 0
