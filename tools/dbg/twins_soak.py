@@ -8,7 +8,8 @@ from test_gpu_env import gait
 pkg = importlib.import_module("bullet-envs_amd")
 STEPS = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 CASES = [(16, 4096, {}), (32, 2048, {}), (16, 4096, dict(warm_start=1)), (16, 2048, dict(obstacle=2, obstacle_pos=[0.12, 0.0, 0.1])),
-         (16, 2048, dict(obstacle=1, obstacle_pos=[0.12, 0.0, 0.1])), (16, 4096, dict(hull_sides=0, contact_model=0, relative_breaking_threshold=0))]
+         (16, 2048, dict(obstacle=1, obstacle_pos=[0.12, 0.0, 0.1])), (16, 4096, dict(hull_sides=0, contact_model=0, relative_breaking_threshold=0)),
+         (16, 4096, dict(contact_order=3)), (32, 2048, dict(contact_order=1))]       # round 6: another sweep order of the manifolds
 bad = 0
 rng = np.random.default_rng(3)
 for n, B, over in CASES:
