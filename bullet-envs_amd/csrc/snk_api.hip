@@ -417,7 +417,7 @@ int snk_create(const snk_params* p, int32_t n_envs, int32_t device, snk_handle**
     if (p->obstacle == 2 && !(p->obstacle_mass > 0.0)) return fail("snk_create: obstacle_mass must be positive");
     if (p->warm_start != 0 && p->warm_start != 1) return fail("snk_create: warm_start must be 0 or 1");
     if (p->friction_directions != 1 && p->friction_directions != 2) return fail("snk_create: friction_directions must be 1 or 2");
-    if (p->contact_order < 0) return fail("snk_create: contact_order must be 0 (link order), 1 (reversed) or k >= 2 (a fixed permutation)");
+    if (p->contact_order < 0) return fail("snk_create: contact_order must be 0 (link order), 1 (reversed), 2 (Bullet's quickSort on equal keys) or k >= 3 (a fixed permutation)");
     if (p->contact_order != 0 && p->contact_model != 1)
         return fail("snk_create: contact_order needs contact_model 1 (it orders the persistent ground manifolds)");
     if (p->warm_start && p->contact_model != 1)

@@ -278,15 +278,37 @@ inline void build_dev_model(const snk_params& P, const HostModel& H, DevModel& D
     D.fricB = P.friction_directions == 1 ? 0.0f : 1.0f;
     D.contact_order = P.contact_order;
     {
-        // The oracle's rule (oracle/snake_oracle.cpp: find_contacts): 1 = reversed; k >= 2 = the cylinder links sorted by
-        // a splitmix-style hash of (k, link).  `link` is the index of the cylinder's link in the unmerged URDF tree with the
+        // The oracle's rule (oracle/snake_oracle.cpp: find_contacts): 1 = reversed; 2 = link order after Bullet's unstable
+        // quickSort on equal keys; k >= 3 = the cylinder links sorted by a splitmix-style hash of (k, link).  `link` is the index of the cylinder's link in the unmerged URDF tree with the
         // root at 0 -- INPUT_INTERFACE_k = 3 k - 1, OUTPUT_BODY_k = 3 k + 1 -- so that both sides sort the same keys.
         const int nc2 = 2 * n;
         unsigned long long key[kMaxCyl];
+        // contact_order 2: where btAlignedObjectArray::quickSort (Hoare partition, pivot = the middle element, `i <= j` swap:
+        // on all-equal keys every partition reverses its range and recurses into the halves) leaves element c of a list
+        // of nc2 equal keys -- the island manager's sort of the plane-link manifolds, restated (oracle: qs_equal_keys)
+        int qs_perm[kMaxCyl], qs_pos[kMaxCyl];
+        for (int c = 0; c < nc2; c++) qs_perm[c] = c;
+        {
+            int stack[2 * kMaxCyl][2], sp = 0;
+            if (nc2 > 1) { stack[sp][0] = 0; stack[sp][1] = nc2 - 1; sp++; }
+            while (sp > 0) {
+                sp--;
+                const int lo = stack[sp][0], hi = stack[sp][1];
+                int i = lo, j = hi;
+                do {
+                    if (i <= j) { const int t = qs_perm[i]; qs_perm[i] = qs_perm[j]; qs_perm[j] = t; i++; j--; }
+                } while (i <= j);
+                // (the two recursive calls work on disjoint ranges: their order does not matter)
+                if (i < hi) { stack[sp][0] = i; stack[sp][1] = hi; sp++; }
+                if (lo < j) { stack[sp][0] = lo; stack[sp][1] = j; sp++; }
+            }
+        }
+        for (int c = 0; c < nc2; c++) qs_pos[qs_perm[c]] = c;
         for (int c = 0; c < nc2; c++) {
             const int link = (c & 1) ? 3 * (c + 1) / 2 + 1 : 3 * c / 2 + 2;
             if (P.contact_order == 0) key[c] = (unsigned long long)c;
             else if (P.contact_order == 1) key[c] = (unsigned long long)(nc2 - 1 - c);
+            else if (P.contact_order == 2) key[c] = (unsigned long long)qs_pos[c];
             else {
                 unsigned long long z = (unsigned long long)P.contact_order * 0x9E3779B97F4A7C15ull + (unsigned long long)(link + 1) * 0xBF58476D1CE4E5B9ull;
                 z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 27; z *= 0x94D049BB133111EBull; z ^= z >> 31;

@@ -118,10 +118,13 @@ typedef struct snk_params {
     int32_t contact_order;      /* 0 (default): the solver sweeps the ground manifolds in link order.  [U]: Bullet hands its
                                    solver the manifolds in the island manager's order, which is not knowable here, and
                                    with 50 unconverged sweeps the order is part of the answer -- the oracle prices other
-                                   orders at -20 % .. +4.5 % of forward motion under the bench gait, the largest entry of
+                                   orders at -3 % .. -24 % of forward motion under the bench gait, the largest entry of
                                    the error bar (profiles/r06_u_rows.json), hence a switch: 1 = link order reversed;
-                                   k >= 2 = the fixed permutation of the cylinder links that sorting by a hash of (k, link)
-                                   gives (the same every substep, as a list of persistent manifolds keeps its order).  A
+                                   2 = link order after the island manager's unstable quickSort on equal island ids (the
+                                   one candidate that can be restated: btAlignedObjectArray::quickSort over the 2n plane-link
+                                   manifolds); k >= 3 = the fixed permutation of the cylinder links that sorting by a hash
+                                   of (k, link) gives (the same every substep, as a list of persistent manifolds keeps its
+                                   order).  A
                                    cylinder's <= 4 points stay together and in their own order.  Needs contact_model 1 */
     int32_t reserved0;          /* 0 */
 } snk_params;

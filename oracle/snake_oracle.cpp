@@ -1410,15 +1410,32 @@ void find_contacts(orc_env* e) {
          * unstable sort over the dispatcher's list), not in link order.  That order is unknown here; what it is worth is
          * priced by sweeping the GROUND manifolds (one per cylinder link: a run of equal `link` among the first
          * `before` contacts, its <= 4 points kept together and in their own order) in other fixed orders:
-         * 1 = reversed, k >= 2 = the permutation of the links that sorting by a hash of (k, link) gives -- the same
-         * permutation in every substep, as a list of persistent manifold objects would keep it. */
+         * 1 = reversed; 2 = the one candidate that can be RESTATED: the island manager sorts its manifold list by island
+         * id with the same unstable btAlignedObjectArray::quickSort as the constraints (buildAndProcessIslands), so IF the
+         * dispatcher's list held exactly the 2n plane-link manifolds in link order (no link-link pair's manifold among
+         * them), the solver would meet them in qs_equal_keys(2n)'s order; k >= 3 = the permutation of the links that
+         * sorting by a hash of (k, link) gives.  The same permutation in every substep, as a list of persistent manifold
+         * objects would keep it. */
+        std::vector<int> qs_pos;
+        if (e->P.contact_order == 2) {
+            const int nc2 = 2 * e->n;
+            std::vector<int> perm(nc2);
+            qs_equal_keys(nc2, perm.data());          /* perm[position] = cylinder (in link order) */
+            qs_pos.assign(nc2, 0);
+            for (int k2 = 0; k2 < nc2; k2++) qs_pos[perm[k2]] = k2;
+        }
         std::vector<std::pair<unsigned long long, std::pair<size_t, size_t>>> runs;
         for (size_t a0 = 0; a0 < before;) {
             size_t a1 = a0;
             while (a1 < before && e->contacts[a1].link == e->contacts[a0].link) a1++;
             unsigned long long key;
             if (e->P.contact_order == 1) key = ~(unsigned long long)a0;                 /* reversed */
-            else {
+            else if (e->P.contact_order == 2) {
+                /* the cylinder's index in link order: INPUT_INTERFACE_k sits on link 3 k - 1, OUTPUT_BODY_k on 3 k + 1 */
+                const int link = e->contacts[a0].link;
+                const int cyl = (link - 2) % 3 == 0 ? 2 * (link - 2) / 3 : 2 * (link - 1) / 3 - 1;
+                key = (unsigned long long)qs_pos[cyl];
+            } else {
                 unsigned long long z = (unsigned long long)e->P.contact_order * 0x9E3779B97F4A7C15ull + (unsigned long long)(e->contacts[a0].link + 1) * 0xBF58476D1CE4E5B9ull;
                 z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 27; z *= 0x94D049BB133111EBull; z ^= z >> 31;
                 key = z;

@@ -134,8 +134,10 @@ typedef struct orc_params {
                                * 1 [U]: the order btMultiBodyDynamicsWorld::solveConstraints hands the solver -- the world's
                                * list [limit_1..limit_n, motor_1..motor_n] after btAlignedObjectArray::quickSort on equal
                                * island ids (not stable: a fixed non-identity permutation, orc_quicksort_equal_keys)    */
-    int32_t contact_order;    /* 0 (default): ground manifolds in link order.  1: reversed.  k >= 2: the fixed permutation
-                               * of the links a hash of (k, link) gives.  Bullet's island-manager order is unknown [U]  */
+    int32_t contact_order;    /* 0 (default): ground manifolds in link order.  1: reversed.  2: link order after the island
+                               * manager's unstable quickSort on equal island ids (orc_quicksort_equal_keys over the 2n
+                               * plane-link manifolds: the restatable candidate).  k >= 3: the fixed permutation of the links
+                               * a hash of (k, link) gives.  Bullet's island-manager order is unknown [U]               */
 } orc_params;
 
 typedef struct orc_env orc_env;

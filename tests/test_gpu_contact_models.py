@@ -38,9 +38,10 @@ SWITCHES = {
     "default+warm": dict(warm_start=1),
     "default+pyramid": dict(cone_friction=0),                            # two friction rows, box bounds, no implicit cone
     "default+1dir": dict(friction_directions=1),                         # no SOLVER_USE_2_FRICTION_DIRECTIONS: one row per contact
-    # the ORDER in which the solver sweeps the ground manifolds (round 6: the largest entry of the error bar, -20 % .. +4.5 %
+    # the ORDER in which the solver sweeps the ground manifolds (round 6: the largest entry of the error bar, -3 % .. -24 %
     # of forward motion in the oracle, profiles/r06_u_rows.json): link order reversed, and one fixed permutation
     "default+reversed": dict(contact_order=1),
+    "default+qsort": dict(contact_order=2),                              # link order after Bullet's quickSort on equal island ids
     "default+perm3": dict(contact_order=3),
 }
 
@@ -91,7 +92,8 @@ def _ground_states(B, n=16, seed=0):
 
 @pytest.mark.parametrize("name,n", [("round1", 16), ("hull", 16), ("manifold", 16), ("hull+manifold@0.02", 16),
                                     ("default", 16), ("default+warm", 16), ("default+warm", 32),
-                                    ("default+reversed", 16), ("default+perm3", 16), ("default+reversed", 32), ("default+perm3", 32)])
+                                    ("default+reversed", 16), ("default+perm3", 16), ("default+reversed", 32), ("default+perm3", 32),
+                                    ("default+qsort", 16), ("default+qsort", 32)])
 def test_substep_parity_under_contact_switch(pkg, oracle_mod, name, n):
     over = dict(SWITCHES[name], n_modules=n, self_collision=0)
     B, K = (48, 3) if n == 16 else (36, 3)     # (round 5: 12 for 32 links -- 36 samples, too few for a 90th percentile)
@@ -173,7 +175,7 @@ def test_substep_parity_under_contact_switch(pkg, oracle_mod, name, n):
     st.close()
 
 
-@pytest.mark.parametrize("n,order", [(16, 0), (32, 0), (16, 3), (32, 3), (16, 1)])
+@pytest.mark.parametrize("n,order", [(16, 0), (32, 0), (16, 3), (32, 3), (16, 1), (16, 2), (32, 2)])
 def test_manifold_parity_from_gait_states(pkg, oracle_mod, n, order):
     """Hull + persistent manifold from states the gait itself produces (a populated contact cache, the snake in
     motion on the ground), both chain lengths: state AND cache are handed to the oracle, then K substeps are compared.

@@ -281,7 +281,7 @@ def test_row_order_switches_keep_the_physics_and_change_the_numbers(oracle_mod):
     unconverged sweeps compute."""
     import bench
     n = 16
-    for over in (dict(noncontact_order=1), dict(contact_order=1), dict(contact_order=3), dict(noncontact_order=1, contact_order=4)):
+    for over in (dict(noncontact_order=1), dict(contact_order=1), dict(contact_order=2), dict(contact_order=3), dict(noncontact_order=1, contact_order=4)):
         e = oracle_mod.OracleEnv(residual_threshold=0.0, **over)
         e.reset()
         for _ in range(240):
@@ -294,6 +294,11 @@ def test_row_order_switches_keep_the_physics_and_change_the_numbers(oracle_mod):
         assert len(set(runs)) == len(runs)
         if over.get("contact_order") == 1:
             assert runs == sorted(runs, reverse=True)
+        elif over.get("contact_order") == 2:
+            # link order after Bullet's quickSort on 32 equal keys: cylinder c sits on link 3 c / 2 + 2 (c even) or
+            # 3 (c + 1) / 2 + 1 (c odd); a snake at rest has every cylinder on the ground
+            want = [(3 * c // 2 + 2 if c % 2 == 0 else 3 * (c + 1) // 2 + 1) for c in oracle_mod.quicksort_equal_keys(2 * n)]
+            assert runs == want, (runs, want)
         elif over.get("contact_order"):
             assert runs != sorted(runs) and runs != sorted(runs, reverse=True)
         else:

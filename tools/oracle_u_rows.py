@@ -15,7 +15,10 @@ Round 6 adds the two rules about ROW ORDER:
   noncontact_order 1       the non-contact rows in the order btAlignedObjectArray::quickSort leaves the world's constraint list
                            [limit_1..limit_16, motor_1..motor_16] in (equal island ids; Hoare partition, not stable): the motors
                            first, as 5 4 7 6 1 0 3 2 13 12 15 14 9 8 11 10, then the limits
-  contact_order 1, 2, 3, 4 the ground manifolds reversed / in three fixed pseudo-random orders instead of link order
+  contact_order 1          the ground manifolds reversed
+  contact_order 2          ... in link order after the island manager's quickSort on equal island ids (the same unstable sort,
+                           over the 32 plane-link manifolds: the one candidate that can be restated)
+  contact_order 3, 4, 5    ... in three fixed pseudo-random orders
 
 Writes profiles/r06_u_rows.json (all rows, round 5's included); prints the table.  CPU only."""
 import json
@@ -44,14 +47,16 @@ ROWS = [
     ("cone_friction 0 (pyramid, two directions)", dict(cone_friction=0)),
     ("noncontact_order 1 (quickSort on equal island ids)", dict(noncontact_order=1)),
     ("contact_order 1 (manifolds reversed)", dict(contact_order=1)),
-    ("contact_order 2 (fixed permutation A)", dict(contact_order=2)),
-    ("contact_order 3 (fixed permutation B)", dict(contact_order=3)),
-    ("contact_order 4 (fixed permutation C)", dict(contact_order=4)),
+    ("contact_order 2 (link order after Bullet's quickSort on equal island ids)", dict(contact_order=2)),
+    ("contact_order 3 (fixed permutation A)", dict(contact_order=3)),
+    ("contact_order 4 (fixed permutation B)", dict(contact_order=4)),
+    ("contact_order 5 (fixed permutation C)", dict(contact_order=5)),
+    ("noncontact_order 1 + contact_order 2 (both quickSorts)", dict(noncontact_order=1, contact_order=2)),
     ("noncontact_order 1 + contact_order 1", dict(noncontact_order=1, contact_order=1)),
 ]
 out = {}
 base = None
-print("%-52s %9s %8s %10s %10s %9s %8s" % ("switch", "substeps", "ends", "reward", "dx", "contacts", "dx vs default"))
+print("%-76s %9s %8s %10s %10s %9s %8s" % ("switch", "substeps", "ends", "reward", "dx", "contacts", "dx vs default"))
 for name, over in ROWS:
     _, _, agg = orc.bench_gait(B, bench.env_phases(ids), 0, T, threads, want_agg=True, max_contacts=0, **over)
     agg = {k: float(v) for k, v in agg.items()}
@@ -59,7 +64,7 @@ for name, over in ROWS:
         base = agg
     agg["dx_rel_to_default"] = agg["mean_dx"] / base["mean_dx"] - 1.0
     out[name] = dict(switches=over, oracle=agg)
-    print("%-52s %9.3f %8.4f %10.5f %10.6f %9.1f %+7.1f %%" % (name, agg["mean_substeps"], agg["episode_end_rate"], agg["mean_reward"],
+    print("%-76s %9.3f %8.4f %10.5f %10.6f %9.1f %+7.1f %%" % (name, agg["mean_substeps"], agg["episode_end_rate"], agg["mean_reward"],
                                                             agg["mean_dx"], agg["mean_contacts"], 100 * agg["dx_rel_to_default"]))
 with open(os.path.join(ROOT, "profiles", "r06_u_rows.json"), "w") as f:
     json.dump(dict(workload="bench gait, %d envs x %d env-steps, float64 oracle, uncapped contacts" % (B, T), rows=out), f, indent=1)
