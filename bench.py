@@ -75,7 +75,7 @@ def _cpu_model():
 
 
 def cpu_baseline(steps=2000, warmup=20, n_links=16, friction_seed=None, hull_sides=32, contact_model=1, warm_start=0,
-                 self_collision=1, one_thread_only=False):
+                 self_collision=1, one_thread_only=False, contact_order=0):
     """BASELINE.md row B3 / SURVEY 8(d): the float64 C++ oracle on the configs[0] action stream, timed from C++
     (oracle/snake_oracle.cpp: orc_bench_gait -- no Python in the timed loop), 1 thread and all cores, `steps`
     env-steps after `warmup` warm-up steps each.  PyBullet itself is probed at run time and reported, never
@@ -102,7 +102,7 @@ def cpu_baseline(steps=2000, warmup=20, n_links=16, friction_seed=None, hull_sid
     # the same model switches as the GPU run (self_collision: inert for 16 links under the gait; the device evaluates
     # the flag for both chains)
     kw = dict(n_modules=n_links, hull_sides=hull_sides, contact_model=contact_model, self_collision=self_collision,
-              warm_start=warm_start)
+              warm_start=warm_start, contact_order=contact_order)
 
     def mu_of(ids):
         return None if friction_seed is None else env_friction(ids, friction_seed)
@@ -357,6 +357,10 @@ def main():
     ap.add_argument("--self-collision", type=int, default=1, choices=(0, 1),
                     help="link-link contacts (the reference's URDF_USE_SELF_COLLISION load flag, snake.py:93): evaluated by "
                          "the 32-link kernels; 0 switches them off (round-1 state of configs[3])")
+    ap.add_argument("--contact-order", type=int, default=0,
+                    help="snk_params::contact_order (DESIGN.md 3): the order in which the solver sweeps the ground manifolds; "
+                         "0 (default) link order, 1 reversed, 2 link order after Bullet's quickSort on equal island ids, "
+                         "k >= 3 fixed permutations -- an error-bar switch, not a BASELINE config")
     ap.add_argument("--cpu-steps", type=int, default=2000,
                     help="env-steps of the CPU baseline (BASELINE.md B3: 2000 after 20 warm-up steps)")
     ap.add_argument("--streamed-rows", action="store_true",
@@ -393,7 +397,7 @@ def main():
         if args.obstacle is None and not args.policy:
             cpu = cpu_baseline(steps=args.cpu_steps, n_links=args.links, friction_seed=args.friction_seed,
                                hull_sides=args.hull_sides, contact_model=args.contact_model, warm_start=args.warm_start,
-                               self_collision=args.self_collision)
+                               self_collision=args.self_collision, contact_order=args.contact_order)
         # (with --obstacle / --policy the C++ gait driver would time another workload than the GPU: no baseline then)
 
     import importlib
@@ -443,6 +447,8 @@ def main():
         os.environ["SNK_FORCE_STREAMED"] = "1"           # read by snk_create
     if args.warm_start:
         extra["warm_start"] = 1
+    if args.contact_order:
+        extra["contact_order"] = args.contact_order
     if args.obstacle is not None:
         extra.update(obstacle=2 if args.obstacle_free else 1, obstacle_pos=[args.obstacle, 0.0, 0.1])
     local = pkg.DeviceVecEnv(E, device_index=local_rank, n_modules=NL, hull_sides=args.hull_sides,
@@ -578,7 +584,7 @@ def main():
         headline_hist = histogram_pass(local, torch, more)
     if (world == 1 and not args.no_variants and not args.policy and NL == 16 and args.hull_sides == 32
             and args.contact_model == 1 and not args.warm_start and args.friction_seed is None
-            and not args.streamed_rows and args.obstacle is None and args.self_collision == 1):
+            and not args.streamed_rows and args.obstacle is None and args.self_collision == 1 and not args.contact_order):
         local.close()
         variants = {}
         Kv = min(K, 50)
@@ -601,7 +607,7 @@ def main():
         # measured in separate --pmc runs of the same command, not in this run; the key names say so.
         cfg_key = ("c%d" % NL) + ("_fric" if args.friction_seed is not None else "") + ("_policy" if args.policy else "") + (
             "_hull%d_cm%d" % (args.hull_sides, args.contact_model) if (args.hull_sides != 32 or args.contact_model != 1) else "") + (
-            "_warm" if args.warm_start else "") + (
+            "_warm" if args.warm_start else "") + ("_order%d" % args.contact_order if args.contact_order else "") + (
             "_nosc" if (NL == 32 and not args.self_collision) else "") + ("_streamed" if args.streamed_rows else "") + (
             ("_obstacle2" if args.obstacle_free else "_obstacle") if args.obstacle is not None else "")
         cfg_index = 3 if NL == 32 else (4 if args.friction_seed is not None else (1 if world == 1 else 2))
@@ -625,6 +631,7 @@ def main():
                 "hull_sides": args.hull_sides, "contact_model": args.contact_model,
                 "relative_breaking_threshold": int(local.params.relative_breaking_threshold),
                 "warm_start": int(local.params.warm_start),
+                "contact_order": int(local.params.contact_order),
                 "contact_overflow": {"substeps_on_streamed_rows": overflow[0], "points_without_rows": overflow[1],
                                      "link_link_or_obstacle_without_rows": overflow[2]},
                 # contact points per physics substep (snk_contact_histogram) over HIST_STEPS further env-steps, counted after
