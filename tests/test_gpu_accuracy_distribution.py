@@ -102,6 +102,14 @@ def test_thirty_two_links(pkg, oracle_mod):
     _check("32 links", pkg, oracle_mod, 32, 1024, 4323, {})
 
 
+@pytest.mark.parametrize("n", [16, 32])
+def test_another_sweep_order_of_the_manifolds(pkg, oracle_mod, n):
+    """snk_params::contact_order 2 (round 6): link order after Bullet's unstable quickSort on equal island ids -- the compact
+    contact list laid out in the sweep's order, for both solves (the 32-link row builder then takes its ground contacts
+    through the Y block): the same distribution gate as under link order."""
+    _check("%d links, contact_order 2" % n, pkg, oracle_mod, n, 512, 4330 + n, dict(contact_order=2))
+
+
 def test_folded_snakes(pkg, oracle_mod):
     """Joint angles up to 1.7 rad: beyond the limits (limit rows), links folded onto each other (link-link contacts: the
     substep goes through the streamed-row solve).  tools/dbg/acc_sweep3.sh."""

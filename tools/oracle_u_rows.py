@@ -53,6 +53,11 @@ ROWS = [
     ("contact_order 5 (fixed permutation C)", dict(contact_order=5)),
     ("noncontact_order 1 + contact_order 2 (both quickSorts)", dict(noncontact_order=1, contact_order=2)),
     ("noncontact_order 1 + contact_order 1", dict(noncontact_order=1, contact_order=1)),
+    # context, not a [U] rule (Bullet's world runs 50 iterations): where the two orders go when the solve is allowed to converge
+    ("n_iterations 200, link order", dict(n_iterations=200)),
+    ("n_iterations 200, contact_order 2", dict(n_iterations=200, contact_order=2)),
+    ("n_iterations 1000, link order", dict(n_iterations=1000)),
+    ("n_iterations 1000, contact_order 2", dict(n_iterations=1000, contact_order=2)),
 ]
 out = {}
 base = None
