@@ -567,6 +567,10 @@ def main():
     if dist is not None:
         ranks = [None] * world
         dist.all_gather_object(ranks, rank_info)
+    else:
+        ranks = [rank_info]
+    # the record must show every rank's own time, not only the maximum (a straggler is then visible)
+    assert len(ranks) == world and all(r is not None and "ms_per_step" in r and "kernel_ms" in r for r in ranks), ranks
 
     # [0] substeps that went through the streamed-row solve because their contacts outgrew the register-resident one's
     # slots (16 links), [1] [2] contacts left without rows: must be zeros
