@@ -764,6 +764,37 @@ def test_bench_multi_rank_rehearsal():
     pids = {k["pid"] for k in r["config"]["ranks"]}
     assert len(pids) == 2 and os.getpid() not in pids, r["config"]["ranks"]
     assert sorted(k["rank"] for k in r["config"]["ranks"]) == [0, 1]
+    # round 6: every rank's own time in the record, the entry point named, both timed regions
+    assert all(k["ms_per_step"] > 0 and k["kernel_ms"] > 0 for k in r["config"]["ranks"])
+    assert r["config"]["api"] == "ShardedVecEnv.step_block" and "H2D of the step's action block" in r["config"]["timed_region"]
+    assert r["actions_resident"]["value"] > 0 and r["actions_resident"]["ms_per_step"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_line_contract_and_profile_form():
+    """The bench line's round-6 fields on one GPU, small and quick: the action upload inside the timed region (named in
+    config.timed_region), the actions-resident rate beside it, the entry point, rank 0's own time; and `--profile`, the form
+    rocprofv3 is put around: W + K launches and nothing else -- no second timed region, no contact histogram, no CPU
+    baseline, no variants (tools/summarize_prof.py relies on exactly W + K launches of the step kernel)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "SNK_BENCH_BACKEND")}
+    base = [sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--envs-per-gpu", "512"]
+    out = subprocess.run(base + ["--no-cpu-baseline", "--no-variants"], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert r["n_gpus"] == 1 and r["unit"] == "env-steps/s" and r["dtype"] == "f32" and r["vs_baseline"] is None
+    assert r["config"]["api"] == "DeviceVecEnv.step" and "H2D of the step's action block" in r["config"]["timed_region"]
+    assert r["actions_resident"]["value"] > 0 and r["config"]["contacts_per_substep"]["substeps"] > 0
+    assert r["config"]["ranks"][0]["ms_per_step"] > 0 and r["config"]["contact_order"] == 0
+    assert r["roofline"]["bound"] == "hbm" and 0 < r["roofline"]["frac"] < 1 and r["roofline"]["launches"] == 3
+    out = subprocess.run(base + ["--profile"], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    p = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert p["actions_resident"] is None and p["config"]["contacts_per_substep"] is None
+    assert p["cpu_baseline"] is None and p["variants"] is None and p["roofline"]["launches"] == 3
 
 
 @pytest.mark.gpu
