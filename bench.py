@@ -9,8 +9,8 @@
 A "step" is one batched SnakeGymEnv.step over 4096 envs per GPU (BASELINE.json configs[1] at
 N=1, configs[2] at N>1): the fused env-step kernel (0..41 physics substeps per env, reward,
 termination, auto-reset), for N>1 the RCCL actions scatter and the packed obs/reward/done
-gather to rank 0, and on rank 0 the asynchronous D2H copy of obs/reward/done into pinned host
-memory (the trainers are host-side).  Actions ("serpenoid gait") are
+gather to rank 0, and on rank 0 the asynchronous D2H copy of the [obs | reward | done] block
+into pinned host memory (the trainers are host-side).  Actions ("serpenoid gait") are
 precomputed into ONE pinned host buffer and uploaded step by step INSIDE the timed region, on
 the launch stream, as SURVEY §8(d) defines the metric ("including action upload and
 obs/reward/done availability at the trainer rank"; ppo/train.py:122 pays that copy every
@@ -246,30 +246,27 @@ def measure_variant(pkg, torch, dev, device_index, E, NL, K, W, friction_seed=No
     for j in range(W + K + HIST_STEPS):
         acts[j] = torch.from_numpy(gait_actions(gids, j, A).astype(np.float32))
     a_dev = torch.empty((E, A), dtype=torch.float32, device=dev)
-    h_obs = torch.empty((E, env.obs_dim), dtype=torch.float32).pin_memory()
-    h_rew = torch.empty((E,), dtype=torch.float32).pin_memory()
-    h_done = torch.empty((E,), dtype=torch.uint8).pin_memory()
+    O = env.obs_dim
+    h_all = torch.empty((E, O + 2), dtype=torch.float32).pin_memory()        # rows [obs | reward | done], one D2H copy per step
+    pack_dev = torch.zeros((E, O + 2), dtype=torch.float32, device=dev)
+    sub_rows = torch.zeros((K, E), dtype=torch.int32, device=dev)            # substep counts, reduced after the timed region
     env.reset()
-    sub = torch.zeros((), dtype=torch.int64, device=dev)
 
-    def step(j):
+    def step(j, row=None):
         a_dev.copy_(acts[j], non_blocking=True)
-        obs, rew, done = env.step(a_dev)
-        h_obs.copy_(obs, non_blocking=True)
-        h_rew.copy_(rew, non_blocking=True)
-        h_done.copy_(done, non_blocking=True)
+        env.step_packed(a_dev, pack_dev, substeps=None if row is None else sub_rows[row])
+        h_all.copy_(pack_dev, non_blocking=True)
     for j in range(W):
         step(j)
     torch.cuda.synchronize()
     env.stepper.timing_enable(K)
     t0 = time.perf_counter()
     for j in range(W, W + K):
-        step(j)
-        sub.add_(env.substeps.sum())
+        step(j, j - W)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     kernel_ms, kcount = env.stepper.timing_read()
-    nsub = float(sub.item())
+    nsub = float(sub_rows.sum().item())
     ov = env.stepper.contact_overflow()
     hist = histogram_pass(env, torch, [acts[j].to(dev) for j in range(W + K, W + K + HIST_STEPS)])
     out = {"value": E * K / el, "unit": "env-steps/s", "steps": K, "warmup": W, "ms_per_step": 1e3 * el / K,
@@ -475,9 +472,14 @@ def main():
             h_all = torch.empty((world * E, O + 2), dtype=torch.float32).pin_memory()
             h_obs, h_rew, h_done = h_all[:, :O], h_all[:, O], h_all.view(torch.int32)[:, O + 1]
         else:
-            h_obs = torch.empty((E, O), dtype=torch.float32).pin_memory()
-            h_rew = torch.empty((E,), dtype=torch.float32).pin_memory()
-            h_done = torch.empty((E,), dtype=torch.uint8).pin_memory()      # the kernel's own done bytes (0 / 1)
+            # N = 1: the step kernel writes rows [obs | reward | done] of one block (snk_step_packed, what the sharded path
+            # gathers) and the block goes to the host in ONE copy (rounds 1-5: three tensors, three copies)
+            h_all = torch.empty((E, O + 2), dtype=torch.float32).pin_memory()
+            h_obs, h_rew, h_done = h_all[:, :O], h_all[:, O], h_all.view(torch.int32)[:, O + 1]
+            pack_dev = torch.zeros((E, O + 2), dtype=torch.float32, device=dev)
+    # Snake.counter of every env, one row per step of a timed region: the mean substep count is a statistic of the run,
+    # reduced AFTER the region (rounds 1-5 reduced it after every step: two small kernels per step on the launch stream)
+    sub_rows = torch.zeros((max(K, 1), E), dtype=torch.int32, device=dev)
     sub_total = torch.zeros((), dtype=torch.int64, device=dev)
 
     if world > 1:
@@ -490,25 +492,28 @@ def main():
         assert world == 1, "--policy measures one GPU"
         torch.manual_seed(0)
         net = pkg.rollout.ActorCritic(local.obs_dim, A, [256, 256]).to(dev)
-        pol_state = {"obs": local.obs}
+        pol_state = {"obs": local.obs, "h_obs": torch.empty((E, local.obs_dim), dtype=torch.float32).pin_memory(),
+                     "h_rew": torch.empty((E,), dtype=torch.float32).pin_memory(),
+                     "h_done": torch.empty((E,), dtype=torch.uint8).pin_memory()}
 
-    def one_step(j, resident=False):
+    def one_step(j, resident=False, row=None):
+        # row: the row of sub_rows this step's substep counts go to (None: warm-up, into the env's own buffer)
         if net is not None:
             with torch.no_grad():
                 mu, sigma, _value = net.heads(pol_state["obs"])
                 act = torch.normal(mu, sigma)
             obs, rew, done = local.step(act)
             sub_total.add_(local.substeps.sum())
-            h_obs.copy_(obs, non_blocking=True)
-            h_rew.copy_(rew, non_blocking=True)
-            h_done.copy_(done, non_blocking=True)
+            pol_state["h_obs"].copy_(obs, non_blocking=True)
+            pol_state["h_rew"].copy_(rew, non_blocking=True)
+            pol_state["h_done"].copy_(done, non_blocking=True)
             return
         # resident: the second timed region -- the action block is in HBM already (rounds 1-5's headline)
         if world > 1:
             # the root hands step_block() its pinned host block (H2D inside, non-blocking, then the scatter) or, in the
             # second region, the block resident on its device
-            blk = env.step_block((acts_res[j - W - K] if resident else h_acts[j]) if rank == 0 else None)
-            sub_total.add_(local.substeps.sum())
+            blk = env.step_block((acts_res[j - W - K] if resident else h_acts[j]) if rank == 0 else None,
+                                 substeps=None if row is None else sub_rows[row])
             if rank == 0:     # trainer side: the whole block to pinned host memory, one contiguous D2H copy
                 h_all.copy_(blk, non_blocking=True)
             return
@@ -517,24 +522,22 @@ def main():
         else:
             acts_dev.copy_(h_acts[j], non_blocking=True)      # 128 KiB H2D on the launch stream, in front of the step
             a_j = acts_dev
-        obs, rew, done = local.step(a_j)
-        sub_total.add_(local.substeps.sum())
-        # trainer side: results to pinned host memory (three contiguous tensors, three copies, no kernel)
-        h_obs.copy_(obs, non_blocking=True)
-        h_rew.copy_(rew, non_blocking=True)
-        h_done.copy_(done, non_blocking=True)
+        local.step_packed(a_j, pack_dev, substeps=None if row is None else sub_rows[row])
+        # trainer side: obs / reward / done to pinned host memory, one contiguous D2H copy of the block
+        h_all.copy_(pack_dev, non_blocking=True)
 
     def timed_region(j0, resident):
         """K steps j0 .. j0 + K - 1 bracketed by barrier + synchronize on both sides; returns (this rank's seconds,
         the maximum over ranks, substeps of all ranks, this rank's substeps, HIP-event kernel ms, launches)."""
         sub_total.zero_()
+        sub_rows.zero_()
         local.stepper.timing_enable(K)
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for j in range(j0, j0 + K):
-            one_step(j, resident)
+            one_step(j, resident, j - j0)
         torch.cuda.synchronize()
         t_own = time.perf_counter() - t0            # this rank's own K steps (a straggler shows in config.ranks)
         if dist is not None:
@@ -542,6 +545,8 @@ def main():
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
         k_ms, k_n = local.stepper.timing_read()
+        if net is None:
+            sub_total.add_(sub_rows.sum())           # (the policy path keeps its per-step reduction)
         t_el = torch.tensor([el], dtype=torch.float64, device=dev)
         subs = sub_total.to(torch.float64).reshape(1)
         loc = float(subs.item())
@@ -647,9 +652,10 @@ def main():
                 "world_size": (dist.get_world_size() if dist is not None else 1),
                 "backend": (dist.get_backend() if dist is not None else None),
                 "ranks": ranks,
-                # the entry point inside the timed loop: N = 1 DeviceVecEnv.step (tensors in, tensors out),
+                # the entry point inside the timed loop: N = 1 DeviceVecEnv.step_packed (tensors in, one [obs | reward |
+                # done] block out: snk_step_packed, the same C entry point the sharded path uses),
                 # N > 1 ShardedVecEnv.step_block (the gathered [obs | reward | done] block, one D2H copy on the root)
-                "api": "ShardedVecEnv.step_block" if world > 1 else "DeviceVecEnv.step",
+                "api": "ShardedVecEnv.step_block" if world > 1 else "DeviceVecEnv.step_packed",
                 "timed_region": "per step: H2D of the step's action block from pinned host memory (%d B), %sthe fused "
                                 "env-step kernel, %sD2H of obs / reward / done to pinned host memory" % (
                                     world * E * A * 4, "RCCL scatter, " if world > 1 else "",

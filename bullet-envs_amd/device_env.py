@@ -43,16 +43,25 @@ class DeviceVecEnv(object):
         self.stepper.reset_device(0, self.obs.data_ptr(), self._stream())
         return self.obs
 
-    def step(self, actions, vec_mode=True):
+    def _sub_ptr(self, substeps):
+        """where Snake.counter of this step goes: self.substeps, or a caller's int32 CUDA tensor [E] (a row of a per-step
+        log, say: a rollout can then look at the counts after its last step instead of reducing them after every one)"""
+        if substeps is None:
+            return self.substeps.data_ptr()
+        t = self.torch
+        assert substeps.is_cuda and substeps.dtype == t.int32 and substeps.is_contiguous() and substeps.numel() == self.num_envs
+        return substeps.data_ptr()
+
+    def step(self, actions, vec_mode=True, substeps=None):
         """actions: float32 CUDA tensor [E, A], contiguous; clipped in place.  Asynchronous."""
         t = self.torch
         assert actions.is_cuda and actions.dtype == t.float32 and actions.is_contiguous()
         assert tuple(actions.shape) == (self.num_envs, self.act_dim)
         self.stepper.step_device(actions.data_ptr(), self.obs.data_ptr(), self.rew.data_ptr(),
-                                 self.done.data_ptr(), self.substeps.data_ptr(), vec_mode, self._stream())
+                                 self.done.data_ptr(), self._sub_ptr(substeps), vec_mode, self._stream())
         return self.obs, self.rew, self.done
 
-    def step_packed(self, actions, packed, vec_mode=True):
+    def step_packed(self, actions, packed, vec_mode=True, substeps=None):
         """The same step, written by the kernel as rows [obs | reward | done] of `packed` ([E, >= O + 2] float32 on this
         device; the done cell holds the integer 0 / 1): the block a sharded env gathers (snk_step_packed).  self.obs /
         rew / done are NOT updated by this call.  Asynchronous."""
@@ -61,7 +70,7 @@ class DeviceVecEnv(object):
         assert tuple(actions.shape) == (self.num_envs, self.act_dim)
         assert packed.is_cuda and packed.dtype == t.float32 and packed.is_contiguous()
         assert packed.shape[0] == self.num_envs and packed.shape[1] >= self.obs_dim + 2
-        self.stepper.step_packed_device(actions.data_ptr(), packed.data_ptr(), packed.shape[1], self.substeps.data_ptr(),
+        self.stepper.step_packed_device(actions.data_ptr(), packed.data_ptr(), packed.shape[1], self._sub_ptr(substeps),
                                         vec_mode, self._stream())
         return packed
 
@@ -157,7 +166,7 @@ class ShardedVecEnv(object):
         # the done cell holds the integer 0 / 1 (its bits travel in the float32 block)
         return allp[:, :self.O], allp[:, self.O], allp.view(t.int32)[:, self.O + 1] != 0, infos
 
-    def step_block(self, actions=None):
+    def step_block(self, actions=None, substeps=None):
         """One collective env-step; on the root returns the contiguous [world * E, O + 2] float32 block on `device`
         (rows [obs | reward | done as int32 bits], env g in row g), None elsewhere.  Valid until the next call."""
         t = self.torch
@@ -175,7 +184,11 @@ class ShardedVecEnv(object):
         # snk_step_packed): nothing is copied between the physics and the gather
         a_loc = self._act if self._xdev == self.device else self._act.to(self.device)
         if self._packed_step:
-            self.env.step_packed(a_loc, self._pack)
+            # (substeps: where the local env's substep counts of this step go -- DeviceVecEnv.step_packed's argument)
+            if substeps is not None:
+                self.env.step_packed(a_loc, self._pack, substeps=substeps)
+            else:
+                self.env.step_packed(a_loc, self._pack)
         else:
             # a local env with the plain contract: its results copied into the block (three small copies per step)
             obs, rew, done = self.env.step(a_loc)

@@ -786,7 +786,7 @@ def test_bench_line_contract_and_profile_form():
     assert out.returncode == 0, out.stderr[-2000:]
     r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert r["n_gpus"] == 1 and r["unit"] == "env-steps/s" and r["dtype"] == "f32" and r["vs_baseline"] is None
-    assert r["config"]["api"] == "DeviceVecEnv.step" and "H2D of the step's action block" in r["config"]["timed_region"]
+    assert r["config"]["api"] == "DeviceVecEnv.step_packed" and "H2D of the step's action block" in r["config"]["timed_region"]
     assert r["actions_resident"]["value"] > 0 and r["config"]["contacts_per_substep"]["substeps"] > 0
     assert r["config"]["ranks"][0]["ms_per_step"] > 0 and r["config"]["contact_order"] == 0
     assert r["roofline"]["bound"] == "hbm" and 0 < r["roofline"]["frac"] < 1 and r["roofline"]["launches"] == 3
